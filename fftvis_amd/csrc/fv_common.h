@@ -1,0 +1,107 @@
+// fv_common.h -- shared host/device helpers for libfftvis_hip (gfx950 only).
+#pragma once
+
+#include "../../include/fftvis_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace fv {
+
+// Status codes returned across the C ABI are the FV_* macros of include/fftvis_hip.h.
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define FV_HIP(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            throw fv::Error(FV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define FV_ROCFFT(expr)                                                                        \
+    do {                                                                                       \
+        rocfft_status _s = (expr);                                                             \
+        if (_s != rocfft_status_success)                                                       \
+            throw fv::Error(FV_ERR_ROCFFT, std::string(#expr) + ": rocfft status " +       \
+                                                   std::to_string((int)_s));                   \
+    } while (0)
+
+#define FV_REQUIRE(cond, msg)                                        \
+    do {                                                             \
+        if (!(cond)) throw fv::Error(FV_ERR_ARG, std::string(msg)); \
+    } while (0)
+
+// Growable device buffer owned by a plan / engine (never shrinks; freed in dtor).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) FV_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        FV_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+    }
+    template <typename U>
+    U *as() const {
+        return reinterpret_cast<U *>(p);
+    }
+};
+
+template <typename T>
+struct cplx {
+    T re, im;
+};
+
+template <typename T>
+__host__ __device__ inline cplx<T> cmul(cplx<T> a, cplx<T> b) {
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+template <typename T>
+__host__ __device__ inline cplx<T> cconj(cplx<T> a) {
+    return {a.re, -a.im};
+}
+template <typename T>
+__host__ __device__ inline cplx<T> cadd(cplx<T> a, cplx<T> b) {
+    return {a.re + b.re, a.im + b.im};
+}
+template <typename T>
+__host__ __device__ inline cplx<T> cscale(cplx<T> a, T s) {
+    return {a.re * s, a.im * s};
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Smallest even integer >= n whose only prime factors are 2, 3, 5 (rocFFT's fast sizes).
+inline int next235even(int n) {
+    if (n <= 2) return 2;
+    if (n % 2) ++n;
+    for (;; n += 2) {
+        int m = n;
+        while (m % 2 == 0) m /= 2;
+        while (m % 3 == 0) m /= 3;
+        while (m % 5 == 0) m /= 5;
+        if (m == 1) return n;
+    }
+}
+
+}  // namespace fv

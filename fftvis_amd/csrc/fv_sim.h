@@ -1,0 +1,748 @@
+// fv_sim.h -- the fused visibility simulator: per time  rotate -> horizon compaction -> az/za;
+// per frequency group  beam x coherency strengths -> type-3 NUFFT (spread, rocFFT, gather).
+//
+// GPU twin of CPUSimulationEngine._evaluate_vis_chunk (src/fftvis/cpu/cpu_simulate.py:856-1071).
+// Loop order follows the reference (time -> frequency -> beam pair); what differs is that a
+// block of neighbouring frequencies shares one fine grid geometry, so their strengths ride one
+// spread launch and one batched FFT as extra "transforms" (DESIGN.md "Frequency groups").
+#pragma once
+
+#include "fv_nufft.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <memory>
+
+namespace fv {
+
+constexpr double SPEED_OF_LIGHT = 299792458.0;  // core/utils.py:9
+
+struct BeamDesc {
+    int kind;            // 0 Airy, 1 table
+    double diameter;     // Airy
+    const void *table;   // device
+    int nfreq_tab, nza, naz;
+    double za_max;
+};
+
+// ---------------------------------------------------------------------------------------------
+// per-time kernels
+// ---------------------------------------------------------------------------------------------
+struct Rot9 {
+    double m[9];
+};
+
+// Pass 1: above-horizon flag count per 256-source block (select_chunk's up > 0,
+// cpu_simulate.py:940-946 via matvis).
+template <typename T>
+__global__ void k_horizon_count(int64_t nsrc, const T *__restrict__ eq, Rot9 rt,
+                                int *__restrict__ block_counts) {
+    __shared__ int wsum[4];
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool up = false;
+    if (j < nsrc) {
+        double ex = eq[j], ey = eq[nsrc + j], ez = eq[2 * nsrc + j];
+        up = rt.m[6] * ex + rt.m[7] * ey + rt.m[8] * ez > 0.0;
+    }
+    unsigned long long b = __ballot(up);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Pass 2: stable compaction + everything that depends only on (time, source):
+//   topo = R_t eq;  az, za in the UN-rotated ENU frame (cpu_simulate.py:957-959, matvis
+//   enu_to_az_za "uvbeam");  x = 2 pi R_plane topo (cpu_simulate.py:961-967).
+template <typename T>
+__global__ void k_horizon_compact(int64_t nsrc, const T *__restrict__ eq, Rot9 rt, Rot9 rp,
+                                  const int *__restrict__ block_off, T *__restrict__ xyz,
+                                  int64_t cap, T *__restrict__ az, T *__restrict__ za,
+                                  int *__restrict__ src_idx) {
+    __shared__ int wsum[4];
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double e = 0, n = 0, u = -1;
+    if (j < nsrc) {
+        double ex = eq[j], ey = eq[nsrc + j], ez = eq[2 * nsrc + j];
+        e = rt.m[0] * ex + rt.m[1] * ey + rt.m[2] * ez;
+        n = rt.m[3] * ex + rt.m[4] * ey + rt.m[5] * ez;
+        u = rt.m[6] * ex + rt.m[7] * ey + rt.m[8] * ez;
+    }
+    const bool up = j < nsrc && u > 0.0;
+    unsigned long long b = __ballot(up);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = __popcll(b);
+    __syncthreads();
+    int base = block_off[blockIdx.x];
+    for (int i = 0; i < wv; ++i) base += wsum[i];
+    if (!up) return;
+    const int64_t pos = base + __popcll(b & ((1ull << lane) - 1ull));
+    const double lsqr = n * n + e * e;
+    const double zeta = sqrt(fmax(0.0, 1.0 - lsqr));
+    double azv = 0.5 * M_PI - atan2(e, n);
+    azv = fmod(azv, 2.0 * M_PI);
+    if (azv < 0) azv += 2.0 * M_PI;
+    az[pos] = (T)azv;
+    za[pos] = (T)(0.5 * M_PI - asin(zeta));
+    const double twopi = 2.0 * M_PI;
+    xyz[pos] = (T)(twopi * (rp.m[0] * e + rp.m[1] * n + rp.m[2] * u));
+    xyz[cap + pos] = (T)(twopi * (rp.m[3] * e + rp.m[4] * n + rp.m[5] * u));
+    xyz[2 * cap + pos] = (T)(twopi * (rp.m[6] * e + rp.m[7] * n + rp.m[8] * u));
+    src_idx[pos] = (int)j;
+}
+
+// ---------------------------------------------------------------------------------------------
+// beam x coherency  (evaluate_beam cpu/beams.py:12-89; _compute_apparent_coherency
+// cpu_simulate.py:90-202; numba kernels cpu/beams.py:129-246)
+// ---------------------------------------------------------------------------------------------
+__device__ inline double airy_efield(double diameter, double freq, double za) {
+    const double x = M_PI * diameter * freq * sin(za) / SPEED_OF_LIGHT;
+    return x == 0.0 ? 1.0 : 2.0 * j1(x) / x;
+}
+
+struct Bilin {
+    int ia0, ia1, iz0, iz1;
+    double wa, wz;
+};
+
+__device__ inline Bilin bilin_setup(const BeamDesc &b, double az, double za) {
+    Bilin o;
+    const double twopi = 2.0 * M_PI;
+    double a = fmod(az, twopi);
+    if (a < 0) a += twopi;
+    const double fa = a / (twopi / b.naz);
+    int ia0 = (int)floor(fa);
+    o.wa = fa - ia0;
+    ia0 %= b.naz;
+    o.ia0 = ia0;
+    o.ia1 = (ia0 + 1) % b.naz;
+    double fz = za / (b.za_max / (b.nza - 1));
+    fz = fmin(fmax(fz, 0.0), (double)(b.nza - 1));
+    int iz0 = min((int)floor(fz), b.nza - 2);
+    o.wz = fz - iz0;
+    o.iz0 = iz0;
+    o.iz1 = iz0 + 1;
+    return o;
+}
+
+// Jones matrix A[ax][feed] (row-major, 4 complex) of one beam at one (source, frequency).
+__device__ inline void eval_jones(const BeamDesc &b, int fidx, double freq, double az, double za,
+                                  cplx<double> A[4]) {
+    if (b.kind == 0) {
+        const double e = airy_efield(b.diameter, freq, za);
+        for (int i = 0; i < 4; ++i) A[i] = {e, 0.0};
+        return;
+    }
+    const Bilin w = bilin_setup(b, az, za);
+    const int ft = b.nfreq_tab > 1 ? fidx : 0;
+    const cplx<double> *tab = (const cplx<double> *)b.table + (int64_t)ft * 4 * b.nza * b.naz;
+    const double w00 = (1 - w.wz) * (1 - w.wa), w01 = (1 - w.wz) * w.wa, w10 = w.wz * (1 - w.wa),
+                 w11 = w.wz * w.wa;
+    for (int i = 0; i < 4; ++i) {
+        const cplx<double> *p = tab + (int64_t)i * b.nza * b.naz;
+        const cplx<double> v00 = p[(int64_t)w.iz0 * b.naz + w.ia0], v01 = p[(int64_t)w.iz0 * b.naz + w.ia1],
+                           v10 = p[(int64_t)w.iz1 * b.naz + w.ia0], v11 = p[(int64_t)w.iz1 * b.naz + w.ia1];
+        A[i] = {v00.re * w00 + v01.re * w01 + v10.re * w10 + v11.re * w11,
+                v00.im * w00 + v01.im * w01 + v10.im * w10 + v11.im * w11};
+    }
+}
+
+// Power beam (unpolarized path: prepare_beam_unpolarized in wrapper.py:278-279 hands the engine a
+// single-polarisation power beam; evaluate_beam returns [0,0,0,:], cpu/beams.py:78-81).
+__device__ inline double eval_power(const BeamDesc &b, int fidx, double freq, double az, double za) {
+    if (b.kind == 0) {
+        const double e = airy_efield(b.diameter, freq, za);
+        return e * e;
+    }
+    const Bilin w = bilin_setup(b, az, za);
+    const int ft = b.nfreq_tab > 1 ? fidx : 0;
+    const double *p = (const double *)b.table + (int64_t)ft * b.nza * b.naz;
+    return p[(int64_t)w.iz0 * b.naz + w.ia0] * (1 - w.wz) * (1 - w.wa) +
+           p[(int64_t)w.iz0 * b.naz + w.ia1] * (1 - w.wz) * w.wa +
+           p[(int64_t)w.iz1 * b.naz + w.ia0] * w.wz * (1 - w.wa) +
+           p[(int64_t)w.iz1 * b.naz + w.ia1] * w.wz * w.wa;
+}
+
+struct StrengthArgs {
+    int64_t M;          // above-horizon sources
+    int nfg;            // frequencies in this group
+    int f_first;        // catalog index of the group's first frequency
+    int nfreq;          // catalog frequency count (flux row length)
+    int polarized, pol_sky, same_beam;
+    int dim, w;
+    double h[3], btc[3];
+    int n2[3];
+    BeamDesc bi, bj;
+};
+
+// thread <-> (sorted source p, frequency fgi); fgi fastest so a wave reads flux rows contiguously
+// and writes its tpol strengths back to back:  cs[p][fgi * tpol + r].
+template <typename T>
+__global__ void k_strengths(StrengthArgs a, const int *__restrict__ perm,
+                            const int *__restrict__ src_idx, const T *__restrict__ az,
+                            const T *__restrict__ za, const void *__restrict__ flux,
+                            const double *__restrict__ freqs, const int *__restrict__ i0s,
+                            const T *__restrict__ fs, cplx<T> *__restrict__ cs) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.M * a.nfg) return;
+    const int64_t p = idx / a.nfg;
+    const int fgi = (int)(idx % a.nfg);
+    const int fidx = a.f_first + fgi;
+    const double freq = freqs[fidx];
+    const int jc = perm[p];           // compacted index
+    const int64_t js = src_idx[jc];   // catalog index
+    const double azv = az[jc], zav = za[jc];
+
+    // type-3 pre-phase exp(i nu btc . x'), x' rebuilt from the sorted grid coordinates
+    double dot = 0.0;
+    for (int d = 0; d < a.dim; ++d) {
+        const double pos = (double)i0s[(int64_t)d * a.M + p] - (double)fs[(int64_t)d * a.M + p];
+        dot += a.btc[d] * (pos - 0.5 * a.n2[d]) * a.h[d];
+    }
+    cplx<double> pre = {1.0, 0.0};
+    if (dot != 0.0) sincos(freq * dot, &pre.im, &pre.re);
+
+    if (!a.polarized) {
+        // cpu_simulate.py:183-187: sqrt(B_i B_j) * I   (principal square root)
+        const double bi = eval_power(a.bi, fidx, freq, azv, zav);
+        const double bj = a.same_beam ? bi : eval_power(a.bj, fidx, freq, azv, zav);
+        const double I = (double)((const T *)flux)[js * a.nfreq + fidx];
+        const double prod = bi * bj;
+        cplx<double> c = prod >= 0 ? cplx<double>{sqrt(prod) * I, 0.0} : cplx<double>{0.0, sqrt(-prod) * I};
+        c = cmul(c, pre);
+        cs[p * a.nfg + fgi] = {(T)c.re, (T)c.im};
+        return;
+    }
+    cplx<double> Ai[4], Aj[4];
+    eval_jones(a.bi, fidx, freq, azv, zav, Ai);
+    if (a.same_beam) {
+        for (int i = 0; i < 4; ++i) Aj[i] = Ai[i];
+    } else {
+        eval_jones(a.bj, fidx, freq, azv, zav, Aj);
+    }
+    cplx<double> o[4];
+    if (!a.pol_sky) {
+        // cpu/beams.py:129-145,182-212: out[a][p] = sum_b conj(Ai[b][a]) Aj[b][p] * I
+        const double I = (double)((const T *)flux)[js * a.nfreq + fidx];
+        for (int aa = 0; aa < 2; ++aa)
+            for (int pp = 0; pp < 2; ++pp) {
+                cplx<double> s = cadd(cmul(cconj(Ai[0 * 2 + aa]), Aj[0 * 2 + pp]),
+                                      cmul(cconj(Ai[1 * 2 + aa]), Aj[1 * 2 + pp]));
+                o[aa * 2 + pp] = cscale(s, I);
+            }
+    } else {
+        // cpu_simulate.py:142-156 + cpu/beams.py:147-180,215-246 on A' = flip(A, axis 0):
+        // out[a][p] = sum_{b,k} conj(A'i[b][a]) C[b][k] A'j[k][p]
+        const cplx<T> *Cp = (const cplx<T> *)flux + (js * a.nfreq + fidx) * 4;
+        cplx<double> C[4];
+        for (int i = 0; i < 4; ++i) C[i] = {(double)Cp[i].re, (double)Cp[i].im};
+        cplx<double> Fi[4] = {Ai[2], Ai[3], Ai[0], Ai[1]};
+        cplx<double> Fj[4] = {Aj[2], Aj[3], Aj[0], Aj[1]};
+        for (int aa = 0; aa < 2; ++aa) {
+            // tmp[k] = sum_b conj(Fi[b][a]) C[b][k]
+            cplx<double> t0 = cadd(cmul(cconj(Fi[0 * 2 + aa]), C[0]), cmul(cconj(Fi[1 * 2 + aa]), C[2]));
+            cplx<double> t1 = cadd(cmul(cconj(Fi[0 * 2 + aa]), C[1]), cmul(cconj(Fi[1 * 2 + aa]), C[3]));
+            for (int pp = 0; pp < 2; ++pp)
+                o[aa * 2 + pp] = cadd(cmul(t0, Fj[0 * 2 + pp]), cmul(t1, Fj[1 * 2 + pp]));
+        }
+    }
+    cplx<T> *dst = cs + (p * a.nfg + fgi) * 4;
+    for (int r = 0; r < 4; ++r) {
+        const cplx<double> v = cmul(o[r], pre);
+        dst[r] = {(T)v.re, (T)v.im};
+    }
+}
+
+// Brute-force type-3 sum on the device (independent checker; fp64 accumulation).
+template <typename T>
+__global__ void k_nudft_direct(int dim, int64_t M, const T *__restrict__ x, const T *__restrict__ y,
+                               const T *__restrict__ z, const cplx<T> *__restrict__ c, int ntrans,
+                               int64_t N, const T *__restrict__ s, const T *__restrict__ t,
+                               const T *__restrict__ u, cplx<T> *__restrict__ out) {
+    const int64_t k = blockIdx.x;
+    const int tr = blockIdx.y;
+    if (k >= N) return;
+    const double sk = s[k], tk = dim > 1 ? (double)t[k] : 0.0, uk = dim > 2 ? (double)u[k] : 0.0;
+    double ar = 0.0, ai = 0.0;
+    for (int64_t j = threadIdx.x; j < M; j += blockDim.x) {
+        double ph = sk * (double)x[j];
+        if (dim > 1) ph += tk * (double)y[j];
+        if (dim > 2) ph += uk * (double)z[j];
+        double sn, cs;
+        sincos(ph, &sn, &cs);
+        const cplx<T> cv = c[(int64_t)tr * M + j];
+        ar += (double)cv.re * cs - (double)cv.im * sn;
+        ai += (double)cv.re * sn + (double)cv.im * cs;
+    }
+    __shared__ double rr[256], ri[256];
+    rr[threadIdx.x] = ar;
+    ri[threadIdx.x] = ai;
+    __syncthreads();
+    for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            rr[threadIdx.x] += rr[threadIdx.x + off];
+            ri[threadIdx.x] += ri[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(int64_t)tr * N + k] = {(T)rr[0], (T)ri[0]};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Engine
+// ---------------------------------------------------------------------------------------------
+struct SimBase {
+    virtual ~SimBase() = default;
+    virtual void set_sources(int64_t nsrc, int nfreq, const void *eq, const void *flux, int pol_sky,
+                             int on_device) = 0;
+    virtual void set_times(int ntimes, const double *rot) = 0;
+    virtual void set_freqs(int nfreq, const double *freqs) = 0;
+    virtual void set_array(const double *R, int64_t nbls, const double *bls, int coplanar) = 0;
+    virtual void set_nbeams(int n) = 0;
+    virtual void set_beam_airy(int b, double diameter) = 0;
+    virtual void set_beam_table(int b, int nfreq_tab, int nza, int naz, double za_max,
+                                const void *table) = 0;
+    virtual void set_beam_pairs(int npairs, const int *bi, const int *bj, const int64_t *off,
+                                const int *idx, const signed char *flipped) = 0;
+    virtual void run(int t0, int t1, int f0, int f1, void *out, int out_on_device) = 0;
+    virtual void sync() = 0;
+    virtual void stats(double *v, int n) = 0;
+    virtual void reset_stats() = 0;
+    virtual void enable_timing(int on) = 0;
+    virtual void timing(double *ms, int n) = 0;
+};
+
+enum { TM_SPREAD = 0, TM_FFT, TM_INTERP, TM_STRENGTHS, TM_PREP, TM_COUNT };
+
+template <typename T>
+class Sim : public SimBase {
+    int device;
+    hipStream_t stream = nullptr;
+    double eps, sigma;
+    bool polarized;
+    int tpol;
+
+    int64_t nsrc = 0;
+    int nfreq_cat = 0;
+    bool pol_sky = false;
+    DevBuf d_eq, d_flux;
+
+    std::vector<Rot9> rots;
+    std::vector<double> freqs;
+    DevBuf d_freqs;
+
+    Rot9 rplane{};
+    int64_t nbls = 0;
+    bool coplanar = true;
+    std::vector<double> h_bls;  // (3, nbls) seconds
+    DevBuf d_bls;               // (3, nbls) T
+
+    struct Beam {
+        int kind = -1;
+        double diameter = 0;
+        int nfreq_tab = 0, nza = 0, naz = 0;
+        double za_max = 0;
+        std::unique_ptr<DevBuf> table;
+    };
+    std::vector<Beam> beams;
+
+    struct Pair {
+        int bi, bj;
+        int64_t n;
+        bool trivial;  // all baselines in order, nothing flipped
+        std::unique_ptr<DevBuf> idx, flip;
+        double btc[3], B[3];
+    };
+    std::vector<Pair> pairs;
+
+    // per-time scratch
+    DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scale, d_out;
+    std::unique_ptr<Nufft3<T>> nufft;
+
+    // stats / timing
+    double st[10] = {0};
+    bool timing_on = false;
+    struct Ev {
+        hipEvent_t a, b;
+        int kind;
+    };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    double tm[TM_COUNT] = {0};
+
+    int dim() const { return coplanar ? 2 : 3; }
+
+    size_t ev_begin(int kind) {
+        if (!timing_on) return (size_t)-1;
+        if (ev_used == ev_pool.size()) {
+            Ev e;
+            FV_HIP(hipEventCreate(&e.a));
+            FV_HIP(hipEventCreate(&e.b));
+            e.kind = kind;
+            ev_pool.push_back(e);
+        }
+        ev_pool[ev_used].kind = kind;
+        FV_HIP(hipEventRecord(ev_pool[ev_used].a, stream));
+        return ev_used++;
+    }
+    void ev_end(size_t i) {
+        if (i == (size_t)-1) return;
+        FV_HIP(hipEventRecord(ev_pool[i].b, stream));
+    }
+    void ev_collect() {
+        for (size_t i = 0; i < ev_used; ++i) {
+            float ms = 0;
+            FV_HIP(hipEventElapsedTime(&ms, ev_pool[i].a, ev_pool[i].b));
+            tm[ev_pool[i].kind] += ms;
+        }
+        ev_used = 0;
+    }
+
+   public:
+    Sim(int device_, double eps_, double sigma_, int polarized_)
+        : device(device_), eps(eps_), sigma(sigma_), polarized(polarized_ != 0),
+          tpol(polarized_ ? 4 : 1) {
+        FV_HIP(hipSetDevice(device));
+        FV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (int i = 0; i < 9; ++i) rplane.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    ~Sim() override {
+        (void)hipSetDevice(device);
+        nufft.reset();
+        for (auto &e : ev_pool) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    void upload(DevBuf &dst, const void *src, size_t bytes, int on_device) {
+        dst.reserve(std::max<size_t>(bytes, 16));
+        if (bytes)
+            FV_HIP(hipMemcpyAsync(dst.p, src, bytes,
+                                  on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        FV_HIP(hipStreamSynchronize(stream));
+    }
+
+    void set_sources(int64_t n, int nfreq, const void *eq, const void *flux, int ps,
+                     int on_device) override {
+        FV_HIP(hipSetDevice(device));
+        FV_REQUIRE(n >= 0 && nfreq >= 1, "bad catalog shape");
+        FV_REQUIRE(n < (int64_t)1 << 31, "catalog too large for 32-bit source indices");
+        FV_REQUIRE(!ps || polarized, "polarized sky needs a polarized engine (cpu/utils.py:56-66)");
+        nsrc = n;
+        nfreq_cat = nfreq;
+        pol_sky = ps != 0;
+        upload(d_eq, eq, sizeof(T) * 3 * n, on_device);
+        upload(d_flux, flux, (pol_sky ? sizeof(T) * 8 : sizeof(T)) * (size_t)n * nfreq, on_device);
+    }
+    void set_times(int ntimes, const double *rot) override {
+        rots.resize(ntimes);
+        for (int i = 0; i < ntimes; ++i) std::memcpy(rots[i].m, rot + 9 * i, 9 * sizeof(double));
+    }
+    void set_freqs(int nf, const double *f) override {
+        FV_HIP(hipSetDevice(device));
+        freqs.assign(f, f + nf);
+        upload(d_freqs, f, sizeof(double) * nf, 0);
+    }
+    void set_array(const double *R, int64_t nb, const double *bls, int cop) override {
+        FV_HIP(hipSetDevice(device));
+        std::memcpy(rplane.m, R, 9 * sizeof(double));
+        nbls = nb;
+        coplanar = cop != 0;
+        h_bls.assign(bls, bls + 3 * nb);
+        std::vector<T> tmp(3 * nb);
+        for (int64_t i = 0; i < 3 * nb; ++i) tmp[i] = (T)bls[i];
+        upload(d_bls, tmp.data(), sizeof(T) * 3 * nb, 0);
+        pairs.clear();
+    }
+    void set_nbeams(int n) override {
+        beams.clear();
+        beams.resize(n);
+    }
+    void set_beam_airy(int b, double diameter) override {
+        FV_REQUIRE(b >= 0 && b < (int)beams.size(), "beam index out of range");
+        beams[b].kind = 0;
+        beams[b].diameter = diameter;
+    }
+    void set_beam_table(int b, int nft, int nza, int naz, double za_max, const void *table) override {
+        FV_HIP(hipSetDevice(device));
+        FV_REQUIRE(b >= 0 && b < (int)beams.size(), "beam index out of range");
+        FV_REQUIRE(nza >= 2 && naz >= 1 && nft >= 1 && za_max > 0, "bad beam table shape");
+        Beam &bm = beams[b];
+        bm.kind = 1;
+        bm.nfreq_tab = nft;
+        bm.nza = nza;
+        bm.naz = naz;
+        bm.za_max = za_max;
+        bm.table.reset(new DevBuf());
+        const size_t per = polarized ? 4 * 16 : 8;  // complex128 Jones or float64 power
+        upload(*bm.table, table, per * (size_t)nft * nza * naz, 0);
+    }
+    void set_beam_pairs(int np, const int *bi, const int *bj, const int64_t *off, const int *idx,
+                        const signed char *flipped) override {
+        FV_HIP(hipSetDevice(device));
+        FV_REQUIRE(nbls > 0 || np == 0, "set_array first");
+        pairs.clear();
+        for (int p = 0; p < np; ++p) {
+            Pair pr;
+            pr.bi = bi[p];
+            pr.bj = bj[p];
+            pr.n = off[p + 1] - off[p];
+            const int *ix = idx + off[p];
+            const signed char *fl = flipped + off[p];
+            pr.trivial = pr.n == nbls;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int64_t k = 0; k < pr.n; ++k) {
+                FV_REQUIRE(ix[k] >= 0 && ix[k] < nbls, "baseline index out of range");
+                if (ix[k] != k || fl[k]) pr.trivial = false;
+                const double sg = fl[k] ? -1.0 : 1.0;
+                for (int d = 0; d < 3; ++d) {
+                    const double v = sg * h_bls[(size_t)d * nbls + ix[k]];
+                    lo[d] = std::min(lo[d], v);
+                    hi[d] = std::max(hi[d], v);
+                }
+            }
+            for (int d = 0; d < 3; ++d) {
+                pr.btc[d] = pr.n ? 0.5 * (lo[d] + hi[d]) : 0.0;
+                pr.B[d] = pr.n ? 0.5 * (hi[d] - lo[d]) * (1.0 + 1e-12) : 0.0;
+            }
+            if (!pr.trivial && pr.n) {
+                pr.idx.reset(new DevBuf());
+                pr.flip.reset(new DevBuf());
+                upload(*pr.idx, ix, sizeof(int) * pr.n, 0);
+                upload(*pr.flip, fl, pr.n, 0);
+            }
+            pairs.push_back(std::move(pr));
+        }
+    }
+
+    // Tight box of {2 pi R_plane v : |v| = 1, v_up >= 0} per coordinate.
+    void source_box(double *xc, double *X) const {
+        for (int d = 0; d < 3; ++d) {
+            const double al = rplane.m[3 * d + 2];
+            const double rad = std::sqrt(std::max(0.0, 1.0 - al * al));
+            const double hi = al >= 0 ? 1.0 : rad, lo = al <= 0 ? -1.0 : -rad;
+            xc[d] = 2.0 * M_PI * 0.5 * (hi + lo);
+            X[d] = 2.0 * M_PI * 0.5 * (hi - lo) * (1.0 + 1e-9) + 1e-12;
+        }
+    }
+
+    // Split [f0, f1) into groups of consecutive channels sharing one fine-grid geometry.
+    std::vector<std::pair<int, int>> freq_groups(int f0, int f1, double cells_per_trans_at) const {
+        const char *er = std::getenv("FFTVIS_HIP_GROUP_RATIO");
+        const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
+        const double ratio = er ? std::atof(er) : 0.90;
+        const double budget = eb ? std::atof(eb) : 6.0 * 1024 * 1024 * 1024;
+        std::vector<std::pair<int, int>> g;
+        int a = f0;
+        while (a < f1) {
+            double lo = std::fabs(freqs[a]), hi = lo;
+            int b = a + 1;
+            while (b < f1) {
+                const double nlo = std::min(lo, std::fabs(freqs[b])), nhi = std::max(hi, std::fabs(freqs[b]));
+                if (nlo < ratio * nhi) break;
+                // grid bytes grow ~ nhi^2 * count
+                const double scale = (nhi / std::max(1.0, std::fabs(freqs[f1 - 1]))) ;
+                const double bytes = cells_per_trans_at * scale * scale * (b + 1 - a) * tpol * sizeof(cplx<T>);
+                if (bytes > budget) break;
+                lo = nlo;
+                hi = nhi;
+                ++b;
+            }
+            g.emplace_back(a, b);
+            a = b;
+        }
+        return g;
+    }
+
+    void run(int t0, int t1, int f0, int f1, void *out, int out_on_device) override {
+        FV_HIP(hipSetDevice(device));
+        FV_REQUIRE(nsrc >= 0 && !rots.empty() && !freqs.empty() && nbls > 0 && !pairs.empty(),
+                   "engine not fully configured");
+        FV_REQUIRE(0 <= t0 && t0 <= t1 && t1 <= (int)rots.size(), "time range");
+        FV_REQUIRE(0 <= f0 && f0 <= f1 && f1 <= (int)freqs.size(), "freq range");
+        FV_REQUIRE((int)freqs.size() == nfreq_cat, "flux frequency axis != freqs");
+        for (const Beam &b : beams) FV_REQUIRE(b.kind >= 0, "beam not set");
+        const int nt = t1 - t0, nf = f1 - f0;
+        const int D = dim();
+        const int64_t per_tf = (int64_t)tpol * nbls;   // elements per (freq, time)
+        const size_t out_bytes = sizeof(cplx<T>) * (size_t)nf * nt * per_tf;
+        cplx<T> *dout;
+        if (out_on_device) {
+            dout = (cplx<T> *)out;
+        } else {
+            d_out.reserve(std::max<size_t>(out_bytes, 16));
+            dout = d_out.as<cplx<T>>();
+        }
+        // Baselines not covered by any pair stay zero (reference zero-initialises, :909-911).
+        FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
+        if (!nufft) nufft.reset(new Nufft3<T>(D, eps, sigma, stream));
+        if (nufft->dim != D) nufft.reset(new Nufft3<T>(D, eps, sigma, stream));
+
+        double xc[3], X[3];
+        source_box(xc, X);
+        int64_t pol_off[16] = {0};
+        if (polarized)
+            for (int r = 0; r < 4; ++r) pol_off[r] = (int64_t)((r % 2) * 2 + r / 2) * nbls;
+
+        const int64_t cap = std::max<int64_t>(nsrc, 1);
+        d_xyz.reserve(sizeof(T) * 3 * cap);
+        d_az.reserve(sizeof(T) * cap);
+        d_za.reserve(sizeof(T) * cap);
+        d_srcidx.reserve(sizeof(int) * cap);
+        const int nblk = (int)cdiv(cap, 256);
+        d_blockcnt.reserve(sizeof(int) * (nblk + 1));
+        d_blockoff.reserve(sizeof(int) * (nblk + 1));
+        d_scale.reserve(sizeof(double) * std::max(nf, 1));
+
+        // grid size estimate at the top frequency for the grouping heuristic
+        double cells_top = 1.0;
+        {
+            KerParams k = make_kernel(eps, sigma);
+            for (int d = 0; d < D; ++d) {
+                DimGeom g;
+                g.X = X[d];
+                double Bm = 0;
+                for (const Pair &p : pairs) Bm = std::max(Bm, p.B[d]);
+                g.B = Bm;
+                set_dim_geom(g, sigma, k.w, std::fabs(freqs[f1 > f0 ? f1 - 1 : f0]));
+                cells_top *= g.n2;
+            }
+        }
+        const auto groups = freq_groups(f0, f1, cells_top);
+
+        int binned_ti = -1;
+        int64_t binned_serial = -1;
+        for (int ti = t0; ti < t1; ++ti) {
+            // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
+            size_t e0 = ev_begin(TM_PREP);
+            int M = 0;
+            if (nsrc > 0) {
+                hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, nsrc,
+                                   d_eq.as<T>(), rots[ti], d_blockcnt.as<int>());
+                hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
+                                   d_blockcnt.as<int>(), d_blockoff.as<int>(), nblk);
+                hipLaunchKernelGGL(k_horizon_compact<T>, dim3(nblk), dim3(256), 0, stream, nsrc,
+                                   d_eq.as<T>(), rots[ti], rplane, d_blockoff.as<int>(),
+                                   d_xyz.as<T>(), cap, d_az.as<T>(), d_za.as<T>(),
+                                   d_srcidx.as<int>());
+                FV_HIP(hipMemcpyAsync(&M, d_blockoff.as<int>() + nblk, sizeof(int),
+                                      hipMemcpyDeviceToHost, stream));
+                FV_HIP(hipStreamSynchronize(stream));
+            }
+            ev_end(e0);
+            st[5] += M;
+            if (M == 0) continue;  // cpu_simulate.py:945-946
+
+            for (const auto &grp : groups) {
+                const int fa = grp.first, fb = grp.second, nfg = fb - fa;
+                const int ntrans = nfg * tpol;
+                double smax = 0;
+                for (int f = fa; f < fb; ++f) smax = std::max(smax, std::fabs(freqs[f]));
+                for (const Pair &pr : pairs) {
+                    if (pr.n == 0) continue;
+                    // ---- geometry + bin sort (skipped when unchanged since last set) -------
+                    size_t e1 = ev_begin(TM_PREP);
+                    nufft->set_geometry(xc, X, pr.btc, pr.B, smax);
+                    if (binned_ti != ti || binned_serial != nufft->geom_serial || nufft->M != M) {
+                        nufft->set_sources(M, d_xyz.as<T>(), d_xyz.as<T>() + cap,
+                                           D > 2 ? d_xyz.as<T>() + 2 * cap : nullptr);
+                        binned_ti = ti;
+                        binned_serial = nufft->geom_serial;
+                    }
+                    ev_end(e1);
+                    // ---- strengths ------------------------------------------------------
+                    size_t e2 = ev_begin(TM_STRENGTHS);
+                    StrengthArgs sa{};
+                    sa.M = M;
+                    sa.nfg = nfg;
+                    sa.f_first = fa;
+                    sa.nfreq = nfreq_cat;
+                    sa.polarized = polarized;
+                    sa.pol_sky = pol_sky;
+                    sa.same_beam = pr.bi == pr.bj;
+                    sa.dim = D;
+                    sa.w = nufft->ker.w;
+                    for (int d = 0; d < 3; ++d) {
+                        sa.h[d] = nufft->geo.d[d].h;
+                        sa.btc[d] = d < D ? pr.btc[d] : 0.0;
+                        sa.n2[d] = d < D ? nufft->geo.d[d].n2 : 1;
+                    }
+                    sa.bi = desc(pr.bi);
+                    sa.bj = desc(pr.bj);
+                    cplx<T> *cs = nufft->strengths_buffer(ntrans);
+                    hipLaunchKernelGGL(k_strengths<T>, dim3(cdiv((int64_t)M * nfg, 256)), dim3(256),
+                                       0, stream, sa, nufft->perm.template as<int>(),
+                                       d_srcidx.as<int>(), d_az.as<T>(), d_za.as<T>(), d_flux.p,
+                                       d_freqs.as<double>(), nufft->i0s.template as<int>(),
+                                       nufft->fs.template as<T>(), cs);
+                    ev_end(e2);
+                    // ---- NUFFT ----------------------------------------------------------
+                    size_t e3 = ev_begin(TM_SPREAD);
+                    nufft->spread(ntrans);
+                    ev_end(e3);
+                    st[0] += 1;
+                    st[1] += (double)nufft->geo.ncell() * ntrans;
+                    st[2] += (double)M * ntrans;
+                    size_t e4 = ev_begin(TM_FFT);
+                    nufft->fft(ntrans);
+                    ev_end(e4);
+                    st[3] += (double)nufft->geo.ncell() * ntrans;
+                    size_t e5 = ev_begin(TM_INTERP);
+                    cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
+                    nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
+                                  D > 2 ? d_bls.as<T>() + 2 * nbls : nullptr,
+                                  pr.trivial ? nullptr : pr.idx->template as<int>(),
+                                  pr.trivial ? nullptr : pr.flip->template as<signed char>(),
+                                  d_freqs.as<double>() + fa, nfg, tpol, obase,
+                                  (int64_t)nt * per_tf, 1, pol_off, false);
+                    ev_end(e5);
+                    st[4] += (double)pr.n * ntrans;
+                    st[6] = nufft->geo.d[0].n2;
+                    st[7] = nufft->geo.d[1].n2;
+                    st[8] = D > 2 ? nufft->geo.d[2].n2 : 1;
+                    st[9] = nufft->ker.w;
+                }
+            }
+        }
+        if (!out_on_device) {
+            FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
+            FV_HIP(hipStreamSynchronize(stream));
+            if (timing_on) ev_collect();
+        }
+    }
+
+    BeamDesc desc(int b) const {
+        FV_REQUIRE(b >= 0 && b < (int)beams.size(), "beam pair refers to a missing beam");
+        const Beam &bm = beams[b];
+        BeamDesc d{};
+        d.kind = bm.kind;
+        d.diameter = bm.diameter;
+        d.table = bm.table ? bm.table->p : nullptr;
+        d.nfreq_tab = bm.nfreq_tab;
+        d.nza = bm.nza;
+        d.naz = bm.naz;
+        d.za_max = bm.za_max;
+        return d;
+    }
+
+    void sync() override {
+        FV_HIP(hipSetDevice(device));
+        FV_HIP(hipStreamSynchronize(stream));
+        if (timing_on) ev_collect();
+    }
+    void stats(double *v, int n) override {
+        for (int i = 0; i < n && i < 10; ++i) v[i] = st[i];
+    }
+    void reset_stats() override {
+        for (double &x : st) x = 0;
+        for (double &x : tm) x = 0;
+        ev_used = 0;
+    }
+    void enable_timing(int on) override { timing_on = on != 0; }
+    void timing(double *ms, int n) override {
+        for (int i = 0; i < n && i < TM_COUNT; ++i) ms[i] = tm[i];
+    }
+};
+
+}  // namespace fv

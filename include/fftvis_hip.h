@@ -1,0 +1,128 @@
+/* fftvis_hip.h -- C ABI of libfftvis_hip.so, the MI355X (gfx950) backend that fills the
+ * reference's stubbed `gpu` backend (tyler-a-cox/fftvis, src/fftvis/gpu/).
+ *
+ * Plain C, plain pointers and sizes; no C++/torch types cross this boundary.  Every entry point
+ * returns an int status (0 = OK, see FV_* below); no exception crosses the ABI.  After a
+ * non-zero status fv_last_error() returns a message owned by the library, valid until the next
+ * failing call on the same host thread.  Host arrays are caller-owned, contiguous, never
+ * modified; complex data is interleaved (re, im).  "precision" is the reference's:
+ * 1 = float32/complex64, 2 = float64/complex128 (src/fftvis/cpu/cpu_simulate.py:591-596).
+ *
+ * Each declaration cites the reference interface it stands behind.
+ */
+#ifndef FFTVIS_HIP_H
+#define FFTVIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FV_OK 0
+#define FV_ERR_ARG 1
+#define FV_ERR_HIP 2
+#define FV_ERR_ROCFFT 3
+#define FV_ERR_INTERNAL 4
+
+/* ---- discovery / diagnostics ------------------------------------------------------------ */
+int fv_version(void);                 /* 10000*major + 100*minor + patch */
+int fv_device_count(int *count);      /* number of visible HIP devices (0 on a CPU-only box) */
+const char *fv_last_error(void);
+
+/* ---- standalone type-3 NUFFT ---------------------------------------------------------------
+ * out[t][k] = sum_j c[t][j] exp(+i (s_k x_j + t_k y_j [+ u_k z_j])),   relative l2 error ~ eps.
+ * Replaces: gpu_nufft2d / gpu_nufft3d stubs  (src/fftvis/gpu/nufft.py:11-50, 53-98), i.e. the
+ * GPU twins of cpu_nufft2d / cpu_nufft3d -> finufft.nufft2d3 / nufft3d3
+ * (src/fftvis/cpu/nufft.py:48-59, 105-118; modeord irrelevant for type 3, isign = +1 default).
+ * dim = 2: z and u must be NULL.  x,y,z: (M) reals; c: (ntrans, M) complex; s,t,u: (N) reals;
+ * out: (ntrans, N) complex, caller-allocated.  upsampfac in {2.0, 1.25}
+ * (cpu/nufft.py:19 "upsample_factor").  Host pointers.                                        */
+int fv_nufft3(int device, int precision, int dim, int64_t M, const void *x, const void *y,
+              const void *z, const void *c, int ntrans, int64_t N, const void *s, const void *t,
+              const void *u, double eps, double upsampfac, void *out);
+
+/* Same transform by brute force on the GPU (O(M N) direct sum in fp64 accumulators): an
+ * independent device-side check used by the parity tests at sizes the CPU oracle cannot reach. */
+int fv_nudft3_direct(int device, int precision, int dim, int64_t M, const void *x, const void *y,
+                     const void *z, const void *c, int ntrans, int64_t N, const void *s,
+                     const void *t, const void *u, void *out);
+
+/* ---- fused simulator (the hot loop) ---------------------------------------------------------
+ * One handle = one GPU context: stream, rocFFT plan cache, device-resident catalog / baselines /
+ * beams / scratch.  A handle is not thread-safe; different handles are independent.
+ * Replaces: GPUSimulationEngine._evaluate_vis_chunk stub (src/fftvis/gpu/gpu_simulate.py:62-91),
+ * i.e. the GPU twin of CPUSimulationEngine._evaluate_vis_chunk
+ * (src/fftvis/cpu/cpu_simulate.py:856-1071) and the helpers it calls
+ * (_compute_apparent_coherency :90-202, _run_nufft :205-300, cpu/beams.py:129-246,
+ *  cpu/utils.py:5-24).                                                                        */
+typedef struct fv_sim fv_sim;
+
+/* precision 1|2; eps: NUFFT accuracy (core/simulate.py:16-19 defaults are the caller's job);
+ * upsampfac 2.0|1.25; polarized: nfeeds = 2 (cpu_simulate.py:589). */
+int fv_sim_create(fv_sim **h, int device, int precision, double eps, double upsampfac,
+                  int polarized);
+int fv_sim_destroy(fv_sim *h);
+
+/* Source catalog.  eq: (3, nsrc) equatorial unit vectors (x = cos dec cos ra, ...), real.
+ * flux: coherency as prepared by prepare_source_catalog (cpu/utils.py:26-80), already x0.5:
+ *   polarized_sky = 0: (nsrc, nfreq) real;  = 1: (nsrc, nfreq, 2, 2) complex.
+ * on_device != 0: pointers are device pointers on this handle's GPU (e.g. tensors received by
+ * an RCCL broadcast); the library copies either way and the caller keeps ownership.          */
+int fv_sim_set_sources(fv_sim *h, int64_t nsrc, int nfreq, const void *eq, const void *flux,
+                       int polarized_sky, int on_device);
+
+/* Per-time equatorial -> topocentric ENU rotation matrices, (ntimes, 3, 3) float64 row-major:
+ * the device-side stand-in for matvis CoordinateRotation.rotate/select_chunk as used at
+ * cpu_simulate.py:937-946 (above-horizon selection up > 0 happens on the device).            */
+int fv_sim_set_times(fv_sim *h, int ntimes, const double *rot_eq2enu);
+
+/* Frequencies (Hz), float64 (nfreq). (cpu_simulate.py:969-973) */
+int fv_sim_set_freqs(fv_sim *h, int nfreq, const double *freqs);
+
+/* Array: rotation_matrix (3,3) float64 applied to topo before the NUFFT (cpu_simulate.py:961-962),
+ * bls (3, nbls) float64 in SECONDS = R (a2 - a1) / c (cpu_simulate.py:650-659), is_coplanar
+ * (cpu_simulate.py:655).                                                                      */
+int fv_sim_set_array(fv_sim *h, const double *rotation_matrix, int64_t nbls, const double *bls,
+                     int is_coplanar);
+
+/* Beams (evaluate_beam, cpu/beams.py:12-89).  kind 0: analytic Airy dish, param[0] = diameter
+ * [m]; E-field 2 J1(x)/x in all four Jones slots, power beam = its square.
+ * kind 1: tabulated on a regular (za, az) grid, order-1 interpolation; table is
+ *   polarized:   (nfreq_tab, 2, 2, nza, naz) complex128  [ax, feed]
+ *   unpolarized: (nfreq_tab, nza, naz) float64 power
+ * with az periodic over 2 pi, za in [0, za_max] inclusive; nfreq_tab is 1 or nfreq.          */
+int fv_sim_set_nbeams(fv_sim *h, int nbeams);
+int fv_sim_set_beam_airy(fv_sim *h, int beam, double diameter);
+int fv_sim_set_beam_table(fv_sim *h, int beam, int nfreq_tab, int nza, int naz, double za_max,
+                          const void *table);
+
+/* Beam pairs (prepare_beam_evaluation, cpu/beams.py:91-127): for pair p, beams (bi[p], bj[p]),
+ * baseline indices idx[off[p] .. off[p+1]) and their `flipped` flags.  npairs = 1, bi=bj=0,
+ * idx = 0..nbls-1, no flips is the beam_idx=None case.                                        */
+int fv_sim_set_beam_pairs(fv_sim *h, int npairs, const int *bi, const int *bj, const int64_t *off,
+                          const int *idx, const signed char *flipped);
+
+/* Run times [t0, t1) x freqs [f0, f1).  Result layout is the reference's FINAL layout
+ * (cpu_simulate.py:850-854): polarized (nf_here, nt_here, 2, 2, nbls), else (nf_here, nt_here,
+ * nbls), complex of the handle's precision.  out_on_device = 0: `out` is a host buffer (the
+ * call synchronises); != 0: `out` is a device buffer and the call only enqueues work on the
+ * handle's stream -- use fv_sim_sync().                                                      */
+int fv_sim_run(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int out_on_device);
+int fv_sim_sync(fv_sim *h);
+
+/* Introspection for bench/roofline: fills up to n doubles:
+ * [0] spread kernel launches, [1] fine-grid cells written by spread (all trans, summed),
+ * [2] source-footprint visits, [3] FFT cells, [4] interp targets x trans, [5] above-horizon
+ * sources summed over times, [6] last n2x, [7] last n2y, [8] last n2z, [9] kernel width w.   */
+int fv_sim_stats(fv_sim *h, double *vals, int n);
+int fv_sim_reset_stats(fv_sim *h);
+/* HIP-event timing of the dominant kernels on the handle's stream (ms, summed since reset):
+ * [0] spread, [1] fft, [2] interp, [3] strengths(beam+coherency), [4] rotate/sort; enable first. */
+int fv_sim_enable_timing(fv_sim *h, int on);
+int fv_sim_timing(fv_sim *h, double *ms, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFTVIS_HIP_H */

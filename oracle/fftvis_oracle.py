@@ -1,0 +1,624 @@
+"""CPU oracle for the fftvis hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This module restates, in plain numpy (fp64), what the reference CPU backend
+computes for one (time x frequency) block of visibilities.  Every function
+cites the reference file:line it follows (paths relative to the reference
+tree, ``src/fftvis/...``).  Only ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` may import it; the product package
+``fftvis_amd`` never does.
+
+PARITY STATUS
+-------------
+* Pinned by the reference's own known-answer tests (restated under
+  ``tests/test_oracle_golden.py`` with committed fixtures in ``tests/golden``):
+  the four coherency kernels (``tests/test_cpu_beams.py:90-109,337-361,541-607,
+  861-1023``), ``prepare_beam_evaluation`` truth tables (``:715-854``),
+  ``get_task_chunks`` / ``get_pos_reds`` / plane rotation / ``inplace_rot``
+  (``tests/test_core_utils.py:26-170``).
+* PARITY UNPINNED for three boundaries whose arithmetic lives in third-party
+  packages that are absent from this pipeline (finufft [unpinned in
+  pyproject.toml:32-44], matvis>=1.3.2, pyuvdata>=3.1.2):
+    - the NUFFT: restated as the *exact* direct non-uniform DFT in fp64 with
+      finufft's documented type-3 convention
+      ``f_k = sum_j c_j exp(+i (s_k x_j + t_k y_j + u_k z_j))`` (isign=+1 is
+      finufft's type-3 default; fftvis passes none, cpu/nufft.py:48-59,105-118);
+    - coordinate rotation (matvis CoordinateRotationERFA): restated as a pure
+      sidereal rotation (``SimpleCoordinateRotation``), no precession /
+      nutation / aberration;
+    - beam interpolation (pyuvdata ``compute_response``): restated as an
+      analytic Airy pattern and as order-1 (bilinear) interpolation of an
+      az/za table.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+speed_of_light = 299792458.0  # core/utils.py:9
+
+default_accuracy_dict = {1: 6e-8, 2: 1e-13}  # core/simulate.py:16-19
+
+
+# ---------------------------------------------------------------------------
+# Catalog / rotation helpers                                   cpu/utils.py
+# ---------------------------------------------------------------------------
+def inplace_rot(rot: np.ndarray, b: np.ndarray) -> None:
+    """b[:, n] <- rot @ b[:, n]            (cpu/utils.py:5-24, core/utils.py:190-210)."""
+    b[:] = rot @ b
+
+
+def prepare_source_catalog(sky_model: np.ndarray, polarized_beam: bool):
+    """Stokes -> coherency with the reference's 0.5 factor (cpu/utils.py:26-80)."""
+    if sky_model.ndim == 2:
+        polarized_sky_model = False
+    elif polarized_beam and sky_model.ndim == 3 and sky_model.shape[-1] == 4:
+        polarized_sky_model = True
+    else:
+        if polarized_beam:
+            raise ValueError(
+                "polarized_beam=True requires sky_model to be either:\n"
+                "  2D unpolarized, or\n"
+                "  3D with last axis of length 4; "
+                f"got ndim={sky_model.ndim}, shape={sky_model.shape}"
+            )
+        raise ValueError(
+            "polarized_beam=False requires sky_model to be 2D; "
+            f"got ndim={sky_model.ndim}, shape={sky_model.shape}"
+        )
+    if not polarized_sky_model:
+        return 0.5 * sky_model, False  # cpu/utils.py:70
+    I, Q, U, V = (sky_model[..., k] for k in range(4))
+    coh = np.empty(sky_model.shape[:2] + (2, 2), dtype=complex)  # cpu/utils.py:72-78
+    coh[..., 0, 0] = 0.5 * (I + Q)
+    coh[..., 0, 1] = 0.5 * (U + 1j * V)
+    coh[..., 1, 0] = 0.5 * (U - 1j * V)
+    coh[..., 1, 1] = 0.5 * (I - Q)
+    return coh, True
+
+
+# ---------------------------------------------------------------------------
+# Coherency kernels (explicit per-source loops)                cpu/beams.py
+# ---------------------------------------------------------------------------
+def get_apparent_flux_polarized_beam(beam: np.ndarray, flux: np.ndarray) -> None:
+    """In place: beam <- (A^H A) * I, Hermitian shortcut (cpu/beams.py:129-145)."""
+    nsrc = beam.shape[2]
+    for s in range(nsrc):
+        c = np.conj(beam[:, :, s])
+        i00 = c[0, 0] * beam[0, 0, s] + c[1, 0] * beam[1, 0, s]
+        i01 = c[0, 0] * beam[0, 1, s] + c[1, 0] * beam[1, 1, s]
+        i11 = c[0, 1] * beam[0, 1, s] + c[1, 1] * beam[1, 1, s]
+        beam[0, 0, s] = i00 * flux[s]
+        beam[0, 1, s] = i01 * flux[s]
+        beam[1, 0, s] = np.conj(i01) * flux[s]
+        beam[1, 1, s] = i11 * flux[s]
+
+
+def get_apparent_flux_polarized(beam: np.ndarray, coherency: np.ndarray) -> None:
+    """In place: beam <- A^H C A (cpu/beams.py:147-180)."""
+    for s in range(beam.shape[2]):
+        A = beam[:, :, s].copy()
+        beam[:, :, s] = (A.conj().T @ coherency[:, :, s]) @ A
+
+
+def get_apparent_flux_polarized_beam_pair(beam_i, beam_j, flux, out) -> None:
+    """out <- A_i^H A_j * I (cpu/beams.py:182-212)."""
+    for s in range(beam_i.shape[2]):
+        out[:, :, s] = (beam_i[:, :, s].conj().T @ beam_j[:, :, s]) * flux[s]
+
+
+def get_apparent_flux_polarized_pair(beam_i, beam_j, coherency, out) -> None:
+    """out <- A_i^H C A_j (cpu/beams.py:215-246)."""
+    for s in range(beam_i.shape[2]):
+        out[:, :, s] = (beam_i[:, :, s].conj().T @ coherency[:, :, s]) @ beam_j[:, :, s]
+
+
+def prepare_beam_evaluation(antnums, baselines, beam_idx):
+    """Beam-pair -> baseline bookkeeping (cpu/beams.py:91-127)."""
+    if beam_idx is None:
+        n = len(baselines)
+        return [(0, 0)], {(0, 0): np.arange(n)}, {(0, 0): [False] * n}
+    uniq = np.unique(beam_idx)
+    nb = len(uniq)
+    pairs = [(uniq[a], uniq[b]) for a in range(nb) for b in range(a, nb)]
+    ant2beam = {a: b for a, b in zip(antnums, beam_idx)}
+    idxs = {bp: [] for bp in pairs}
+    flips = {bp: [] for bp in pairs}
+    for k, (ai, aj) in enumerate(baselines):
+        bi, bj = ant2beam[ai], ant2beam[aj]
+        if (bi, bj) in pairs:
+            bp, fl = (bi, bj), False
+        elif (bj, bi) in pairs:
+            bp, fl = (bj, bi), True
+        else:
+            raise ValueError("Beam pair not in beam pair list")
+        idxs[bp].append(k)
+        flips[bp].append(fl)
+    return pairs, idxs, flips
+
+
+def compute_apparent_coherency(
+    beam_evaluations, bi, bj, flux_here, freqidx, polarized, polarized_sky_model, nfeeds
+):
+    """(nfeeds**2, nsrc) strengths handed to the NUFFT (cpu_simulate.py:90-202).
+
+    Row order r = f1*nfeeds + f2 (np.reshape of (nfeeds, nfeeds, nsrc), :191).
+    """
+    nsrc = flux_here.shape[0]
+    cross = bi != bj
+    if polarized and polarized_sky_model:
+        coh = np.transpose(flux_here[:, freqidx], (1, 2, 0))  # :148,155
+        if cross:
+            out = np.zeros((nfeeds, nfeeds, nsrc), dtype=complex)
+            get_apparent_flux_polarized_pair(
+                np.flip(beam_evaluations[bi], axis=0),  # :146-147
+                np.flip(beam_evaluations[bj], axis=0),
+                coh,
+                out,
+            )
+        else:
+            # :152-156 -- the kernel runs on a *flipped view* of the buffer; the
+            # reshape at :191 then materialises that view (rows in flipped order).
+            buf = np.array(beam_evaluations[bi], dtype=complex)
+            view = np.flip(buf, axis=0)
+            get_apparent_flux_polarized(view, coh)
+            out = np.array(view)
+    elif polarized:
+        if cross:  # :162-171
+            out = np.zeros((nfeeds, nfeeds, nsrc), dtype=complex)
+            get_apparent_flux_polarized_beam_pair(
+                beam_evaluations[bi], beam_evaluations[bj], flux_here[:, freqidx], out
+            )
+        else:  # :172-177
+            out = np.array(beam_evaluations[bi], dtype=complex)
+            get_apparent_flux_polarized_beam(out, flux_here[:, freqidx])
+    else:  # :183-187
+        out = np.sqrt(
+            np.asarray(beam_evaluations[bi], dtype=complex)
+            * np.asarray(beam_evaluations[bj], dtype=complex)
+        )
+        out = out * flux_here[:, freqidx]
+    return np.reshape(out, (nfeeds**2, nsrc)).astype(complex)
+
+
+# ---------------------------------------------------------------------------
+# NUFFT boundary: exact direct sums in place of finufft        cpu/nufft.py
+# ---------------------------------------------------------------------------
+def nudft_type3(coords, c, targets, isign: int = +1, chunk: int = 2048, longdouble=False):
+    """Exact type-3 NUDFT  f[t,k] = sum_j c[t,j] exp(isign*i*sum_d s_d[k] x_d[j]).
+
+    Stands in for finufft.nufft2d3 / nufft3d3 as called at cpu/nufft.py:48-59 and
+    :105-118 (modeord is irrelevant for type 3).  ``coords`` and ``targets`` are
+    sequences of d arrays; c is (M,) or (ntrans, M).  Returns (N,) or (ntrans, N)
+    exactly as finufft does for 1-D / 2-D ``c``.
+    """
+    c = np.asarray(c)
+    squeeze = c.ndim == 1
+    c2 = np.atleast_2d(c).astype(complex)
+    rdt = np.longdouble if longdouble else np.float64
+    X = [np.asarray(a, dtype=rdt) for a in coords]
+    S = [np.asarray(a, dtype=rdt) for a in targets]
+    N = S[0].shape[0]
+    out = np.zeros((c2.shape[0], N), dtype=complex)
+    for k0 in range(0, N, chunk):
+        k1 = min(N, k0 + chunk)
+        ph = np.zeros((k1 - k0, X[0].shape[0]), dtype=rdt)
+        for xd, sd in zip(X, S):
+            ph += np.outer(sd[k0:k1], xd)
+        e = (np.cos(ph) + (1j * isign) * np.sin(ph)).astype(complex)
+        out[:, k0:k1] = c2 @ e.T
+    return out[0] if squeeze else out
+
+
+def cpu_nufft2d(x, y, weights, u, v, eps=None, **_):
+    """cpu/nufft.py:11-59 with the exact sum."""
+    return nudft_type3([x, y], weights, [u, v])
+
+
+def cpu_nufft3d(x, y, z, weights, u, v, w, eps=None, **_):
+    """cpu/nufft.py:62-118 with the exact sum."""
+    return nudft_type3([x, y, z], weights, [u, v, w])
+
+
+def cpu_nufft2d_type1(x, y, weights, n_modes, index, eps=None, **_):
+    """cpu/nufft.py:120-175: type-1 to (n_modes, n_modes) in FFT order
+    (modeord=1), then fancy-index the integer baselines (negative indices wrap,
+    which is exactly what FFT ordering needs).  The mode (k1,k2) of finufft's
+    type-1 is sum_j c_j exp(+i (k1 x_j + k2 y_j)), so picking mode ``index`` is
+    the direct sum at integer targets.
+    """
+    idx = np.asarray(index)
+    return nudft_type3([x, y], weights, [idx[0].astype(float), idx[1].astype(float)])
+
+
+def run_nufft(
+    apparent_coherency, topo, uvw, bls, flipped, bls_idxs, use_type1, is_coplanar,
+    tx, ty, type1_n_modes, nfeeds,
+):
+    """Dispatch + flip/conj + reshape/swapaxes (cpu_simulate.py:205-300)."""
+    nbls_here = len(bls_idxs)
+    flipped = np.asarray(flipped, dtype=bool)
+    if use_type1:
+        bls_here = np.where(flipped, -bls[:, bls_idxs], bls[:, bls_idxs])  # :259
+        v = cpu_nufft2d_type1(tx, ty, apparent_coherency, type1_n_modes, bls_here)
+    else:
+        _uvw = np.where(flipped, -uvw[:, bls_idxs], uvw[:, bls_idxs])  # :271
+        if is_coplanar:
+            v = cpu_nufft2d(topo[0], topo[1], apparent_coherency, _uvw[0], _uvw[1])
+        else:
+            v = cpu_nufft3d(
+                topo[0], topo[1], topo[2], apparent_coherency, _uvw[0], _uvw[1], _uvw[2]
+            )
+    v = np.where(flipped, np.conj(v), v)  # :298
+    return np.swapaxes(v.reshape(nfeeds, nfeeds, nbls_here), 2, 0)  # :300
+
+
+def compute_basis_visibilities(
+    beam_evaluations, flux_here, ant1_idxs, ant2_idxs, beam_coefs, freqidx, topo, uvw,
+    bls, tx, ty, nbls, nfeeds, use_type1, is_coplanar, type1_n_modes,
+    polarized=False, polarized_sky_model=False,
+):
+    """Eigenbeam path (cpu_simulate.py:303-470)."""
+    K = len(beam_evaluations)
+    vis_out = np.zeros((nbls, nfeeds, nfeeds), dtype=complex)
+    flipped = np.zeros(nbls, dtype=bool)  # :403
+    bls_idxs = np.arange(nbls)
+    a1 = beam_coefs[ant1_idxs, :, freqidx].conj()  # :416
+    a2 = beam_coefs[ant2_idxs, :, freqidx]  # :417
+    for k in range(K):
+        for l in range(k, K):
+            phi = compute_apparent_coherency(
+                beam_evaluations, k, l, flux_here, freqidx, polarized,
+                polarized_sky_model, nfeeds,
+            )
+            vkl = run_nufft(
+                phi, topo, uvw, bls, flipped, bls_idxs, use_type1, is_coplanar,
+                tx, ty, type1_n_modes, nfeeds,
+            )
+            vis_out += (a1[:, k] * a2[:, l])[:, None, None] * vkl  # :461-462
+            if l != k:
+                vis_out += (a1[:, l] * a2[:, k])[:, None, None] * vkl.swapaxes(1, 2)  # :464-468
+    return vis_out
+
+
+# ---------------------------------------------------------------------------
+# Third-party boundaries restated (matvis / pyuvdata) -- PARITY UNPINNED
+# ---------------------------------------------------------------------------
+def enu_to_az_za(enu_e, enu_n, orientation="uvbeam", periodic_azimuth=True):
+    """matvis.coordinates.enu_to_az_za as called at cpu_simulate.py:957-959.
+
+    [from memory of matvis' public source; not in this container]
+    za = pi/2 - arcsin(sqrt(1 - e^2 - n^2)); astropy az = arctan2(e, n);
+    'uvbeam' az = pi/2 - az (east through north), wrapped to [0, 2pi).
+    """
+    lsqr = enu_n * enu_n + enu_e * enu_e
+    zeta = np.sqrt(np.clip(1.0 - lsqr, 0.0, None))
+    az = np.arctan2(enu_e, enu_n)
+    za = 0.5 * np.pi - np.arcsin(zeta)
+    if orientation == "uvbeam":
+        az = 0.5 * np.pi - az
+    if periodic_azimuth:
+        az = np.mod(az, 2 * np.pi)
+    return az, za
+
+
+def eq_unit_vectors(ra, dec):
+    """ICRS unit vectors (3, N)."""
+    cd = np.cos(dec)
+    return np.array([cd * np.cos(ra), cd * np.sin(ra), np.sin(dec)])
+
+
+def gmst_rad(jd):
+    """Greenwich mean sidereal time (IAU-1982 polynomial), radians."""
+    d = np.asarray(jd, dtype=float) - 2451545.0
+    T = d / 36525.0
+    deg = 280.46061837 + 360.98564736629 * d + 0.000387933 * T * T - T**3 / 38710000.0
+    return np.deg2rad(np.mod(deg, 360.0))
+
+
+def eq_to_enu_matrix(lst, lat):
+    """3x3 rotation taking equatorial unit vectors to local (east, north, up)."""
+    sl, cl = np.sin(lst), np.cos(lst)
+    sp, cp = np.sin(lat), np.cos(lat)
+    return np.array(
+        [[-sl, cl, 0.0], [-sp * cl, -sp * sl, cp], [cp * cl, cp * sl, sp]]
+    )
+
+
+class SimpleCoordinateRotation:
+    """Stand-in for matvis CoordinateRotation (cpu_simulate.py:693-704,913,937,940).
+
+    Documented approximation: a pure sidereal rotation of the catalog
+    (no precession / nutation / aberration / refraction).  ``rotate`` keeps all
+    sources; ``select_chunk`` returns the above-horizon ones of that chunk
+    (up > 0) with their flux rows, like matvis does.
+    """
+
+    def __init__(self, flux, times, telescope_loc, ra, dec, chunk_size=None):
+        self.flux = flux
+        self.times = np.asarray(times, dtype=float)
+        self.lat, self.lon = _latlon(telescope_loc)
+        self.eq = eq_unit_vectors(np.asarray(ra, float), np.asarray(dec, float))
+        self.nsrc = self.eq.shape[1]
+        self.chunk_size = chunk_size or self.nsrc
+
+    def setup(self):
+        pass
+
+    def rotation_matrix(self, ti):
+        return eq_to_enu_matrix(gmst_rad(self.times[ti]) + self.lon, self.lat)
+
+    def rotate(self, ti):
+        self._topo = self.rotation_matrix(ti) @ self.eq
+
+    def select_chunk(self, chunk, ti=None):
+        sl = slice(chunk * self.chunk_size, min(self.nsrc, (chunk + 1) * self.chunk_size))
+        topo = self._topo[:, sl]
+        above = topo[2] > 0
+        return np.ascontiguousarray(topo[:, above]), self.flux[sl][above], int(above.sum())
+
+
+def _latlon(telescope_loc):
+    """Accept (lat, lon[, height]) in radians or an object with .lat/.lon in radians."""
+    if hasattr(telescope_loc, "lat"):
+        lat, lon = telescope_loc.lat, telescope_loc.lon
+        lat = getattr(lat, "rad", lat)
+        lon = getattr(lon, "rad", lon)
+        return float(lat), float(lon)
+    return float(telescope_loc[0]), float(telescope_loc[1])
+
+
+def _bessel_j1(x):
+    from scipy.special import j1
+
+    return j1(x)
+
+
+class AiryBeam:
+    """Analytic Airy dish, the pyuvdata ``AiryBeam`` the reference tests use
+    (tests/test_beam_basis.py:33-42) [formula from memory of pyuvdata's docs]:
+    E-field 2 J1(x)/x with x = pi D nu sin(za) / c in all four Jones slots of
+    the (2 vector axes, 2 feeds) response; power beam is its square.
+    """
+
+    def __init__(self, diameter: float, beam_type: str = "efield"):
+        self.diameter = float(diameter)
+        self.beam_type = beam_type
+
+    def efield_scalar(self, za, freq):
+        x = np.pi * self.diameter * freq * np.sin(za) / speed_of_light
+        out = np.ones_like(x)
+        nz = x != 0
+        out[nz] = 2.0 * _bessel_j1(x[nz]) / x[nz]
+        return out
+
+    def compute_response(self, az_array, za_array, freq_array, **_):
+        f = float(np.atleast_1d(freq_array)[0])
+        e = self.efield_scalar(np.asarray(za_array, float), f)
+        if self.beam_type == "power":
+            return (e * e)[None, None, None, :].astype(complex)
+        out = np.empty((2, 2, 1, e.size), dtype=complex)
+        out[:] = e
+        return out
+
+
+class TabulatedBeam:
+    """A UVBeam-like table on a regular (za, az) grid, order-1 interpolation.
+
+    data[freq, ax, feed, iza, iaz] complex (efield) or data[freq, iza, iaz]
+    real (power).  az is periodic with period 2*pi (naz cells of width
+    2*pi/naz), za runs 0..za_max inclusive over nza nodes.  Stands in for
+    pyuvdata's az_za_map_coordinates(order=1) at cpu/beams.py:69-74.
+    """
+
+    def __init__(self, data, freqs, za_max=np.pi, beam_type="efield"):
+        self.data = np.asarray(data)
+        self.freqs = np.asarray(freqs, dtype=float)
+        self.za_max = float(za_max)
+        self.beam_type = beam_type
+        self.nza, self.naz = self.data.shape[-2:]
+
+    def _weights(self, az, za):
+        fa = np.mod(az, 2 * np.pi) / (2 * np.pi / self.naz)
+        ia0 = np.floor(fa).astype(int)
+        wa = fa - ia0
+        ia0 %= self.naz
+        ia1 = (ia0 + 1) % self.naz
+        fz = np.clip(za / (self.za_max / (self.nza - 1)), 0, self.nza - 1)
+        iz0 = np.minimum(np.floor(fz).astype(int), self.nza - 2)
+        wz = fz - iz0
+        return ia0, ia1, wa, iz0, iz0 + 1, wz
+
+    def compute_response(self, az_array, za_array, freq_array, **_):
+        f = float(np.atleast_1d(freq_array)[0])
+        fi = int(np.argmin(np.abs(self.freqs - f)))
+        ia0, ia1, wa, iz0, iz1, wz = self._weights(
+            np.asarray(az_array, float), np.asarray(za_array, float)
+        )
+        tab = self.data[fi]
+        v = (
+            tab[..., iz0, ia0] * (1 - wz) * (1 - wa)
+            + tab[..., iz0, ia1] * (1 - wz) * wa
+            + tab[..., iz1, ia0] * wz * (1 - wa)
+            + tab[..., iz1, ia1] * wz * wa
+        )
+        if self.beam_type == "power":
+            return v[None, None, None, :].astype(complex)
+        return v[:, :, None, :].astype(complex)
+
+
+def evaluate_beam(beam, az, za, polarized, freq):
+    """CPUBeamEvaluator.evaluate_beam (cpu/beams.py:12-89)."""
+    r = beam.compute_response(az_array=az, za_array=za, freq_array=np.atleast_1d(freq))
+    return r[:, :, 0, :] if polarized else r[0, 0, 0, :]
+
+
+# ---------------------------------------------------------------------------
+# Setup helpers                                               core/utils.py
+# ---------------------------------------------------------------------------
+def get_pos_reds(antpos, decimals=3, include_autos=True):
+    """Redundant-baseline groups (core/utils.py:11-71)."""
+    keys = list(antpos)
+    uv_to_key, reds = {}, {}
+    for ai in keys:
+        for aj in keys:
+            if ai < aj or (include_autos and ai == aj):
+                u, v, _ = np.round(antpos[aj] - antpos[ai], decimals)
+                u, v = float(u) + 0.0, float(v) + 0.0
+                if (u, v) not in uv_to_key and (-u, -v) not in uv_to_key:
+                    reds[(ai, aj)] = [(ai, aj)]
+                    uv_to_key[(u, v)] = (ai, aj)
+                elif (-u, -v) in uv_to_key:
+                    reds[uv_to_key[(-u, -v)]].append((aj, ai))
+                else:
+                    reds[uv_to_key[(u, v)]].append((ai, aj))
+    out = []
+    for red in reds.values():
+        a1, a2 = red[0]
+        if (antpos[a2] - antpos[a1])[1] < 0:
+            out.append([(b[1], b[0]) for b in red])
+        else:
+            out.append(red)
+    return out
+
+
+def get_plane_to_xy_rotation_matrix(antvecs):
+    """Plane fit + Rodrigues rotation (core/utils.py:74-119)."""
+    x, y, z = np.asarray(antvecs, float).T
+    A = np.array([x, y, np.ones_like(z)]).T
+    (sx, sy, _), *_ = np.linalg.lstsq(A, z, rcond=None)
+    if np.isclose(sx, 0) and np.isclose(sy, 0.0):
+        return np.eye(3)
+    normal = np.array([sx, sy, -1.0])
+    normal /= np.linalg.norm(normal)
+    axis = np.array([sy, -sx, 0.0])
+    axis /= np.linalg.norm(axis)
+    theta = np.arccos(-normal[2])
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(theta) * K + (1 - np.cos(theta)) * (K @ K)
+
+
+def get_task_chunks(nprocesses, nfreqs, ntimes):
+    """(time, freq) task chunking (core/utils.py:122-187)."""
+    ntasks = ntimes * nfreqs
+    if ntasks < 2 * nprocesses:
+        return 1, [slice(None)], [slice(None)], nfreqs, ntimes
+    nt = int(np.ceil(ntimes / nprocesses))
+    nf, nfc = nfreqs, 1
+    size = nf * nt
+    sizes = [size]
+    while nf > 1 and (nprocesses * size) > ntasks:
+        nfc += 1
+        nf = int(np.ceil(nfreqs / nfc))
+        nt = int(np.ceil(ntimes / (nprocesses / nfc)))
+        size = nf * nt
+        sizes.append(size)
+    nfc = 1 + int(np.argmin(sizes))
+    nf = int(np.ceil(nfreqs / nfc))
+    nt = int(np.ceil(ntimes / (nprocesses / nfc)))
+    ntc = int(np.ceil(nprocesses / nfc))
+    fch = [slice(nf * i, min(nfreqs, (i + 1) * nf)) for i in range(nfc)] * ntc
+    tch = sum(([slice(i * nt, min(ntimes, (i + 1) * nt))] * nfc for i in range(ntc)), start=[])
+    return nprocesses, fch, tch, nf, nt
+
+
+# ---------------------------------------------------------------------------
+# The hot loop and its caller                              cpu/cpu_simulate.py
+# ---------------------------------------------------------------------------
+def evaluate_vis_chunk(
+    time_idx, freq_idx, beam_list, coord_mgr, rotation_matrix, antnums, baselines, bls,
+    freqs, nfeeds, beam_idx=None, polarized=False, polarized_sky_model=False,
+    is_coplanar=False, nchunks=1, beam_coefs=None,
+):
+    """_evaluate_vis_chunk (cpu_simulate.py:856-1071), type-3 branch only.
+
+    Returns the reference's scratch layout (nt_here, nbls, nfeeds, nfeeds, nf_here).
+    """
+    nbls = bls.shape[1]
+    ntimes, nfreqs = len(coord_mgr.times), len(freqs)
+    t_range = range(ntimes)[time_idx]
+    f_range = range(nfreqs)[freq_idx]
+    vis = np.zeros((len(t_range), nbls, nfeeds, nfeeds, len(f_range)), dtype=complex)
+    coord_mgr.setup()
+    use_basis = beam_coefs is not None
+    if use_basis:
+        a1 = np.array([antnums.index(b[0]) for b in baselines])  # :920-921
+        a2 = np.array([antnums.index(b[1]) for b in baselines])
+    else:
+        pairs, pair_idx, pair_flip = prepare_beam_evaluation(antnums, baselines, beam_idx)
+    rot_is_identity = np.allclose(rotation_matrix, np.eye(3))  # :933
+    for tloc, ti in enumerate(t_range):
+        coord_mgr.rotate(ti)  # :937
+        for chunk in range(nchunks):
+            topo, flux, nsim = coord_mgr.select_chunk(chunk, ti)  # :940
+            topo = np.array(topo[:, :nsim], dtype=float)
+            flux = flux[:nsim]
+            if nsim == 0:
+                continue
+            az, za = enu_to_az_za(topo[0], topo[1], orientation="uvbeam")  # :957-959
+            if not rot_is_identity:
+                inplace_rot(rotation_matrix, topo)  # :961-962
+            topo *= 2 * np.pi  # :967
+            for floc, fi in enumerate(f_range):
+                freq = freqs[fi]
+                uvw = bls * freq  # :973
+                bev = [
+                    evaluate_beam(b, az, za, polarized, freq).astype(complex)
+                    for b in beam_list
+                ]  # :975-984
+                if use_basis:
+                    vis[tloc, :, :, :, floc] += compute_basis_visibilities(
+                        bev, flux, a1, a2, beam_coefs, fi, topo, uvw, bls, None, None,
+                        nbls, nfeeds, False, is_coplanar, None, polarized,
+                        polarized_sky_model,
+                    )  # :998-1024
+                else:
+                    for bi, bj in pairs:  # :1030
+                        idxs = np.asarray(pair_idx[(bi, bj)], dtype=int)
+                        if idxs.size == 0:
+                            continue
+                        c = compute_apparent_coherency(
+                            bev, bi, bj, flux, fi, polarized, polarized_sky_model, nfeeds
+                        )
+                        v = run_nufft(
+                            c, topo, uvw, bls, pair_flip[(bi, bj)], idxs, False,
+                            is_coplanar, None, None, None, nfeeds,
+                        )
+                        vis[tloc, idxs, :, :, floc] += v  # :1069
+    return vis
+
+
+def simulate(
+    ants, freqs, fluxes, beam_list, ra, dec, times, telescope_loc, baselines=None,
+    beam_idx=None, polarized=False, flat_array_tol=1e-6, nchunks=1, beam_coefs=None,
+    coord_mgr=None,
+):
+    """CPUSimulationEngine.simulate (cpu_simulate.py:537-854), force_use_type3=True,
+    nprocesses=1, precision=2.  Returns (nf, nt, nbls) or (nf, nt, 2, 2, nbls)."""
+    freqs = np.asarray(freqs, dtype=float)
+    nfeeds = 2 if polarized else 1
+    if baselines is None:
+        baselines = [red[0] for red in get_pos_reds(ants, include_autos=True)]  # :614-616
+    coherency, pol_sky = prepare_source_catalog(np.asarray(fluxes), polarized)  # :622
+    antnums = list(ants.keys())
+    key2idx = {a: i for i, a in enumerate(antnums)}
+    antvecs = np.array([ants[a] for a in ants], dtype=float)
+    R = np.ascontiguousarray(get_plane_to_xy_rotation_matrix(antvecs).T)  # :642-643
+    rot = R @ antvecs.T
+    bls = np.array(
+        [rot[:, key2idx[b[1]]] - rot[:, key2idx[b[0]]] for b in baselines]
+    ).T.reshape(3, len(baselines))  # :650-652
+    is_coplanar = bool(np.all(np.abs(bls[2]) <= flat_array_tol))  # :655
+    bls = bls / speed_of_light  # :658
+    if coord_mgr is None:
+        chunk_size = int(np.ceil(np.size(dec) / nchunks))  # :691
+        coord_mgr = SimpleCoordinateRotation(
+            coherency, times, telescope_loc, ra, dec, chunk_size=chunk_size
+        )
+    vis = evaluate_vis_chunk(
+        slice(None), slice(None), beam_list, coord_mgr, R, antnums, baselines, bls, freqs,
+        nfeeds, beam_idx=beam_idx, polarized=polarized, polarized_sky_model=pol_sky,
+        is_coplanar=is_coplanar, nchunks=nchunks, beam_coefs=beam_coefs,
+    )
+    if polarized:
+        return np.transpose(vis, (4, 0, 2, 3, 1))  # :851
+    return np.moveaxis(vis[..., 0, 0, :], 2, 0)  # :853
