@@ -124,6 +124,89 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
     FV_HIP(hipGetLastError());
 }
 
+template <typename T>
+static void beam_eval_host(int device, int polarized, int kind, double diameter, int nft, int nza,
+                           int naz, double za_max, const void *table, int fidx, double freq,
+                           int64_t n, const void *az, const void *za, void *out) {
+    FV_REQUIRE(kind == 0 || kind == 1, "beam kind must be 0 (Airy) or 1 (table)");
+    FV_REQUIRE(n >= 0 && (n == 0 || (az && za && out)), "bad beam_eval arrays");
+    FV_HIP(hipSetDevice(device));
+    if (n == 0) return;
+    StreamGuard sg;
+    DevBuf daz, dza, dout, dtab;
+    BeamDesc b{};
+    b.kind = kind;
+    b.diameter = diameter;
+    if (kind == 1) {
+        FV_REQUIRE(table && nza >= 2 && naz >= 1 && nft >= 1 && za_max > 0, "bad beam table");
+        FV_REQUIRE(nft == 1 || (fidx >= 0 && fidx < nft), "freq_index outside the beam table");
+        const size_t bytes = (polarized ? 64 : 8) * (size_t)nft * nza * naz;
+        dtab.reserve(bytes);
+        FV_HIP(hipMemcpyAsync(dtab.p, table, bytes, hipMemcpyHostToDevice, sg.s));
+        b.table = dtab.p;
+        b.nfreq_tab = nft;
+        b.nza = nza;
+        b.naz = naz;
+        b.za_max = za_max;
+    } else {
+        FV_REQUIRE(diameter > 0, "diameter must be positive");
+    }
+    const size_t nout = (polarized ? 4 : 1) * (size_t)n;
+    daz.reserve(sizeof(T) * n);
+    dza.reserve(sizeof(T) * n);
+    dout.reserve(sizeof(cplx<T>) * nout);
+    FV_HIP(hipMemcpyAsync(daz.p, az, sizeof(T) * n, hipMemcpyHostToDevice, sg.s));
+    FV_HIP(hipMemcpyAsync(dza.p, za, sizeof(T) * n, hipMemcpyHostToDevice, sg.s));
+    hipLaunchKernelGGL(k_beam_eval<T>, dim3(cdiv(n, 256)), dim3(256), 0, sg.s, b, polarized, fidx,
+                       freq, n, daz.as<T>(), dza.as<T>(), dout.as<cplx<T>>());
+    FV_HIP(hipMemcpyAsync(out, dout.p, sizeof(cplx<T>) * nout, hipMemcpyDeviceToHost, sg.s));
+    FV_HIP(hipStreamSynchronize(sg.s));
+    FV_HIP(hipGetLastError());
+}
+
+template <typename T>
+static void coherency_host(int device, int variant, int64_t n, const void *bi, const void *bj,
+                           const void *flux, void *out) {
+    FV_REQUIRE(variant >= 0 && variant <= 4, "coherency variant must be 0..4");
+    FV_REQUIRE(n >= 0 && (n == 0 || (bi && bj && flux && out)), "bad coherency arrays");
+    FV_HIP(hipSetDevice(device));
+    if (n == 0) return;
+    StreamGuard sg;
+    const size_t nb = (variant == 4 ? 1 : 4) * (size_t)n;
+    const bool cflux = variant == 1 || variant == 3;
+    const size_t fbytes = cflux ? sizeof(cplx<T>) * 4 * n : sizeof(T) * n;
+    DevBuf dbi, dbj, dfl, dout;
+    dbi.reserve(sizeof(cplx<T>) * nb);
+    dbj.reserve(sizeof(cplx<T>) * nb);
+    dfl.reserve(fbytes);
+    dout.reserve(sizeof(cplx<T>) * nb);
+    FV_HIP(hipMemcpyAsync(dbi.p, bi, sizeof(cplx<T>) * nb, hipMemcpyHostToDevice, sg.s));
+    FV_HIP(hipMemcpyAsync(dbj.p, bj, sizeof(cplx<T>) * nb, hipMemcpyHostToDevice, sg.s));
+    FV_HIP(hipMemcpyAsync(dfl.p, flux, fbytes, hipMemcpyHostToDevice, sg.s));
+    hipLaunchKernelGGL(k_apparent_coherency<T>, dim3(cdiv(n, 256)), dim3(256), 0, sg.s, variant, n,
+                       dbi.as<cplx<T>>(), dbj.as<cplx<T>>(), dfl.p, dout.as<cplx<T>>());
+    FV_HIP(hipMemcpyAsync(out, dout.p, sizeof(cplx<T>) * nb, hipMemcpyDeviceToHost, sg.s));
+    FV_HIP(hipStreamSynchronize(sg.s));
+    FV_HIP(hipGetLastError());
+}
+
+template <typename T>
+static void inplace_rot_host(int device, const double *rot, void *b, int64_t n) {
+    FV_REQUIRE(rot && n >= 0 && (b || n == 0), "bad inplace_rot arrays");
+    FV_HIP(hipSetDevice(device));
+    if (n == 0) return;
+    StreamGuard sg;
+    DevBuf db;
+    db.reserve(sizeof(T) * 3 * n);
+    Rot9 r;
+    std::memcpy(r.m, rot, sizeof(r.m));
+    FV_HIP(hipMemcpyAsync(db.p, b, sizeof(T) * 3 * n, hipMemcpyHostToDevice, sg.s));
+    hipLaunchKernelGGL(k_inplace_rot<T>, dim3(cdiv(n, 256)), dim3(256), 0, sg.s, r, db.as<T>(), n);
+    FV_HIP(hipMemcpyAsync(b, db.p, sizeof(T) * 3 * n, hipMemcpyDeviceToHost, sg.s));
+    FV_HIP(hipStreamSynchronize(sg.s));
+    FV_HIP(hipGetLastError());
+}
+
 }  // namespace fv
 
 using namespace fv;
@@ -178,6 +261,41 @@ int fv_nudft3_direct(int device, int precision, int dim, int64_t M, const void *
     });
 }
 
+int fv_beam_eval(int device, int precision, int polarized, int kind, double diameter,
+                 int nfreq_tab, int nza, int naz, double za_max, const void *table, int freq_index,
+                 double freq, int64_t n, const void *az, const void *za, void *out) {
+    return guarded([&] {
+        FV_REQUIRE(precision == 1 || precision == 2, "precision must be 1 or 2");
+        if (precision == 2)
+            beam_eval_host<double>(device, polarized, kind, diameter, nfreq_tab, nza, naz, za_max,
+                                   table, freq_index, freq, n, az, za, out);
+        else
+            beam_eval_host<float>(device, polarized, kind, diameter, nfreq_tab, nza, naz, za_max,
+                                  table, freq_index, freq, n, az, za, out);
+    });
+}
+
+int fv_apparent_coherency(int device, int precision, int variant, int64_t n, const void *beam_i,
+                          const void *beam_j, const void *flux, void *out) {
+    return guarded([&] {
+        FV_REQUIRE(precision == 1 || precision == 2, "precision must be 1 or 2");
+        if (precision == 2)
+            coherency_host<double>(device, variant, n, beam_i, beam_j, flux, out);
+        else
+            coherency_host<float>(device, variant, n, beam_i, beam_j, flux, out);
+    });
+}
+
+int fv_inplace_rot(int device, int precision, const double *rot, void *b, int64_t n) {
+    return guarded([&] {
+        FV_REQUIRE(precision == 1 || precision == 2, "precision must be 1 or 2");
+        if (precision == 2)
+            inplace_rot_host<double>(device, rot, b, n);
+        else
+            inplace_rot_host<float>(device, rot, b, n);
+    });
+}
+
 int fv_sim_create(fv_sim **h, int device, int precision, double eps, double upsampfac,
                   int polarized) {
     return guarded([&] {
@@ -212,6 +330,9 @@ int fv_sim_set_sources(fv_sim *h, int64_t nsrc, int nfreq, const void *eq, const
 }
 int fv_sim_set_times(fv_sim *h, int ntimes, const double *rot) {
     FV_SIM_CALL(FV_REQUIRE(ntimes >= 0 && (rot || !ntimes), "bad times"); h->impl->set_times(ntimes, rot));
+}
+int fv_sim_set_topo(fv_sim *h, int ntimes, int64_t nsrc, const void *topo, int on_device) {
+    FV_SIM_CALL(FV_REQUIRE(ntimes >= 1 && topo, "bad topo"); h->impl->set_topo(ntimes, nsrc, topo, on_device));
 }
 int fv_sim_set_freqs(fv_sim *h, int nfreq, const double *freqs) {
     FV_SIM_CALL(FV_REQUIRE(nfreq >= 1 && freqs, "bad freqs"); h->impl->set_freqs(nfreq, freqs));

@@ -162,6 +162,101 @@ __device__ inline double eval_power(const BeamDesc &b, int fidx, double freq, do
            p[(int64_t)w.iz1 * b.naz + w.ia1] * w.wz * w.wa;
 }
 
+// out[a][p] = sum_b conj(Ai[b][a]) Aj[b][p] * I      (cpu/beams.py:129-145, 182-212;
+// einsum "bas,s,bps->aps" in tests/test_cpu_beams.py:870)
+__host__ __device__ inline void coh_AhB_flux(const cplx<double> Ai[4], const cplx<double> Aj[4],
+                                             double I, cplx<double> o[4]) {
+    for (int a = 0; a < 2; ++a)
+        for (int p = 0; p < 2; ++p)
+            o[a * 2 + p] = cscale(cadd(cmul(cconj(Ai[a]), Aj[p]), cmul(cconj(Ai[2 + a]), Aj[2 + p])), I);
+}
+
+// out[a][p] = sum_{b,k} conj(Ai[b][a]) C[b][k] Aj[k][p]   (cpu/beams.py:147-180, 215-246;
+// einsum "bas,bks,kps->aps" in tests/test_cpu_beams.py:953)
+__host__ __device__ inline void coh_AhCB(const cplx<double> Ai[4], const cplx<double> C[4],
+                                         const cplx<double> Aj[4], cplx<double> o[4]) {
+    for (int a = 0; a < 2; ++a) {
+        const cplx<double> t0 = cadd(cmul(cconj(Ai[a]), C[0]), cmul(cconj(Ai[2 + a]), C[2]));
+        const cplx<double> t1 = cadd(cmul(cconj(Ai[a]), C[1]), cmul(cconj(Ai[2 + a]), C[3]));
+        for (int p = 0; p < 2; ++p) o[a * 2 + p] = cadd(cmul(t0, Aj[p]), cmul(t1, Aj[2 + p]));
+    }
+}
+
+__host__ __device__ inline cplx<double> csqrt_principal(cplx<double> z) {
+    const double r = hypot(z.re, z.im);
+    if (r == 0.0) return {0.0, 0.0};
+    double sr = sqrt(0.5 * (r + fabs(z.re)));
+    double si = 0.5 * z.im / sr;
+    if (z.re < 0) {  // swap so that the real part stays >= 0
+        const double t = sr;
+        sr = fabs(si);
+        si = z.im < 0 ? -t : t;
+    }
+    return {sr, si};
+}
+
+// Stand-alone coherency op on reference-layout arrays (2, 2, n) [a][b][src]:
+// variant 0: beam <- (A^H A) I          get_apparent_flux_polarized_beam   cpu/beams.py:129-145
+//         1: beam <- A^H C A            get_apparent_flux_polarized        cpu/beams.py:147-180
+//         2: out  <- Ai^H Aj I          ..._polarized_beam_pair            cpu/beams.py:182-212
+//         3: out  <- Ai^H C Aj          ..._polarized_pair                 cpu/beams.py:215-246
+//         4: out  <- sqrt(Bi Bj) I      unpolarized, (n) arrays            cpu_simulate.py:183-187
+template <typename T>
+__global__ void k_apparent_coherency(int variant, int64_t n, const cplx<T> *__restrict__ bi,
+                                     const cplx<T> *__restrict__ bj, const void *__restrict__ flux,
+                                     cplx<T> *__restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    if (variant == 4) {
+        const cplx<double> a = {(double)bi[s].re, (double)bi[s].im}, b = {(double)bj[s].re, (double)bj[s].im};
+        const cplx<double> r = cscale(csqrt_principal(cmul(a, b)), (double)((const T *)flux)[s]);
+        out[s] = {(T)r.re, (T)r.im};
+        return;
+    }
+    cplx<double> Ai[4], Aj[4], o[4];
+    for (int i = 0; i < 4; ++i) {
+        Ai[i] = {(double)bi[i * n + s].re, (double)bi[i * n + s].im};
+        Aj[i] = {(double)bj[i * n + s].re, (double)bj[i * n + s].im};
+    }
+    if (variant == 0 || variant == 2) {
+        coh_AhB_flux(Ai, Aj, (double)((const T *)flux)[s], o);
+    } else {
+        const cplx<T> *Cp = (const cplx<T> *)flux;
+        cplx<double> C[4];
+        for (int i = 0; i < 4; ++i) C[i] = {(double)Cp[i * n + s].re, (double)Cp[i * n + s].im};
+        coh_AhCB(Ai, C, Aj, o);
+    }
+    for (int i = 0; i < 4; ++i) out[i * n + s] = {(T)o[i].re, (T)o[i].im};
+}
+
+// Stand-alone beam evaluation (GPUBeamEvaluator.evaluate_beam, gpu/beams.py:18-66):
+// polarized -> (2, 2, n) [ax][feed][src]; else (n) power (imaginary part 0).
+template <typename T>
+__global__ void k_beam_eval(BeamDesc b, int polarized, int fidx, double freq, int64_t n,
+                            const T *__restrict__ az, const T *__restrict__ za,
+                            cplx<T> *__restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    if (!polarized) {
+        out[s] = {(T)eval_power(b, fidx, freq, (double)az[s], (double)za[s]), T(0)};
+        return;
+    }
+    cplx<double> A[4];
+    eval_jones(b, fidx, freq, (double)az[s], (double)za[s], A);
+    for (int i = 0; i < 4; ++i) out[i * n + s] = {(T)A[i].re, (T)A[i].im};
+}
+
+// b[:, j] <- rot b[:, j]   (gpu/utils.py:8-22; cpu/utils.py:5-24)
+template <typename T>
+__global__ void k_inplace_rot(Rot9 r, T *__restrict__ b, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double x = b[j], y = b[n + j], z = b[2 * n + j];
+    b[j] = (T)(r.m[0] * x + r.m[1] * y + r.m[2] * z);
+    b[n + j] = (T)(r.m[3] * x + r.m[4] * y + r.m[5] * z);
+    b[2 * n + j] = (T)(r.m[6] * x + r.m[7] * y + r.m[8] * z);
+}
+
 struct StrengthArgs {
     int64_t M;          // above-horizon sources
     int nfg;            // frequencies in this group
@@ -206,8 +301,7 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ perm,
         const double bi = eval_power(a.bi, fidx, freq, azv, zav);
         const double bj = a.same_beam ? bi : eval_power(a.bj, fidx, freq, azv, zav);
         const double I = (double)((const T *)flux)[js * a.nfreq + fidx];
-        const double prod = bi * bj;
-        cplx<double> c = prod >= 0 ? cplx<double>{sqrt(prod) * I, 0.0} : cplx<double>{0.0, sqrt(-prod) * I};
+        cplx<double> c = cscale(csqrt_principal(cplx<double>{bi * bj, 0.0}), I);
         c = cmul(c, pre);
         cs[p * a.nfg + fgi] = {(T)c.re, (T)c.im};
         return;
@@ -221,29 +315,16 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ perm,
     }
     cplx<double> o[4];
     if (!a.pol_sky) {
-        // cpu/beams.py:129-145,182-212: out[a][p] = sum_b conj(Ai[b][a]) Aj[b][p] * I
         const double I = (double)((const T *)flux)[js * a.nfreq + fidx];
-        for (int aa = 0; aa < 2; ++aa)
-            for (int pp = 0; pp < 2; ++pp) {
-                cplx<double> s = cadd(cmul(cconj(Ai[0 * 2 + aa]), Aj[0 * 2 + pp]),
-                                      cmul(cconj(Ai[1 * 2 + aa]), Aj[1 * 2 + pp]));
-                o[aa * 2 + pp] = cscale(s, I);
-            }
+        coh_AhB_flux(Ai, Aj, I, o);
     } else {
-        // cpu_simulate.py:142-156 + cpu/beams.py:147-180,215-246 on A' = flip(A, axis 0):
-        // out[a][p] = sum_{b,k} conj(A'i[b][a]) C[b][k] A'j[k][p]
+        // cpu_simulate.py:142-156: the kernels run on A' = flip(A, axis 0)
         const cplx<T> *Cp = (const cplx<T> *)flux + (js * a.nfreq + fidx) * 4;
         cplx<double> C[4];
         for (int i = 0; i < 4; ++i) C[i] = {(double)Cp[i].re, (double)Cp[i].im};
-        cplx<double> Fi[4] = {Ai[2], Ai[3], Ai[0], Ai[1]};
-        cplx<double> Fj[4] = {Aj[2], Aj[3], Aj[0], Aj[1]};
-        for (int aa = 0; aa < 2; ++aa) {
-            // tmp[k] = sum_b conj(Fi[b][a]) C[b][k]
-            cplx<double> t0 = cadd(cmul(cconj(Fi[0 * 2 + aa]), C[0]), cmul(cconj(Fi[1 * 2 + aa]), C[2]));
-            cplx<double> t1 = cadd(cmul(cconj(Fi[0 * 2 + aa]), C[1]), cmul(cconj(Fi[1 * 2 + aa]), C[3]));
-            for (int pp = 0; pp < 2; ++pp)
-                o[aa * 2 + pp] = cadd(cmul(t0, Fj[0 * 2 + pp]), cmul(t1, Fj[1 * 2 + pp]));
-        }
+        const cplx<double> Fi[4] = {Ai[2], Ai[3], Ai[0], Ai[1]};
+        const cplx<double> Fj[4] = {Aj[2], Aj[3], Aj[0], Aj[1]};
+        coh_AhCB(Fi, C, Fj, o);
     }
     cplx<T> *dst = cs + (p * a.nfg + fgi) * 4;
     for (int r = 0; r < 4; ++r) {
@@ -295,6 +376,7 @@ struct SimBase {
     virtual void set_sources(int64_t nsrc, int nfreq, const void *eq, const void *flux, int pol_sky,
                              int on_device) = 0;
     virtual void set_times(int ntimes, const double *rot) = 0;
+    virtual void set_topo(int ntimes, int64_t nsrc, const void *topo, int on_device) = 0;
     virtual void set_freqs(int nfreq, const double *freqs) = 0;
     virtual void set_array(const double *R, int64_t nbls, const double *bls, int coplanar) = 0;
     virtual void set_nbeams(int n) = 0;
@@ -327,6 +409,8 @@ class Sim : public SimBase {
     DevBuf d_eq, d_flux;
 
     std::vector<Rot9> rots;
+    int ntimes_topo = 0;  // > 0: per-time topocentric unit vectors were supplied instead
+    DevBuf d_topo;        // (ntimes, 3, nsrc) T
     std::vector<double> freqs;
     DevBuf d_freqs;
 
@@ -436,8 +520,16 @@ class Sim : public SimBase {
         upload(d_flux, flux, (pol_sky ? sizeof(T) * 8 : sizeof(T)) * (size_t)n * nfreq, on_device);
     }
     void set_times(int ntimes, const double *rot) override {
+        ntimes_topo = 0;
         rots.resize(ntimes);
         for (int i = 0; i < ntimes; ++i) std::memcpy(rots[i].m, rot + 9 * i, 9 * sizeof(double));
+    }
+    void set_topo(int ntimes, int64_t n, const void *topo, int on_device) override {
+        FV_HIP(hipSetDevice(device));
+        FV_REQUIRE(n == nsrc, "topo source count != catalog (set_sources first)");
+        ntimes_topo = ntimes;
+        rots.assign(ntimes, Rot9{{1, 0, 0, 0, 1, 0, 0, 0, 1}});
+        upload(d_topo, topo, sizeof(T) * 3 * (size_t)n * ntimes, on_device);
     }
     void set_freqs(int nf, const double *f) override {
         FV_HIP(hipSetDevice(device));
@@ -618,12 +710,14 @@ class Sim : public SimBase {
             size_t e0 = ev_begin(TM_PREP);
             int M = 0;
             if (nsrc > 0) {
+                // either R_t . eq on the fly, or topocentric vectors the caller computed
+                const T *vec = ntimes_topo ? d_topo.as<T>() + (size_t)ti * 3 * nsrc : d_eq.as<T>();
                 hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, nsrc,
-                                   d_eq.as<T>(), rots[ti], d_blockcnt.as<int>());
+                                   vec, rots[ti], d_blockcnt.as<int>());
                 hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
                                    d_blockcnt.as<int>(), d_blockoff.as<int>(), nblk);
                 hipLaunchKernelGGL(k_horizon_compact<T>, dim3(nblk), dim3(256), 0, stream, nsrc,
-                                   d_eq.as<T>(), rots[ti], rplane, d_blockoff.as<int>(),
+                                   vec, rots[ti], rplane, d_blockoff.as<int>(),
                                    d_xyz.as<T>(), cap, d_az.as<T>(), d_za.as<T>(),
                                    d_srcidx.as<int>());
                 FV_HIP(hipMemcpyAsync(&M, d_blockoff.as<int>() + nblk, sizeof(int),

@@ -1,0 +1,129 @@
+"""Seeded synthetic inputs for the benchmark configurations (BASELINE.json ``configs``,
+SURVEY.md section 8(d)).  Pure numpy; used by bench.py, __graft_entry__.smoke() and the tests.
+
+The antenna layouts are documented-synthetic stand-ins for ``hera_sim.antpos.hex_array``
+(reference docs/tutorials/fftvis_gridded_array.ipynb:107), which is not importable here.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .core.beams import AiryBeam, TabulatedBeam
+
+HERA_LAT = np.deg2rad(-30.7215)  # reference tests/test_wrapper.py:81-85
+HERA_LON = np.deg2rad(21.4283)
+SPACING = 14.6
+
+
+def hex_positions(side: int, spacing: float = SPACING) -> np.ndarray:
+    """Filled hexagon with ``side`` antennas per edge: 3 side (side - 1) + 1 positions, z = 0."""
+    pts = []
+    for q in range(-(side - 1), side):
+        for r in range(max(-(side - 1), -q - (side - 1)), min(side - 1, -q + side - 1) + 1):
+            pts.append((spacing * (q + 0.5 * r), spacing * (np.sqrt(3) / 2) * r, 0.0))
+    pts = np.array(pts)
+    order = np.lexsort((pts[:, 0], pts[:, 1]))
+    return pts[order]
+
+
+def hera_like_array(kind: str) -> dict:
+    """``hera7`` (side 2), ``hera37`` (side 4), ``hera350``: a split-core side-11 hexagon
+    (three 120-degree sectors displaced by thirds of the lattice vectors, one seam row removed:
+    320 antennas) plus 30 outriggers on the fifth ring of a 6x-spacing lattice (longest baseline
+    ~876 m)."""
+    if kind == "hera7":
+        pos = hex_positions(2)
+    elif kind == "hera37":
+        pos = hex_positions(4)
+    elif kind == "hera350":
+        core = hex_positions(11)
+        ang = np.mod(np.arctan2(core[:, 1], core[:, 0]), 2 * np.pi)
+        r = np.hypot(core[:, 0], core[:, 1])
+        seam = (np.abs(ang) < 1e-9) | (r < 1e-9)  # centre + the 10 antennas due east of it
+        core, ang = core[~seam], ang[~seam]
+        sector = (ang // (2 * np.pi / 3)).astype(int)
+        a1 = np.array([SPACING, 0.0, 0.0])
+        a2 = np.array([SPACING / 2, SPACING * np.sqrt(3) / 2, 0.0])
+        shift = np.array([0 * a1, (a1 + a2) / 3.0, (2 * a2 - a1) / 3.0])
+        core = core + shift[sector]
+        ring = []
+        big = 6 * SPACING
+        n = 5
+        for q in range(-n, n + 1):
+            for rr in range(max(-n, -q - n), min(n, -q + n) + 1):
+                if max(abs(q), abs(rr), abs(q + rr)) == n:
+                    ring.append((big * (q + 0.5 * rr), big * (np.sqrt(3) / 2) * rr, 0.0))
+        pos = np.vstack([core, np.array(ring)])
+        assert len(pos) == 350
+    else:
+        raise ValueError(kind)
+    return {i: p for i, p in enumerate(pos)}
+
+
+def all_cross_baselines(ants: dict):
+    keys = list(ants)
+    return [(a, b) for i, a in enumerate(keys) for b in keys[i + 1:]]
+
+
+def catalog(nsrc: int, freqs: np.ndarray, seed: int = 0, polarized_sky: bool = False):
+    """Isotropic point sources; flux U(0,1) (nu/nu0)^-0.8 (reference fftvis_tutorial.ipynb
+    cell 15); polarized sky adds Q,U,V ~ 0.1 I N(0,1)."""
+    rng = np.random.default_rng(seed)
+    ra = rng.uniform(0, 2 * np.pi, nsrc)
+    dec = np.arcsin(rng.uniform(-1, 1, nsrc))
+    amp = rng.uniform(0, 1, nsrc)
+    flux = amp[:, None] * (np.asarray(freqs)[None, :] / freqs[0]) ** -0.8
+    if polarized_sky:
+        quv = 0.1 * flux[:, :, None] * rng.normal(size=(nsrc, 1, 3))
+        flux = np.concatenate([flux[:, :, None], quv], axis=2)
+    return ra, dec, flux
+
+
+def synthetic_efield_table(freqs, diameter: float = 14.0, nza: int = 181, naz: int = 360):
+    """Tabulated Jones [freq, vector axis, feed, za, az] on a 1-degree grid: Airy amplitude times
+    a dipole-like rotation plus a smooth complex leakage term."""
+    from scipy.special import j1
+
+    za = np.linspace(0, np.pi, nza)
+    az = 2 * np.pi * np.arange(naz) / naz
+    Z, A = np.meshgrid(za, az, indexing="ij")
+    tab = np.empty((len(freqs), 2, 2, nza, naz), dtype=complex)
+    for i, f in enumerate(freqs):
+        x = np.pi * diameter * f * np.sin(Z) / 299792458.0
+        e = np.where(x == 0, 1.0, 2 * j1(x) / np.where(x == 0, 1, x))
+        leak = 0.05 * (1 + 0.5j) * np.sin(Z)
+        tab[i, 0, 0] = e * np.cos(A) + leak * np.sin(2 * A)
+        tab[i, 0, 1] = e * np.sin(A) + leak * np.cos(A)
+        tab[i, 1, 0] = -e * np.sin(A) * np.cos(Z) + leak * np.cos(2 * A)
+        tab[i, 1, 1] = e * np.cos(A) * np.cos(Z) - leak * np.sin(A)
+    return tab
+
+
+CONFIGS = {
+    # name: (array, nsrc, nfreq, ntimes, polarized, beam)
+    "C1": ("hera7", 100, 8, 2, False, "airy"),
+    "C2": ("hera37", 10_000, 64, 10, False, "airy"),
+    "C3": ("hera350", 100_000, 128, 20, True, "table"),
+    "C4": ("hera350", 1_000_000, 256, 60, True, "table"),
+}
+
+
+def make_config(name: str, seed: int = 0, nsrc=None, nfreq=None, ntimes=None):
+    """Inputs of one BASELINE.json configuration as a dict of simulate_vis keyword arguments
+    (optionally shrunk for tests)."""
+    arr, ns, nf, nt, pol, beamkind = CONFIGS[name]
+    ns, nf, nt = nsrc or ns, nfreq or nf, ntimes or nt
+    ants = hera_like_array(arr)
+    freqs = np.linspace(100e6, 200e6, nf)
+    times = np.linspace(2459845.0, 2459845.05, nt)
+    ra, dec, flux = catalog(ns, freqs, seed)
+    if beamkind == "airy":
+        beam = AiryBeam(14.0)
+    else:
+        beam = TabulatedBeam(synthetic_efield_table(freqs), freqs)
+    return dict(
+        ants=ants, fluxes=flux, ra=ra, dec=dec, freqs=freqs, times=times, beam=beam,
+        telescope_loc=(HERA_LAT, HERA_LON), baselines=all_cross_baselines(ants), polarized=pol,
+        precision=2, eps=6e-8,
+    )

@@ -48,6 +48,24 @@ int fv_nudft3_direct(int device, int precision, int dim, int64_t M, const void *
                      const void *z, const void *c, int ntrans, int64_t N, const void *s,
                      const void *t, const void *u, void *out);
 
+/* ---- stand-alone pieces of the slice (the other stubbed GPU entry points) -----------------
+ * Host pointers; real/complex of `precision`.
+ *
+ * fv_beam_eval: GPUBeamEvaluator.evaluate_beam (src/fftvis/gpu/beams.py:18-66; CPU twin
+ * cpu/beams.py:12-89).  kind/diameter/table as in fv_sim_set_beam_*; out is (2,2,n) complex
+ * [ax][feed][src] when polarized, else (n) complex power.
+ * fv_apparent_coherency: GPUBeamEvaluator.get_apparent_flux_polarized (gpu/beams.py:68-88) and
+ * its CPU siblings (cpu/beams.py:129-246, cpu_simulate.py:183-187); variant 0..4:
+ *   0 (A^H A) I   1 A^H C A   2 Ai^H Aj I   3 Ai^H C Aj   4 sqrt(Bi Bj) I (1-D arrays).
+ *   beam_i/beam_j/out: (2,2,n) complex (variant 4: (n)); flux: (n) real or (2,2,n) complex.
+ * fv_inplace_rot: gpu.utils.inplace_rot (src/fftvis/gpu/utils.py:8-22): b (3,n) <- rot (3,3) b. */
+int fv_beam_eval(int device, int precision, int polarized, int kind, double diameter,
+                 int nfreq_tab, int nza, int naz, double za_max, const void *table, int freq_index,
+                 double freq, int64_t n, const void *az, const void *za, void *out);
+int fv_apparent_coherency(int device, int precision, int variant, int64_t n, const void *beam_i,
+                          const void *beam_j, const void *flux, void *out);
+int fv_inplace_rot(int device, int precision, const double *rot, void *b, int64_t n);
+
 /* ---- fused simulator (the hot loop) ---------------------------------------------------------
  * One handle = one GPU context: stream, rocFFT plan cache, device-resident catalog / baselines /
  * beams / scratch.  A handle is not thread-safe; different handles are independent.
@@ -76,6 +94,12 @@ int fv_sim_set_sources(fv_sim *h, int64_t nsrc, int nfreq, const void *eq, const
  * the device-side stand-in for matvis CoordinateRotation.rotate/select_chunk as used at
  * cpu_simulate.py:937-946 (above-horizon selection up > 0 happens on the device).            */
 int fv_sim_set_times(fv_sim *h, int ntimes, const double *rot_eq2enu);
+
+/* Alternative to fv_sim_set_times for callers that own an astrometry engine (matvis
+ * CoordinateRotationERFA/Astropy): per-time topocentric ENU unit vectors of EVERY catalog source,
+ * (ntimes, 3, nsrc) real of the handle's precision -- what coord_mgr.rotate(ti) produces at
+ * cpu_simulate.py:937 before the horizon cut.  Call after fv_sim_set_sources.                 */
+int fv_sim_set_topo(fv_sim *h, int ntimes, int64_t nsrc, const void *topo, int on_device);
 
 /* Frequencies (Hz), float64 (nfreq). (cpu_simulate.py:969-973) */
 int fv_sim_set_freqs(fv_sim *h, int nfreq, const double *freqs);
