@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- simulated visibilities/s of the fftvis hot path on MI355X.
+
+A "step" is one pass of the hot path (rotate -> beam -> coherency -> type-3 NUFFT for every
+(time, frequency) slice) over one BASELINE.json configuration with seeded synthetic inputs that
+are already resident in HBM when the timed region starts.  Default workload: configs[1]
+("C2": HERA-37, 1e4 sources, 64 freqs, 10 times, unpolarized Airy, fp64, eps = 6e-8).
+
+Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the path shards by
+independent (time, frequency) slices with no data-path collective, so every rank simulates its
+own block of `ntimes` consecutive integrations of one long observation (weak scaling); the only
+communication is the one-off RCCL broadcast of the source catalog from rank 0 before the timed
+region, plus the barriers / MAX-reduce of the timing contract.
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--workload", default=os.environ.get("FFTVIS_BENCH_WORKLOAD", "C2"),
+                   choices=["C1", "C2", "C3", "C4"])
+    p.add_argument("--nsrc", type=int, default=None)
+    p.add_argument("--nfreq", type=int, default=None)
+    p.add_argument("--ntimes", type=int, default=None)
+    p.add_argument("--eps", type=float, default=6e-8)
+    p.add_argument("--upsample", type=float, default=2.0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    return p.parse_args()
+
+
+def cpu_baseline(cfg, seconds: float):
+    """Time the CPU port of the reference's per-slice work (oracle/: numpy beam + coherency,
+    type-3 NUFFT port with scipy.fft on all host cores) on a bounded sample of slices."""
+    from oracle import cpu_nufft
+    from oracle import fftvis_oracle as orc
+    from tests.helpers import oracle_beam
+
+    freqs, times = cfg["freqs"], cfg["times"]
+    pol = cfg["polarized"]
+    nfeeds = 2 if pol else 1
+    ants = cfg["ants"]
+    key2idx = {a: i for i, a in enumerate(ants)}
+    antvecs = np.array([ants[a] for a in ants], dtype=float)
+    bls = np.array([antvecs[key2idx[b[1]]] - antvecs[key2idx[b[0]]] for b in cfg["baselines"]]).T
+    bls = bls / orc.speed_of_light
+    coh, pol_sky = orc.prepare_source_catalog(cfg["fluxes"], pol)
+    mgr = orc.SimpleCoordinateRotation(coh, times, cfg["telescope_loc"], cfg["ra"], cfg["dec"])
+    beam = oracle_beam(cfg["beam"], pol, freqs)
+    nslices, t_used = 0, 0.0
+    t_start = time.perf_counter()
+    for ti in range(len(times)):
+        mgr.rotate(ti)
+        topo, flux, n = mgr.select_chunk(0, ti)
+        az, za = orc.enu_to_az_za(topo[0], topo[1])
+        topo = 2 * np.pi * topo
+        for fi in np.linspace(0, len(freqs) - 1, min(len(freqs), 8)).astype(int):
+            bev = [orc.evaluate_beam(beam, az, za, pol, freqs[fi]).astype(complex)]
+            c = orc.compute_apparent_coherency(bev, 0, 0, flux, fi, pol, pol_sky, nfeeds)
+            uvw = bls * freqs[fi]
+            cpu_nufft.nufft_type3([topo[0], topo[1]], c, [uvw[0], uvw[1]], eps=cfg["eps"])
+            nslices += 1
+            t_used = time.perf_counter() - t_start
+            if t_used > seconds:
+                break
+        if t_used > seconds:
+            break
+    nbls = len(cfg["baselines"])
+    return {
+        "value": nbls * nslices / t_used,
+        "unit": "visibilities/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"{nslices} (time,freq) slices of the workload in {t_used:.1f} s; numpy "
+                  "spread/interp (1 thread) + scipy.fft on all cores -- CPU restatement, not finufft",
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    from fftvis_amd import _lib, synth
+    from fftvis_amd.core import utils
+    from fftvis_amd.core.coords import SiderealRotation, eq_unit_vectors
+    from fftvis_amd.gpu.gpu_simulate import SimHandle, prepare_array
+
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+
+    cfg = synth.make_config(a.workload, nsrc=a.nsrc, nfreq=a.nfreq, ntimes=a.ntimes)
+    cfg["eps"] = a.eps
+    freqs, pol = cfg["freqs"], cfg["polarized"]
+    ntimes, nfreq = len(cfg["times"]), len(freqs)
+    baselines = cfg["baselines"]
+    nbls = len(baselines)
+
+    # ---- catalog: built on rank 0, broadcast over RCCL/xGMI, handed over as device pointers --
+    nsrc = len(cfg["ra"])
+    if rank == 0:
+        coh, pol_sky = utils.prepare_source_catalog(cfg["fluxes"], pol)
+        eq = torch.from_numpy(eq_unit_vectors(cfg["ra"], cfg["dec"])).to(dev)
+        flux = torch.from_numpy(np.ascontiguousarray(coh)).to(dev)
+    else:
+        pol_sky = False
+        eq = torch.empty((3, nsrc), dtype=torch.float64, device=dev)
+        flux = torch.empty((nsrc, nfreq), dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.broadcast(eq, 0)
+        dist.broadcast(flux, 0)
+    torch.cuda.synchronize()
+
+    # ---- this rank's block of the observation: ntimes integrations after rank * span ----------
+    dt = cfg["times"][1] - cfg["times"][0] if ntimes > 1 else 0.0
+    my_times = cfg["times"] + rank * ntimes * dt
+    R, bls, coplanar = prepare_array(cfg["ants"], baselines, 1e-6, np.float64)
+    pairs, pidx, pflip = utils.prepare_beam_evaluation(list(cfg["ants"]), baselines, None)
+
+    h = SimHandle(local_rank, 2, a.eps, a.upsample, pol)
+    h.set_sources_device(nsrc, nfreq, eq.data_ptr(), flux.data_ptr(), pol_sky)
+    h.set_times(SiderealRotation(my_times, cfg["telescope_loc"]).matrices())
+    h.set_freqs(freqs)
+    h.set_array(R, bls, coplanar)
+    h.set_beams([cfg["beam"]], freqs)
+    h.set_beam_pairs(pairs, pidx, pflip)
+    out = torch.empty(h.out_shape(ntimes, nfreq), dtype=torch.complex128, device=dev)
+
+    def step():
+        h.run_device(0, ntimes, 0, nfreq, out.data_ptr())
+
+    for _ in range(a.warmup):
+        step()
+    h.sync()
+    h.reset_stats()
+    h.enable_timing(True)  # HIP events on the engine's own stream, around each kernel family
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    h.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    st, tm = h.stats(), h.timing()
+    finite = bool(torch.isfinite(torch.view_as_real(out)).all().item())
+    vis_per_step = nbls * nfreq * ntimes
+    value = vis_per_step * world * a.steps / elapsed
+
+    if rank == 0:
+        # ---- roofline of the spread kernel (the kernel BASELINE.json's metric names) ----------
+        launches = max(st["spread_launches"], 1.0)
+        R8 = 8.0
+        d = 2 if coplanar else 3
+        # algorithmic bytes:  M (d R + T 2R)  +  T G1 2R   summed over launches
+        spread_bytes = st["source_visits"] * 2 * R8 + (st["sources_above_horizon"] / max(ntimes * a.steps, 1)) \
+            * d * R8 * launches + st["spread_cells"] * 2 * R8
+        spread_s = tm["spread"] * 1e-3
+        ach = spread_bytes / spread_s / 1e9 if spread_s > 0 else 0.0
+        fft_bytes = 2 * st["fft_cells"] * 2 * R8  # one read + one write of the grid (lower bound)
+        interp_bytes = st["interp_items"] * 2 * R8 + st["fft_cells"] * 2 * R8 / 4  # read region ~ 1/sigma^2
+        kern = {
+            "spread_ms_per_launch": tm["spread"] / launches,
+            "fft_ms_per_launch": tm["fft"] / launches,
+            "interp_ms_per_launch": tm["interp"] / launches,
+            "strengths_ms_per_launch": tm["strengths"] / launches,
+            "prep_ms_total": tm["prep"],
+            "launches": launches,
+            "fft_GBps_min": fft_bytes / max(tm["fft"] * 1e-3, 1e-12) / 1e9,
+            "grid": [int(st["n2x"]), int(st["n2y"]), int(st["n2z"])],
+            "kernel_width": int(st["w"]),
+        }
+        res = {
+            "metric": "simulated visibilities/sec (baselines x freqs x times) at eps=6e-8",
+            "value": value,
+            "unit": "visibilities/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{a.workload}: {synth.CONFIGS[a.workload][0]}, {nsrc} sources, "
+                            f"{nfreq} freqs, {ntimes} times/GPU, {nbls} baselines, "
+                            f"{'polarized table beam' if pol else 'unpolarized Airy beam'}, "
+                            f"type-3 NUFFT eps={a.eps:g} upsampfac={a.upsample:g}",
+                "slices_per_step": nfreq * ntimes,
+                "finite_output": finite,
+            },
+            "roofline": {
+                "kernel": "k_spread2d",
+                "bound": "hbm",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": spread_bytes / launches,
+                "avg_launch_ms": tm["spread"] / launches,
+            },
+            "kernels": kern,
+        }
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
+        print(json.dumps(res))
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,8 +69,9 @@ class TabulatedBeam:
         return TabulatedBeam(p, self.freqs, self.za_max)
 
 
-def describe_beam(beam, polarized: bool, freqs: np.ndarray):
+def describe_beam(beam, polarized: bool, freqs):
     """-> ("airy", diameter) or ("table", table ndarray, za_max) ready for the C ABI.
+    ``freqs`` = the simulated frequencies (None: take the table's frequency axis as it is).
 
     Accepts this package's beams and duck-types pyuvdata's: a ``BeamInterface`` is unwrapped
     (``.beam``); an object with ``.diameter`` whose class name contains "Airy" is an Airy dish;
@@ -87,7 +88,7 @@ def describe_beam(beam, polarized: bool, freqs: np.ndarray):
         if polarized and not tb.is_efield:
             raise ValueError("polarized simulation needs an E-field beam table")
         data = tb.data
-        if data.shape[0] not in (1, len(freqs)):
+        if freqs is not None and data.shape[0] not in (1, len(freqs)):
             raise ValueError("beam table frequency axis must have length 1 or nfreqs")
         dt = np.complex128 if polarized else np.float64
         return ("table", np.ascontiguousarray(data, dtype=dt), tb.za_max)
@@ -103,7 +104,7 @@ def describe_beam(beam, polarized: bool, freqs: np.ndarray):
             raise ValueError("UVBeam-like azimuth axis must tile [0, 2 pi) periodically")
         tab = np.transpose(d, (2, 0, 1, 3, 4))
         bf = np.asarray(getattr(inner, "freq_array", freqs), dtype=float).ravel()
-        if tab.shape[0] > 1 and not (tab.shape[0] == len(freqs) and np.allclose(bf, freqs)):
+        if freqs is not None and tab.shape[0] > 1 and not (tab.shape[0] == len(freqs) and np.allclose(bf, freqs)):
             # linear interpolation in frequency, done once on the host (wrapper.py:264-269)
             idx = np.clip(np.searchsorted(bf, freqs) - 1, 0, bf.size - 2)
             wt = ((np.asarray(freqs) - bf[idx]) / (bf[idx + 1] - bf[idx]))[:, None, None, None, None]

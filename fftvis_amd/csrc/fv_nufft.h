@@ -144,40 +144,6 @@ __global__ void k_bin_scatter(int64_t M, int dim, const int *__restrict__ i0u,
     perm[pos] = (int)j;
 }
 
-// Make the order inside each bin deterministic (ascending original index): LDS-free insertion
-// sort per bin by one thread -- bins hold tens of sources; removes run-to-run reordering of the
-// floating-point accumulation order that the atomic cursor would otherwise introduce.
-template <typename T>
-__global__ void k_bin_order(int ntiles, int64_t M, int dim, const int *__restrict__ bin_start,
-                            int *__restrict__ i0s, T *__restrict__ fs, int *__restrict__ perm) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles) return;
-    int b = bin_start[t], e = bin_start[t + 1];
-    for (int i = b + 1; i < e; ++i) {
-        int key = perm[i];
-        int ci[3];
-        T cf[3];
-        for (int d = 0; d < dim; ++d) {
-            ci[d] = i0s[(int64_t)d * M + i];
-            cf[d] = fs[(int64_t)d * M + i];
-        }
-        int k = i - 1;
-        while (k >= b && perm[k] > key) {
-            perm[k + 1] = perm[k];
-            for (int d = 0; d < dim; ++d) {
-                i0s[(int64_t)d * M + k + 1] = i0s[(int64_t)d * M + k];
-                fs[(int64_t)d * M + k + 1] = fs[(int64_t)d * M + k];
-            }
-            --k;
-        }
-        perm[k + 1] = key;
-        for (int d = 0; d < dim; ++d) {
-            i0s[(int64_t)d * M + k + 1] = ci[d];
-            fs[(int64_t)d * M + k + 1] = cf[d];
-        }
-    }
-}
-
 // Deconvolution table for one dimension of the fine grid, centring sign folded in:
 //   tab[i] = (-1)^i / psi_hat(2 pi (i - n2/2) / n2)   for |i - n2/2| <= n1/2, else 0.
 template <typename T>
@@ -530,8 +496,6 @@ class Nufft3 {
             hipLaunchKernelGGL(k_bin_scatter<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, dim,
                                i0u.as<int>(), fu.as<T>(), tile_of.as<int>(), bin_start.as<int>(),
                                cursor.as<int>(), i0s.as<int>(), fs.as<T>(), perm.as<int>());
-            hipLaunchKernelGGL(k_bin_order<T>, dim3(cdiv(nt, 64)), dim3(64), 0, stream, nt, M, dim,
-                               bin_start.as<int>(), i0s.as<int>(), fs.as<T>(), perm.as<int>());
         }
     }
 

@@ -619,12 +619,19 @@ class Sim : public SimBase {
         }
     }
 
-    // Split [f0, f1) into groups of consecutive channels sharing one fine-grid geometry.
-    std::vector<std::pair<int, int>> freq_groups(int f0, int f1, double cells_per_trans_at) const {
+    // Split [f0, f1) into groups of consecutive channels sharing one fine-grid geometry (sized
+    // for the group's top frequency).  Small grids are launch-bound, so they tolerate a wide
+    // frequency ratio (more wasted cells, far fewer launches); large grids are HBM-bound and get
+    // a narrow one.  cells_top = fine-grid cells per transform at the highest frequency.
+    std::vector<std::pair<int, int>> freq_groups(int f0, int f1, double cells_top) const {
         const char *er = std::getenv("FFTVIS_HIP_GROUP_RATIO");
         const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
-        const double ratio = er ? std::atof(er) : 0.90;
-        const double budget = eb ? std::atof(eb) : 6.0 * 1024 * 1024 * 1024;
+        const double budget = eb ? std::atof(eb) : 8.0 * 1024 * 1024 * 1024;
+        double fmax = 1.0;
+        for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
+        const double mb = cells_top * sizeof(cplx<T>) / (1024.0 * 1024.0);
+        double ratio = 0.5 + 0.4 * std::min(1.0, std::max(0.0, std::log2(mb / 16.0) / 4.0));
+        if (er) ratio = std::atof(er);
         std::vector<std::pair<int, int>> g;
         int a = f0;
         while (a < f1) {
@@ -633,9 +640,8 @@ class Sim : public SimBase {
             while (b < f1) {
                 const double nlo = std::min(lo, std::fabs(freqs[b])), nhi = std::max(hi, std::fabs(freqs[b]));
                 if (nlo < ratio * nhi) break;
-                // grid bytes grow ~ nhi^2 * count
-                const double scale = (nhi / std::max(1.0, std::fabs(freqs[f1 - 1]))) ;
-                const double bytes = cells_per_trans_at * scale * scale * (b + 1 - a) * tpol * sizeof(cplx<T>);
+                const double sc = nhi / fmax;
+                const double bytes = cells_top * sc * sc * (b + 1 - a) * tpol * sizeof(cplx<T>);
                 if (bytes > budget) break;
                 lo = nlo;
                 hi = nhi;

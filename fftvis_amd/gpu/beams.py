@@ -53,7 +53,7 @@ class GPUBeamEvaluator(BeamEvaluator):
         az = np.ascontiguousarray(az, dtype=rdt)
         za = np.ascontiguousarray(za, dtype=rdt)
         n = az.size
-        desc = describe_beam(beam, polarized, np.atleast_1d(np.asarray(freq, dtype=float)))
+        desc = describe_beam(beam, polarized, None)
         out = np.empty((2, 2, n) if polarized else (n,), dtype=cdt)
         L = _lib.lib()
         _lib.require_gpu()

@@ -1,0 +1,331 @@
+"""GPU parity tests: every call goes through the C ABI of libfftvis_hip.so and is compared with
+the CPU oracle on the same seeded inputs.  Tolerances: the NUFFT is specified to relative l2
+error ~eps (finufft's contract, reference docs + tests/test_cpu_simulate.py:152,195); we require
+<= 5*eps (or the fp64/fp32 rounding floor of the phases, whichever is larger)."""
+
+import os
+
+import numpy as np
+import pytest
+
+import fftvis_amd
+from fftvis_amd import synth
+from fftvis_amd.gpu import GPUBeamEvaluator, gpu_nufft2d
+from fftvis_amd.gpu.nufft import gpu_nudft_direct
+from fftvis_amd.gpu.utils import inplace_rot
+from oracle import fftvis_oracle as orc
+from oracle import nudft
+from tests.helpers import oracle_beam, oracle_simulate, rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _problem(M, N, S, ntrans, seed=1, one_sided=True):
+    rng = np.random.default_rng(seed)
+    x, y = rng.uniform(-2 * np.pi, 2 * np.pi, (2, M))
+    c = rng.normal(size=(ntrans, M)) + 1j * rng.normal(size=(ntrans, M))
+    s, t = rng.uniform(-S, S, (2, N))
+    if one_sided:
+        t = np.abs(t)
+    return x, y, c, s, t
+
+
+# ---------------------------------------------------------------------------------------------
+# type-3 NUFFT op
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("eps", [1e-2, 1e-4, 6e-8, 1e-10, 1e-13])
+def test_nufft2d_meets_eps_fp64(gpu, eps):
+    x, y, c, s, t = _problem(4000, 700, 80.0, 4)
+    ex = nudft.nudft_type3([x, y], c, [s, t])
+    got = gpu_nufft2d(x, y, c, s, t, eps)
+    assert got.dtype == np.complex128 and got.shape == (4, 700)
+    assert rel_l2(got, ex) < max(5 * eps, 2e-12)
+
+
+@pytest.mark.parametrize("eps", [1e-3, 6e-8])
+def test_nufft2d_upsample_1p25(gpu, eps):
+    x, y, c, s, t = _problem(3000, 500, 60.0, 2)
+    ex = nudft.nudft_type3([x, y], c, [s, t])
+    assert rel_l2(gpu_nufft2d(x, y, c, s, t, eps, upsample_factor=1.25), ex) < 10 * eps
+
+
+def test_nufft2d_fp32(gpu):
+    x, y, c, s, t = _problem(3000, 500, 60.0, 3)
+    ex = nudft.nudft_type3([x, y], c, [s, t])
+    got = gpu_nufft2d(x.astype(np.float32), y.astype(np.float32), c.astype(np.complex64),
+                      s.astype(np.float32), t.astype(np.float32), 1e-4)
+    assert got.dtype == np.complex64  # reference tests/test_wrapper.py:320-321
+    assert rel_l2(got, ex) < 1e-3
+
+
+def test_nufft2d_shapes_and_edge_cases(gpu):
+    x, y, c, s, t = _problem(500, 60, 20.0, 1)
+    ex = nudft.nudft_type3([x, y], c[0], [s, t])
+    got = gpu_nufft2d(x, y, c[0], s, t, 1e-9)  # 1-D weights -> 1-D result, like finufft
+    assert got.shape == (60,) and rel_l2(got, ex) < 1e-8
+    # many transforms (more than the 16-entry offset table, odd count for the LDS chunking)
+    x, y, c, s, t = _problem(300, 40, 15.0, 19, seed=3)
+    assert rel_l2(gpu_nufft2d(x, y, c, s, t, 1e-9), nudft.nudft_type3([x, y], c, [s, t])) < 1e-8
+    # single source, single target, coincident points, zero extent
+    one = gpu_nufft2d(np.array([0.3]), np.array([-0.2]), np.array([[2.0 + 1j]]), np.array([5.0]),
+                      np.array([7.0]), 1e-10)
+    np.testing.assert_allclose(one, (2 + 1j) * np.exp(1j * (0.3 * 5 - 0.2 * 7)), rtol=1e-9)
+    xs = np.full(50, 1.25)
+    ys = np.full(50, -0.5)
+    cc = np.ones((1, 50), complex)
+    ss = np.full(30, 3.0)
+    tt = np.full(30, 4.0)
+    np.testing.assert_allclose(gpu_nufft2d(xs, ys, cc, ss, tt, 1e-10),
+                               nudft.nudft_type3([xs, ys], cc, [ss, tt]), rtol=1e-8)
+    # empty sources -> zeros; empty targets -> empty
+    z = gpu_nufft2d(np.zeros(0), np.zeros(0), np.zeros((2, 0), complex), s, t, 1e-6)
+    assert z.shape == (2, 40) and not z.any()
+    assert gpu_nufft2d(x, y, c, np.zeros(0), np.zeros(0), 1e-6).shape == (19, 0)
+    with pytest.raises(ValueError):
+        gpu_nufft2d(x, y[:-1], c, s, t, 1e-6)
+    # off-centre boxes exercise pre-/post-phases
+    xo, yo = x + 11.0, y - 7.0
+    so, to = s + 300.0, t - 120.0
+    assert rel_l2(gpu_nufft2d(xo, yo, c, so, to, 1e-9), nudft.nudft_type3([xo, yo], c, [so, to])) < 2e-8
+
+
+def test_nufft2d_linearity_and_brute_force_at_scale(gpu):
+    """Size-independent properties at a HERA-350-sized grid: linearity in the strengths and
+    agreement with the independent brute-force GPU sum on a random target subset."""
+    rng = np.random.default_rng(7)
+    M, N, S = 100_000, 20_000, 195.0
+    r = np.sqrt(rng.uniform(0, 1, M))
+    ph = rng.uniform(0, 2 * np.pi, M)
+    x, y = 2 * np.pi * r * np.cos(ph), 2 * np.pi * r * np.sin(ph)
+    s, t = rng.uniform(-S, S, (2, N))
+    c1 = rng.normal(size=(1, M)) + 1j * rng.normal(size=(1, M))
+    c2 = rng.normal(size=(1, M)) + 1j * rng.normal(size=(1, M))
+    eps = 6e-8
+    f1, f2 = gpu_nufft2d(x, y, c1, s, t, eps), gpu_nufft2d(x, y, c2, s, t, eps)
+    f12 = gpu_nufft2d(x, y, 2.0 * c1 - 3j * c2, s, t, eps)
+    assert rel_l2(f12, 2.0 * f1 - 3j * f2) < 1e-12  # the pipeline is linear to rounding
+    sub = rng.choice(N, 256, replace=False)
+    bf = gpu_nudft_direct([x, y], c1, [s[sub], t[sub]])
+    assert rel_l2(f1[:, sub], bf) < 5 * eps
+    # and the brute-force kernel itself agrees with the CPU oracle on a smaller subset
+    sub2 = sub[:32]
+    assert rel_l2(gpu_nudft_direct([x, y], c1, [s[sub2], t[sub2]]),
+                  nudft.nudft_type3([x, y], c1, [s[sub2], t[sub2]])) < 1e-11
+
+
+# ---------------------------------------------------------------------------------------------
+# beam evaluation, coherency, rotation ops
+# ---------------------------------------------------------------------------------------------
+def test_inplace_rot(gpu):
+    """reference tests/test_core_utils.py:138-170 (90-degree case) + random."""
+    b = np.eye(3)
+    rot = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    inplace_rot(rot, b)
+    np.testing.assert_allclose(b, rot)
+    rng = np.random.default_rng(0)
+    b = rng.normal(size=(3, 1000))
+    R = orc.get_plane_to_xy_rotation_matrix(rng.normal(size=(9, 3)) * [30, 30, 1])
+    exp = R @ b
+    inplace_rot(R, b)
+    np.testing.assert_allclose(b, exp, rtol=1e-13, atol=1e-14)
+    b32 = rng.normal(size=(3, 10)).astype(np.float32)
+    exp = R @ b32
+    inplace_rot(R, b32)
+    np.testing.assert_allclose(b32, exp, rtol=1e-5, atol=1e-6)
+
+
+def _golden_cases():
+    z = np.load(os.path.join(GOLD, "coherency_cases.npz"))
+    return z, sorted({k.split("__")[0] for k in z.files})
+
+
+@pytest.mark.parametrize("name", _golden_cases()[1])
+def test_coherency_kernels_golden(gpu, name):
+    """The reference's einsum known-answers (tests/test_cpu_beams.py) through the GPU op."""
+    z, _ = _golden_cases()
+    ev = GPUBeamEvaluator()
+    v = int(z[name + "__variant"])
+    bi, bj, fl = z[name + "__beam_i"].copy(), z[name + "__beam_j"].copy(), z[name + "__flux"]
+    if v == 0:
+        got = ev.get_apparent_flux_polarized_beam(bi, fl)
+    elif v == 1:
+        got = ev.get_apparent_flux_polarized(bi, fl)
+    elif v == 2:
+        got = ev.get_apparent_flux_polarized_beam_pair(bi, bj, fl, np.zeros_like(bi))
+    else:
+        got = ev.get_apparent_flux_polarized_pair(bi, bj, fl, np.zeros_like(bi))
+    np.testing.assert_allclose(got, z[name + "__expected"], rtol=1e-12, atol=1e-13)
+
+
+def test_coherency_edge_cases(gpu):
+    ev = GPUBeamEvaluator()
+    b = np.zeros((2, 2, 0), dtype=complex)
+    assert ev.get_apparent_flux_polarized_beam(b, np.zeros(0)).shape == (2, 2, 0)  # :337-347
+    rng = np.random.default_rng(1)
+    bi = rng.uniform(0, 1, 50) + 0j
+    bj = rng.uniform(0, 1, 50) + 0j
+    fl = rng.uniform(0, 2, 50)
+    np.testing.assert_allclose(ev.get_apparent_flux_unpolarized(bi, bj, fl),
+                               np.sqrt(bi * bj) * fl, rtol=1e-13)
+    zc = rng.normal(size=20) + 1j * rng.normal(size=20)  # principal branch for complex input
+    np.testing.assert_allclose(ev.get_apparent_flux_unpolarized(zc, zc.conj() * 1j, np.ones(20)),
+                               np.sqrt(zc * zc.conj() * 1j), rtol=1e-12, atol=1e-14)
+
+
+def test_evaluate_beam(gpu):
+    rng = np.random.default_rng(2)
+    az = rng.uniform(0, 2 * np.pi, 3000)
+    za = rng.uniform(0, np.pi / 2, 3000)
+    az[:3] = [0.0, 2 * np.pi - 1e-12, np.pi]
+    za[:3] = [0.0, np.pi / 2, 1e-9]
+    ev = GPUBeamEvaluator()
+    freqs = np.linspace(100e6, 200e6, 4)
+    airy = fftvis_amd.AiryBeam(14.0)
+    for pol in (False, True):
+        got = ev.evaluate_beam(airy, az, za, pol, 150e6)
+        exp = orc.evaluate_beam(oracle_beam(airy, pol, freqs), az, za, pol, 150e6)
+        assert got.shape == ((2, 2, 3000) if pol else (3000,))  # cpu/beams.py:76-81
+        np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-14)
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs), freqs)
+    for pol in (False, True):
+        for fi in (0, 3):
+            got = ev.evaluate_beam(tab, az, za, pol, freqs[fi], freq_index=fi)
+            exp = orc.evaluate_beam(oracle_beam(tab, pol, freqs), az, za, pol, freqs[fi])
+            np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-14)
+    with pytest.raises(NotImplementedError):
+        ev.evaluate_beam(tab, az, za, True, freqs[0], spline_opts={"order": 3})
+
+
+# ---------------------------------------------------------------------------------------------
+# full simulator
+# ---------------------------------------------------------------------------------------------
+TOL = 5 * 6e-8
+
+
+def test_sim_c1_against_committed_fixture(gpu):
+    """BASELINE.json configs[0] in full, against the committed oracle output."""
+    z = np.load(os.path.join(GOLD, "sim_c1.npz"))
+    ants = {i: p for i, p in enumerate(z["antpos"])}
+    kw = dict(ants=ants, fluxes=z["fluxes"], ra=z["ra"], dec=z["dec"], freqs=z["freqs"],
+              times=z["times"], beam=fftvis_amd.AiryBeam(float(z["airy_diameter"])),
+              telescope_loc=tuple(z["telescope_loc"]), baselines=[tuple(b) for b in z["baselines"]],
+              precision=2, eps=6e-8)
+    v = fftvis_amd.simulate_vis(**kw, polarized=False)
+    assert v.shape == (8, 2, 21) and v.dtype == np.complex128
+    assert rel_l2(v, z["vis_unpolarized"]) < TOL
+    vp = fftvis_amd.simulate_vis(**kw, polarized=True)
+    assert vp.shape == (8, 2, 2, 2, 21)
+    assert rel_l2(vp, z["vis_polarized"]) < TOL
+    # tighter eps tightens the agreement; fp64 default eps of the reference
+    v13 = fftvis_amd.simulate_vis(**dict(kw, eps=None), polarized=False)
+    assert rel_l2(v13, z["vis_unpolarized"]) < 1e-11
+
+
+def _variants():
+    c1 = synth.make_config("C1")
+    freqs = c1["freqs"]
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs), freqs)
+    tab2 = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, diameter=12.0), freqs)
+    _, _, fl4 = synth.catalog(100, freqs, 0, polarized_sky=True)
+    bidx = np.array([0, 1, 0, 1, 1, 0, 1])
+    bls = c1["baselines"] + [(3, 0), (6, 1), (2, 2)]  # flipped pairs and an auto
+    tilted = {k: np.array([v[0], v[1], 0.01 * v[0] - 0.02 * v[1]]) for k, v in c1["ants"].items()}
+    return {
+        "pol_table": dict(c1, polarized=True, beam=tab),
+        "unpol_table": dict(c1, beam=tab),
+        "pol_table_pol_sky": dict(c1, polarized=True, beam=tab, fluxes=fl4),
+        "two_beams_pol": dict(c1, polarized=True, beam=[tab, tab2], beam_idx=bidx, baselines=bls),
+        "two_beams_pol_sky": dict(c1, polarized=True, beam=[tab, tab2], beam_idx=bidx, baselines=bls, fluxes=fl4),
+        "two_airy_unpol": dict(c1, beam=[fftvis_amd.AiryBeam(14.0), fftvis_amd.AiryBeam(10.0)],
+                               beam_idx=bidx, baselines=bls),
+        "tilted_array": dict(c1, ants=tilted),
+        "default_baselines": dict(c1, baselines=None),
+        "upsample_1p25": dict(c1, upsample_factor=1.25),
+    }
+
+
+@pytest.mark.parametrize("name", list(_variants()))
+def test_sim_variants_match_oracle(gpu, name):
+    cfg = _variants()[name]
+    got = fftvis_amd.simulate_vis(**cfg)
+    exp = oracle_simulate(cfg)
+    assert got.shape == exp.shape
+    assert rel_l2(got, exp) < (4 * TOL if name == "upsample_1p25" else TOL)
+
+
+def test_sim_fp32(gpu):
+    cfg = dict(synth.make_config("C1"), precision=1, eps=1e-4)
+    got = fftvis_amd.simulate_vis(**cfg)
+    assert got.dtype == np.complex64
+    assert rel_l2(got, oracle_simulate(cfg)) < 2e-3  # tests/test_cpu_simulate.py:195 uses atol 1e-4
+
+
+def test_sim_blocks_and_chunk_layout(gpu):
+    """(time, freq) blocks assemble to the whole run (how ranks shard the job, reference
+    cpu_simulate.py:843-847) and _evaluate_vis_chunk returns the scratch layout (:909-911)."""
+    cfg = synth.make_config("C2", nsrc=1500, nfreq=12, ntimes=4)
+    cfg["polarized"] = True
+    kw = {k: cfg[k] for k in ("ants", "freqs", "fluxes", "ra", "dec", "times", "telescope_loc",
+                              "baselines", "polarized", "eps")}
+    kw["beam_list"] = [cfg["beam"]]
+    eng = fftvis_amd.create_simulation_engine("gpu")
+    full = eng.simulate(**kw)
+    assert full.shape == (12, 4, 2, 2, 666)
+    blk = eng.simulate(**kw, time_idx=slice(1, 3), freq_idx=slice(4, 9))
+    np.testing.assert_allclose(blk, full[4:9, 1:3], rtol=0, atol=1e-7 * np.abs(full).max())
+    chunk = eng._evaluate_vis_chunk(slice(1, 3), slice(4, 9), **kw)
+    assert chunk.shape == (2, 666, 2, 2, 5)
+    # LDS float atomics make runs agree to rounding, not bitwise
+    np.testing.assert_allclose(np.transpose(chunk, (4, 0, 2, 3, 1)), blk, rtol=0,
+                               atol=1e-13 * np.abs(full).max())
+    exp = oracle_simulate(dict(cfg, beam=cfg["beam"]))
+    assert rel_l2(full, exp) < TOL
+
+
+def test_sim_c2_size_properties(gpu):
+    """configs[1] geometry (HERA-37, 666 baselines, 64 channels) with a reduced catalog:
+    oracle parity on a subset of baselines + linearity in the flux."""
+    cfg = synth.make_config("C2", nsrc=3000, ntimes=2)
+    v = fftvis_amd.simulate_vis(**cfg)
+    assert v.shape == (64, 2, 666)
+    rng = np.random.default_rng(0)
+    sub = sorted(rng.choice(666, 40, replace=False))
+    sub_cfg = dict(cfg, baselines=[cfg["baselines"][i] for i in sub])
+    assert rel_l2(v[..., sub], oracle_simulate(sub_cfg)) < TOL
+    _, _, fl2 = synth.catalog(3000, cfg["freqs"], 5)
+    v2 = fftvis_amd.simulate_vis(**dict(cfg, fluxes=fl2))
+    v12 = fftvis_amd.simulate_vis(**dict(cfg, fluxes=2.0 * cfg["fluxes"] + 0.5 * fl2))
+    assert rel_l2(v12, 2.0 * v + 0.5 * v2) < 1e-11
+
+
+def test_sim_precomputed_topo_equals_rotation(gpu):
+    """Handing the engine per-time topocentric vectors (the matvis coord_mgr route) gives the
+    same answer as the on-device rotation."""
+    cfg = synth.make_config("C1")
+
+    class Mgr:  # the slice of matvis' CoordinateRotation the engine consumes
+        def __init__(self):
+            self.o = orc.SimpleCoordinateRotation(None, cfg["times"], cfg["telescope_loc"], cfg["ra"], cfg["dec"])
+
+        def setup(self):
+            pass
+
+        def rotate(self, ti):
+            self.o.rotate(ti)
+            self.all_coords_topo = self.o._topo
+
+    a = fftvis_amd.simulate_vis(**cfg)
+    b = fftvis_amd.simulate_vis(**cfg, coord_mgr=Mgr())
+    assert rel_l2(b, a) < 1e-12
+
+
+def test_sim_empty_sky_and_errors(gpu):
+    cfg = synth.make_config("C1", nsrc=20)
+    below = dict(cfg, dec=np.full(20, np.pi / 2 - 1e-3))  # never rises at latitude -30.7
+    v = fftvis_amd.simulate_vis(**below)
+    assert v.shape == (8, 2, 21) and not v.any()  # cpu_simulate.py:945-946
+    with pytest.raises(ValueError, match="requires sky_model to be 2D"):
+        fftvis_amd.simulate_vis(**dict(cfg, fluxes=np.ones((20, 8, 4))))
+    with pytest.raises(NotImplementedError):
+        fftvis_amd.simulate_vis(**dict(cfg, beam_spline_opts={"order": 3}))

@@ -1,0 +1,149 @@
+"""CPU-only tests of the product's host logic and of the C-ABI library's surface."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fftvis_amd
+from fftvis_amd import _lib, synth
+from fftvis_amd.core import coords, utils
+from fftvis_amd.core.beams import TabulatedBeam, describe_beam
+from oracle import fftvis_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """Every function include/fftvis_hip.h declares must be exported (no compute calls here)."""
+    hdr = open(os.path.join(ROOT, "include", "fftvis_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(fv_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 25
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SYMBOLS), "ctypes table out of sync with the header"
+    assert _lib.lib().fv_version() >= 100
+
+
+def test_library_reports_errors_not_crashes():
+    L = _lib.lib()
+    assert L.fv_nufft3(0, 7, 2, 0, None, None, None, None, 1, 0, None, None, None, 1e-6, 2.0, None) == 1
+    assert b"precision" in L.fv_last_error()
+    h = ctypes.c_void_p()
+    assert L.fv_sim_create(ctypes.byref(h), 0, 2, 1e-6, 3.0, 0) == 1  # bad upsample factor
+    assert b"upsample" in L.fv_last_error()
+    assert L.fv_sim_sync(None) == 1
+
+
+def test_host_helpers_match_oracle():
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        ants = {i: np.r_[rng.integers(-3, 4, 2) * 14.6, 0.0] for i in range(8)}
+        assert utils.get_pos_reds(ants) == orc.get_pos_reds(ants)
+        assert utils.get_pos_reds(ants, include_autos=False) == orc.get_pos_reds(ants, include_autos=False)
+    for args in [(3, 30, 1), (10, 5, 1), (8, 128, 20), (8, 256, 60), (2, 8, 2), (6, 20, 30), (5, 7, 11)]:
+        assert utils.get_task_chunks(*args) == orc.get_task_chunks(*args)
+    av = rng.normal(size=(12, 3)) * [100, 100, 1]
+    np.testing.assert_allclose(utils.get_plane_to_xy_rotation_matrix(av),
+                               orc.get_plane_to_xy_rotation_matrix(av), atol=1e-14)
+    sm = rng.normal(size=(5, 3, 4))
+    np.testing.assert_allclose(utils.prepare_source_catalog(sm, True)[0],
+                               orc.prepare_source_catalog(sm, True)[0])
+    a = utils.prepare_beam_evaluation([0, 1, 2, 3], [(0, 1), (1, 0), (2, 3), (3, 1), (0, 0)], [0, 2, 2, 1])
+    b = orc.prepare_beam_evaluation([0, 1, 2, 3], [(0, 1), (1, 0), (2, 3), (3, 1), (0, 0)], [0, 2, 2, 1])
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+
+
+def test_task_chunks_reference_values():
+    """reference tests/test_core_utils.py:26-45."""
+    n, fc, tc, nf, nt = utils.get_task_chunks(3, 30, 1)
+    assert (n, nf, nt) == (3, 10, 1)
+    assert utils.get_task_chunks(10, 5, 1)[0] == 1
+    # every (t, f) cell is covered exactly once for the multi-GPU shard shapes we use
+    for nproc, nfreq, ntime in [(8, 256, 60), (8, 128, 20), (4, 64, 10), (2, 64, 10)]:
+        n, fc, tc, _, _ = utils.get_task_chunks(nproc, nfreq, ntime)
+        cover = np.zeros((ntime, nfreq), int)
+        for f, t in zip(fc, tc):
+            cover[t, f] += 1
+        assert (cover == 1).all()
+
+
+def test_validate_beam_idx_errors():
+    """error texts of reference core/utils.py:358-429."""
+    with pytest.raises(ValueError, match="beam_idx must be provided"):
+        utils.validate_beam_idx(None, None, 2, 5)
+    with pytest.raises(ValueError, match="length nant"):
+        utils.validate_beam_idx(np.array([0, 1]), None, 2, 5)
+    with pytest.raises(ValueError, match="greater than the number of beams"):
+        utils.validate_beam_idx(np.array([0, 1, 2]), None, 2, 3)
+    with pytest.raises(ValueError, match="should not be provided when beam_coefs"):
+        utils.validate_beam_idx(np.array([0]), np.ones((1, 1, 1)), 1, 1)
+    assert utils.validate_beam_idx(None, None, 1, 4) is None
+    np.testing.assert_array_equal(utils.validate_beam_idx(None, None, 3, 3), np.arange(3))
+
+
+def test_sidereal_rotation_matches_oracle_and_is_orthonormal():
+    times = np.linspace(2459845.0, 2459845.05, 4)
+    R = coords.SiderealRotation(times, (synth.HERA_LAT, synth.HERA_LON)).matrices()
+    for i, t in enumerate(times):
+        Ro = orc.eq_to_enu_matrix(orc.gmst_rad(t) + synth.HERA_LON, synth.HERA_LAT)
+        np.testing.assert_allclose(R[i], Ro, atol=1e-14)
+        np.testing.assert_allclose(R[i] @ R[i].T, np.eye(3), atol=1e-14)
+    # a source at the local zenith maps to 'up'
+    lst = coords.gmst_rad(times[0]) + synth.HERA_LON
+    z = coords.eq_unit_vectors(np.array([lst]), np.array([synth.HERA_LAT]))
+    np.testing.assert_allclose(R[0] @ z[:, 0], [0, 0, 1], atol=1e-12)
+
+
+def test_describe_beam_rules():
+    freqs = np.linspace(100e6, 120e6, 3)
+    assert describe_beam(fftvis_amd.AiryBeam(14.0), False, freqs) == ("airy", 14.0)
+    tab = TabulatedBeam(synth.synthetic_efield_table(freqs, nza=19, naz=36), freqs)
+    kind, data, za_max = describe_beam(tab, True, freqs)
+    assert kind == "table" and data.shape == (3, 2, 2, 19, 36) and data.dtype == np.complex128
+    kind, data, _ = describe_beam(tab, False, freqs)  # power of feed 0
+    assert data.shape == (3, 19, 36) and data.dtype == np.float64
+    np.testing.assert_allclose(data, (np.abs(tab.data[:, :, 0]) ** 2).sum(1))
+    with pytest.raises(ValueError, match="E-field"):
+        describe_beam(TabulatedBeam(data, freqs), True, freqs)
+    with pytest.raises(NotImplementedError):
+        describe_beam(object(), False, freqs)
+
+    class FakeUVBeam:  # pyuvdata future-array-shape layout
+        data_array = np.transpose(tab.data, (1, 2, 0, 3, 4))
+        axis1_array = 2 * np.pi * np.arange(36) / 36
+        axis2_array = np.linspace(0, np.pi, 19)
+        freq_array = freqs
+
+    kind, d2, zm = describe_beam(FakeUVBeam(), True, freqs)
+    np.testing.assert_allclose(d2, tab.data)
+    assert np.isclose(zm, np.pi)
+
+
+def test_engine_argument_errors_need_no_gpu():
+    cfg = synth.make_config("C1", nsrc=5, nfreq=2, ntimes=1)
+    with pytest.raises(ValueError, match="not compatible with unpolarized"):
+        fftvis_amd.simulate_vis(**cfg, beam_coefs=np.ones((7, 1, 2)))
+    with pytest.raises(ValueError, match="Unsupported backend"):
+        fftvis_amd.create_simulation_engine("tpu")
+    assert fftvis_amd.default_accuracy_dict == {1: 6e-8, 2: 1e-13}
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product refuses to compute (it never routes to the oracle)."""
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    cfg = synth.make_config("C1", nsrc=5, nfreq=2, ntimes=1)
+    with pytest.raises(_lib.FftvisHipError):
+        fftvis_amd.simulate_vis(**cfg)
+    with pytest.raises(_lib.FftvisHipError):
+        fftvis_amd.gpu.gpu_nufft2d(np.zeros(3), np.zeros(3), np.ones(3, complex), np.zeros(2), np.zeros(2), 1e-6)
+    src = ""
+    for dp, _, fs in os.walk(os.path.join(ROOT, "fftvis_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src += open(os.path.join(dp, f)).read()
+    assert "import oracle" not in src and "from oracle" not in src
