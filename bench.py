@@ -193,8 +193,8 @@ def main():
             * d * R8 * launches + st["spread_cells"] * 2 * R8
         spread_s = tm["spread"] * 1e-3
         ach = spread_bytes / spread_s / 1e9 if spread_s > 0 else 0.0
-        fft_bytes = 2 * st["fft_cells"] * 2 * R8  # one read + one write of the grid (lower bound)
-        interp_bytes = st["interp_items"] * 2 * R8 + st["fft_cells"] * 2 * R8 / 4  # read region ~ 1/sigma^2
+        fft_bytes = st["fft_cells"] * 2 * R8  # cells the three pruned-FFT kernels move through HBM
+        interp_bytes = st["interp_items"] * 2 * R8
         kern = {
             "spread_ms_per_launch": tm["spread"] / launches,
             "fft_ms_per_launch": tm["fft"] / launches,
@@ -203,7 +203,7 @@ def main():
             "prep_ms_total": tm["prep"],
             "launches": launches,
             "fft_GBps_min": fft_bytes / max(tm["fft"] * 1e-3, 1e-12) / 1e9,
-            "grid": [int(st["n2x"]), int(st["n2y"]), int(st["n2z"])],
+            "grid": {"n2": [int(st["n2x"]), int(st["n2y"])], "active": [int(st["n2z"]) // 65536, int(st["n2z"]) % 65536]},
             "kernel_width": int(st["w"]),
         }
         res = {

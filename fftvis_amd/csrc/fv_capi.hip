@@ -1,5 +1,5 @@
 // fv_capi.hip -- extern "C" entry points of libfftvis_hip.so (see include/fftvis_hip.h).
-// Single translation unit: hipcc --offload-arch=gfx950 -O3 -shared -fPIC ... -lrocfft
+// Single translation unit: hipcc --offload-arch=gfx950 -O3 -shared -fPIC ...
 
 #include "../../include/fftvis_hip.h"
 #include "fv_sim.h"
@@ -9,14 +9,6 @@
 namespace fv {
 
 static thread_local std::string g_last_error;
-
-void ensure_rocfft() {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        if (rocfft_setup() != rocfft_status_success)
-            throw Error(FV_ERR_ROCFFT, "rocfft_setup failed");
-    });
-}
 
 template <typename F>
 static int guarded(F &&f) {

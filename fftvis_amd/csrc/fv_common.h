@@ -4,7 +4,6 @@
 #include "../../include/fftvis_hip.h"
 
 #include <hip/hip_runtime.h>
-#include <rocfft/rocfft.h>
 
 #include <cmath>
 #include <cstdint>
@@ -28,14 +27,6 @@ struct Error : std::runtime_error {
         hipError_t _e = (expr);                                                                 \
         if (_e != hipSuccess)                                                                   \
             throw fv::Error(FV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-    } while (0)
-
-#define FV_ROCFFT(expr)                                                                        \
-    do {                                                                                       \
-        rocfft_status _s = (expr);                                                             \
-        if (_s != rocfft_status_success)                                                       \
-            throw fv::Error(FV_ERR_ROCFFT, std::string(#expr) + ": rocfft status " +       \
-                                                   std::to_string((int)_s));                   \
     } while (0)
 
 #define FV_REQUIRE(cond, msg)                                        \

@@ -1,4 +1,4 @@
-// fv_nufft.h -- type-3 NUFFT on MI355X: bin-sort -> LDS-tiled spread -> rocFFT -> gather.
+// fv_nufft.h -- type-3 NUFFT on MI355X: bin-sort -> LDS-tiled spread -> pruned FFT -> gather.
 //
 //   f[t][k] = sum_j c[j][t] exp(+i s_k . x_j)      (finufft type-3 convention, isign = +1;
 //                                                   reference call sites src/fftvis/cpu/nufft.py:48-59,105-118)
@@ -7,10 +7,15 @@
 //  * All ntrans strength vectors share the source points; in the simulator a "trans" is a
 //    (frequency, polarisation-product) pair, and each *frequency group* has its own target set
 //    scale[g] * (sign_k * b_k), so one spread + one batched FFT serves a whole block of frequencies.
-//  * Fine grid is stored CENTRED (cell index = mode + n2/2): sources occupy the middle n1 cells,
-//    targets read the middle n2/sigma cells, nothing ever wraps.  The (-1)^index factors this costs
-//    are folded into the deconvolution table (input side) and the gather weights (output side).
-//  * Spread is output-driven: one workgroup owns one 32x32 tile of the fine grid for TC transforms,
+//  * Only the part of the fine grid that can be non-zero is ever materialised.  Per dimension the
+//    sources touch `na` ~ n2/sigma cells around mode 0 (buffer A, mode m = index - na/2) and the
+//    targets read `no` ~ n2/sigma cells around mode 0 of the transform (mode l = index - no/2).
+//    The uniform step  g_l = sum_m b_m exp(+2 pi i m l / n2)  is therefore a PRUNED FFT: row
+//    kernels read na inputs, run length-Q power-of-two FFTs in LDS (n2 = P*Q, decimation in time
+//    over the P residues) and write no outputs; a tile transpose sits between the x- and y-pass.
+//    HBM traffic ~ 6 na^2 cells per transform instead of the >= 8 n2^2 = 32 na^2 of a full-grid
+//    library FFT (four passes) plus the zero padding the spread would have to write.
+//  * Spread is output-driven: one workgroup owns one 32x32 tile of A for TC transforms,
 //    accumulates all sources whose footprint touches it in LDS (ds_add_f64 / ds_add_f32), then
 //    writes every cell of the tile exactly once (zeros included, deconvolution applied) with 512-B
 //    row segments.  No global atomics, no separate memset pass.
@@ -18,31 +23,60 @@
 
 #include "fv_eskernel.h"
 
-#include <map>
-#include <tuple>
-
 namespace fv {
 
 constexpr int TILE = 32;       // fine-grid tile edge (cells) owned by one spread workgroup
 constexpr int GROUP = 16;      // lanes cooperating on one source / one target (>= MAX_W)
 constexpr int SPREAD_THREADS = 256;
 constexpr int INTERP_THREADS = 256;
+constexpr int FFT_THREADS = 256;
+constexpr int FFT_NOUT = 16;   // outputs accumulated in registers per thread of a row-FFT
+constexpr int FFT_QMAX_LOG = 12;  // LDS row buffer: Q <= 4096 complex (64 KiB fp64)
 
 struct DimGeom {
     double xc = 0, X = 0;    // source-coordinate centre / half-width
     double btc = 0, B = 0;   // base-target centre / half-width (before frequency scaling)
     double S = 0;            // scale_max * B
     double h = 1;            // x-space grid spacing: xi = (x - xc) / h
-    int n1 = 2, n2 = 2;      // active region / FFT length
+    int n1 = 2;              // cells the sources can touch
+    int na = 32;             // n1 rounded up to whole tiles: extent of buffer A
+    int n2 = 64, P = 1, Q = 64, logQ = 6;  // FFT length n2 = P * Q
+    int no = 2;              // transform outputs kept (centred on mode 0)
 };
 
 struct Geom {
     int dim = 2;
     DimGeom d[3];
     int ntile[3] = {1, 1, 1};
-    int64_t ncell() const { return (int64_t)d[0].n2 * d[1].n2 * (dim > 2 ? d[2].n2 : 1); }
     int ntiles() const { return ntile[0] * ntile[1] * ntile[2]; }
+    int64_t cells_a() const { return (int64_t)d[0].na * d[1].na * (dim > 2 ? d[2].na : 1); }
+    int64_t cells_o() const { return (int64_t)d[0].no * d[1].no * (dim > 2 ? d[2].no : 1); }
 };
+
+// Smallest n2 = P * 2^b >= nmin with 64 <= 2^b <= 4096 and P <= 16 (P unbounded at 2^b = 4096);
+// then as many factors of two as possible move from P into Q.
+inline void choose_pq(int nmin, DimGeom &g) {
+    int best = 0, bp = 0, bq = 0;
+    for (int b = 6; b <= FFT_QMAX_LOG; ++b) {
+        const int q = 1 << b;
+        const int p = (nmin + q - 1) / q;
+        if (p > 16 && b < FFT_QMAX_LOG) continue;
+        const int n = p * q;
+        if (best == 0 || n < best) {
+            best = n;
+            bp = p;
+            bq = b;
+        }
+    }
+    while (bp % 2 == 0 && bq < FFT_QMAX_LOG) {
+        bp /= 2;
+        ++bq;
+    }
+    g.n2 = best;
+    g.P = bp;
+    g.Q = 1 << bq;
+    g.logQ = bq;
+}
 
 inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
     g.S = std::fabs(scale_max) * g.B;
@@ -58,8 +92,12 @@ inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
     int n1 = (int)std::ceil(2.0 * sigma * Ss * Xs / M_PI + w + 1);
     n1 += n1 % 2;
     g.n1 = n1;
-    g.n2 = next235even((int)std::ceil(sigma * n1));
+    g.na = (int)cdiv(n1, TILE) * TILE;
+    choose_pq(std::max(g.na, (int)std::ceil(sigma * n1)), g);
     g.h = M_PI / (sigma * Ss);
+    // targets sit at |eta| <= n2/(2 sigma) (in transform cells); keep the footprint around them
+    g.no = 2 * ((int)std::ceil(0.5 * g.n2 / sigma) + w / 2 + 2);
+    g.no = std::min(g.no, g.n2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -68,13 +106,14 @@ inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
 
 struct BinArgs {
     double xc[3], invh[3];
-    int n2[3], ntile[3];
+    int na[3], ntile[3];
     int w, dim;
 };
 
-// Footprint start cell i0 = ceil(p - w/2) and first kernel argument f = i0 - p, per dimension,
-// plus the tile the footprint's middle cell falls in.  Positions are formed in fp64 and split into
-// (int cell, T offset) so that fp32 runs keep sub-cell accuracy on multi-thousand-cell grids.
+// Footprint start cell i0 = ceil(p - w/2) in buffer-A coordinates and first kernel argument
+// f = i0 - p, per dimension, plus the tile the footprint's middle cell falls in.  Positions are
+// formed in fp64 and split into (int cell, T offset) so that fp32 runs keep sub-cell accuracy on
+// multi-thousand-cell grids.
 template <typename T>
 __global__ void k_bin_count(int64_t M, const T *__restrict__ x, const T *__restrict__ y,
                             const T *__restrict__ z, BinArgs a, int *__restrict__ i0u,
@@ -86,11 +125,11 @@ __global__ void k_bin_count(int64_t M, const T *__restrict__ x, const T *__restr
     int tl[3] = {0, 0, 0};
     bool oob = false;
     for (int d = 0; d < a.dim; ++d) {
-        double p = ((double)src[d][j] - a.xc[d]) * a.invh[d] + 0.5 * a.n2[d];
+        double p = ((double)src[d][j] - a.xc[d]) * a.invh[d] + 0.5 * a.na[d];
         int i0 = (int)ceil(p - 0.5 * a.w);
-        if (i0 < 0 || i0 + a.w > a.n2[d] || !(p == p)) {  // outside the planned box: never write OOB
+        if (i0 < 0 || i0 + a.w > a.na[d] || !(p == p)) {  // outside the planned box: never write OOB
             oob = true;
-            i0 = max(0, min(a.n2[d] - a.w, i0));
+            i0 = max(0, min(a.na[d] - a.w, i0));
             if (!(p == p)) p = i0 + 0.5 * a.w;
         }
         i0u[(int64_t)d * M + j] = i0;
@@ -144,19 +183,24 @@ __global__ void k_bin_scatter(int64_t M, int dim, const int *__restrict__ i0u,
     perm[pos] = (int)j;
 }
 
-// Deconvolution table for one dimension of the fine grid, centring sign folded in:
-//   tab[i] = (-1)^i / psi_hat(2 pi (i - n2/2) / n2)   for |i - n2/2| <= n1/2, else 0.
+// Inner-kernel deconvolution table of one dimension in buffer-A coordinates:
+//   tab[i] = 1 / psi_hat(2 pi (i - na/2) / n2).
 template <typename T>
-__global__ void k_deconv_table(int n1, int n2, KerParams ker, T *__restrict__ tab) {
+__global__ void k_deconv_table(int na, int n2, KerParams ker, T *__restrict__ tab) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n2) return;
-    int m = i - n2 / 2;
-    double v = 0.0;
-    if (abs(m) <= n1 / 2) {
-        v = 1.0 / es_hat(ker, 2.0 * M_PI * (double)m / (double)n2);
-        if (i & 1) v = -v;
-    }
-    tab[i] = (T)v;
+    if (i >= na) return;
+    const int m = i - na / 2;
+    tab[i] = (T)(1.0 / es_hat(ker, 2.0 * M_PI * (double)m / (double)n2));
+}
+
+// tw[j] = exp(+2 pi i j / n2), j in [0, n2)  (inverse-sign FFT twiddles, formed in fp64)
+template <typename T>
+__global__ void k_twiddle_table(int n2, cplx<T> *__restrict__ tw) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n2) return;
+    double s, c;
+    sincospi(2.0 * (double)j / (double)n2, &s, &c);
+    tw[j] = {(T)c, (T)s};
 }
 
 // Gather user-order strengths (ntrans, M) into sorted order [M][ntrans] and apply the type-3
@@ -164,18 +208,18 @@ __global__ void k_deconv_table(int n1, int n2, KerParams ker, T *__restrict__ ta
 template <typename T>
 __global__ void k_load_strengths(int64_t M, int ntrans, int tpol, int dim,
                                  const cplx<T> *__restrict__ cin, const int *__restrict__ perm,
-                                 const int *__restrict__ i0s, const T *__restrict__ fs, int w,
-                                 double h0, double h1, double h2, int n20, int n21, int n22,
-                                 double btc0, double btc1, double btc2,
-                                 const double *__restrict__ scale, cplx<T> *__restrict__ cs) {
+                                 const int *__restrict__ i0s, const T *__restrict__ fs, double h0,
+                                 double h1, double h2, int na0, int na1, int na2, double btc0,
+                                 double btc1, double btc2, const double *__restrict__ scale,
+                                 cplx<T> *__restrict__ cs) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= M) return;
     const double h[3] = {h0, h1, h2}, btc[3] = {btc0, btc1, btc2};
-    const int n2[3] = {n20, n21, n22};
+    const int na[3] = {na0, na1, na2};
     double dot = 0.0;  // btc . x'
     for (int d = 0; d < dim; ++d) {
         double pos = (double)i0s[(int64_t)d * M + p] - (double)fs[(int64_t)d * M + p];
-        dot += btc[d] * (pos - 0.5 * n2[d]) * h[d];
+        dot += btc[d] * (pos - 0.5 * na[d]) * h[d];
     }
     int j = perm[p];
     for (int t = 0; t < ntrans; ++t) {
@@ -196,8 +240,8 @@ template <typename T, int TC>
 __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
     int64_t M, const int *__restrict__ i0s, const T *__restrict__ fs,
     const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans,
-    const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid, int n2x,
-    int n2y, int ntx, int nty, int w, T beta, T c4) {
+    const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid, int nax,
+    int nay, int ntx, int nty, int w, T beta, T c4) {
     __shared__ T acc[2 * TC * TILE * TILE];  // [re|im][q][row][col]
     const int tid = threadIdx.x;
     const int bx = blockIdx.x, by = blockIdx.y;
@@ -254,30 +298,131 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
     // write-out: every cell of the tile once, deconvolved; a wave covers 2 rows x 512 B.
     const int col = tid & (TILE - 1);
     const int gx = x0 + col;
-    if (gx < n2x) {
-        const T dxv = decx[gx];
-        for (int q = 0; q < TC; ++q) {
-            if (t0 + q >= ntrans) break;
-            const T *are = acc + q * TILE * TILE;
-            const T *aim = acc + (TC + q) * TILE * TILE;
-            cplx<T> *plane = grid + (int64_t)(t0 + q) * n2y * n2x;
-            for (int row = tid / TILE; row < TILE; row += SPREAD_THREADS / TILE) {
-                const int gy = y0 + row;
-                if (gy >= n2y) break;
-                const T f = dxv * decy[gy];
-                plane[(int64_t)gy * n2x + gx] = {are[row * TILE + col] * f, aim[row * TILE + col] * f};
-            }
+    const T dxv = decx[gx];
+    for (int q = 0; q < TC; ++q) {
+        if (t0 + q >= ntrans) break;
+        const T *are = acc + q * TILE * TILE;
+        const T *aim = acc + (TC + q) * TILE * TILE;
+        cplx<T> *plane = grid + (int64_t)(t0 + q) * nay * nax;
+        for (int row = tid / TILE; row < TILE; row += SPREAD_THREADS / TILE) {
+            const int gy = y0 + row;
+            const T f = dxv * decy[gy];
+            plane[(int64_t)gy * nax + gx] = {are[row * TILE + col] * f, aim[row * TILE + col] * f};
         }
     }
 }
 
+// --- pruned row FFT -----------------------------------------------------------------------------
+// out[row][j] = sum_{ia < n_in} in[row][ia] exp(+2 pi i (ia - n_in/2)(j - n_out/2) / n2),
+// n2 = P * Q.  Decimation in time over the P residues of ia: for each p the subsequence
+// a' -> in[P a' + p] (zero-padded to Q) is transformed in LDS by an in-place radix-2 DIF FFT
+// (result left bit-reversed), and every kept output accumulates  tw[p l] * F_p[l mod Q]  in
+// registers.  tpr threads cooperate on a row, rpw = 256 / tpr rows share a workgroup.
+struct RowFftArgs {
+    int n_in, n_out, n2, P, Q, logQ, tpr, rpw;
+    int64_t nrows;       // rows over all transforms
+    int64_t in_pitch;    // elements between consecutive input rows
+    int64_t out_pitch;   // elements between consecutive output rows
+};
+
+template <typename T>
+__global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restrict__ in,
+                                                         cplx<T> *__restrict__ out,
+                                                         const cplx<T> *__restrict__ tw,
+                                                         RowFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
+    cplx<T> *buf = reinterpret_cast<cplx<T> *>(fft_smem);
+    const int tid = threadIdx.x;
+    const int r = tid / a.tpr, lane = tid % a.tpr;
+    const int64_t row = (int64_t)blockIdx.x * a.rpw + r;
+    const bool valid = row < a.nrows;
+    const int j0 = blockIdx.y * (FFT_NOUT * a.tpr);
+    cplx<T> *rb = buf + (int64_t)r * a.Q;
+    const cplx<T> *rin = in + (valid ? row : 0) * a.in_pitch;
+    const int Q = a.Q, half_n = a.n_out / 2;
+
+    cplx<T> acc[FFT_NOUT];
+#pragma unroll
+    for (int i = 0; i < FFT_NOUT; ++i) acc[i] = {T(0), T(0)};
+
+    for (int p = 0; p < a.P; ++p) {
+        for (int q = lane; q < Q; q += a.tpr) {
+            const int ia = a.P * q + p;
+            rb[q] = (valid && ia < a.n_in) ? rin[ia] : cplx<T>{T(0), T(0)};
+        }
+        __syncthreads();
+        for (int s = 0; s < a.logQ; ++s) {
+            const int half = Q >> (s + 1);
+            const int tstride = a.P << s;  // n2 / (2 half)
+            for (int u = lane; u < (Q >> 1); u += a.tpr) {
+                const int blk = u / half, jj = u - blk * half;
+                const int i0 = blk * 2 * half + jj, i1 = i0 + half;
+                const cplx<T> x0 = rb[i0], x1 = rb[i1];
+                const cplx<T> d = {x0.re - x1.re, x0.im - x1.im};
+                rb[i0] = {x0.re + x1.re, x0.im + x1.im};
+                rb[i1] = cmul(d, tw[jj * tstride]);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < FFT_NOUT; ++i) {
+            const int j = j0 + lane + i * a.tpr;
+            if (j < a.n_out) {
+                const int l = j - half_n;
+                const int lq = ((l % Q) + Q) % Q;
+                const int idx = (int)(__brev((unsigned)lq) >> (32 - a.logQ));
+                cplx<T> v = rb[idx];
+                if (p) {
+                    int ti = (int)(((int64_t)p * l) % a.n2);
+                    if (ti < 0) ti += a.n2;
+                    v = cmul(v, tw[ti]);
+                }
+                acc[i].re += v.re;
+                acc[i].im += v.im;
+            }
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+    cplx<T> *rout = out + row * a.out_pitch;
+#pragma unroll
+    for (int i = 0; i < FFT_NOUT; ++i) {
+        const int j = j0 + lane + i * a.tpr;
+        if (j < a.n_out) {
+            const int l = j - half_n;
+            int ti = (int)((-(int64_t)(a.n_in / 2) * l) % a.n2);
+            if (ti < 0) ti += a.n2;
+            rout[j] = cmul(acc[i], tw[ti]);
+        }
+    }
+}
+
+// [batch][R][C] -> [batch][C][R], 32x32 tiles through LDS (both sides coalesced).
+template <typename T>
+__global__ void k_transpose(const cplx<T> *__restrict__ in, cplx<T> *__restrict__ out, int R, int C) {
+    __shared__ cplx<T> tile[32][33];
+    const int64_t plane = (int64_t)blockIdx.z * R * C;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per sweep
+    for (int rr = ty; rr < 32; rr += 8) {
+        const int rI = r0 + rr, cI = c0 + tx;
+        if (rI < R && cI < C) tile[rr][tx] = in[plane + (int64_t)rI * C + cI];
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8) {
+        const int cO = c0 + cc, rO = r0 + tx;
+        if (cO < C && rO < R) out[plane + (int64_t)cO * R + rO] = tile[tx][cc];
+    }
+}
+
 // --- 2-D gather (interp) ------------------------------------------------------------------------
+// The transformed grid arrives TRANSPOSED from the second FFT pass: [trans][lx][ly], y contiguous.
+// Index 0 of the per-dimension arrays below is the contiguous ("fast") dimension.
 struct InterpArgs {
-    int dim, w, tpol, nfg;        // tpol transforms per frequency group, nfg groups
-    int n2[3];
-    double h[3];                  // theta = h * s'
-    double btc[3], xc[3];
-    double sign;                  // prod_d (-1)^(n2_d / 2)
+    int w, tpol, nfg;             // tpol transforms per frequency group, nfg groups
+    int n2[2], no[2];
+    double h[2];                  // theta = h * s'
+    double btc[2], xc[2];
     int64_t out_fg_stride;        // output element strides
     int64_t out_k_stride;
     int64_t out_pol_off[16];      // offset of polarisation product r (r < tpol <= 16); beyond: r * out_pol_off[1]
@@ -286,9 +431,10 @@ struct InterpArgs {
 
 template <typename T>
 __global__ __launch_bounds__(INTERP_THREADS) void k_interp2d(
-    const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ btx,
-    const T *__restrict__ bty, const int *__restrict__ bl_idx, const signed char *__restrict__ flip,
-    const double *__restrict__ scale, InterpArgs a, KerParams ker, cplx<T> *__restrict__ out) {
+    const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ bt_fast,
+    const T *__restrict__ bt_slow, const int *__restrict__ bl_idx,
+    const signed char *__restrict__ flip, const double *__restrict__ scale, InterpArgs a,
+    KerParams ker, cplx<T> *__restrict__ out) {
     const int tid = threadIdx.x;
     const int g = tid & (GROUP - 1);
     const int lane_base = (tid & 63) & ~(GROUP - 1);
@@ -299,37 +445,34 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp2d(
     const int64_t k = bl_idx ? bl_idx[kl] : kl;
     const double sg = (flip && flip[kl]) ? -1.0 : 1.0;
     const double sc = scale[fg];
-    const double sx = sc * sg * (double)btx[k], sy = sc * sg * (double)bty[k];  // actual target
-    const double spx = sx - sc * a.btc[0], spy = sy - sc * a.btc[1];          // s' = s - s_c
-    const double thx = a.h[0] * spx, thy = a.h[1] * spy;
-    const double ex = thx * a.n2[0] * (0.5 / M_PI) + 0.5 * a.n2[0];
-    const double ey = thy * a.n2[1] * (0.5 / M_PI) + 0.5 * a.n2[1];
+    const double sf = sc * sg * (double)bt_fast[k], ss = sc * sg * (double)bt_slow[k];  // target
+    const double thf = a.h[0] * (sf - sc * a.btc[0]), ths = a.h[1] * (ss - sc * a.btc[1]);
+    const double ef = thf * a.n2[0] * (0.5 / M_PI) + 0.5 * a.no[0];
+    const double es = ths * a.n2[1] * (0.5 / M_PI) + 0.5 * a.no[1];
     const int w = a.w;
-    int j0x = (int)ceil(ex - 0.5 * w), j0y = (int)ceil(ey - 0.5 * w);
-    j0x = max(0, min(a.n2[0] - w, j0x));
-    j0y = max(0, min(a.n2[1] - w, j0y));
+    int j0f = (int)ceil(ef - 0.5 * w), j0s = (int)ceil(es - 0.5 * w);
+    j0f = max(0, min(a.no[0] - w, j0f));
+    j0s = max(0, min(a.no[1] - w, j0s));
     const T beta = (T)ker.beta, c4 = (T)ker.c;
-    T kx = g < w ? es_eval<T>((T)((double)(j0x + g) - ex), beta, c4) : T(0);
-    if ((j0x + g) & 1) kx = -kx;
-    T kyv = g < w ? es_eval<T>((T)((double)(j0y + g) - ey), beta, c4) : T(0);
-    if ((j0y + g) & 1) kyv = -kyv;
-    T ky[MAX_W];
+    const T kf = g < w ? es_eval<T>((T)((double)(j0f + g) - ef), beta, c4) : T(0);
+    const T ksv = g < w ? es_eval<T>((T)((double)(j0s + g) - es), beta, c4) : T(0);
+    T ks[MAX_W];
 #pragma unroll
-    for (int r = 0; r < MAX_W; ++r) ky[r] = __shfl(kyv, lane_base + r, 64);
+    for (int r = 0; r < MAX_W; ++r) ks[r] = __shfl(ksv, lane_base + r, 64);
 
-    // psi_1_hat at theta_x, theta_y: quadrature nodes split over the 16 lanes
-    double hx = 0.0, hy = 0.0;
+    // psi_1_hat at both thetas: quadrature nodes split over the 16 lanes
+    double hf = 0.0, hs = 0.0;
     for (int q = g; q < ker.nq; q += GROUP) {
-        hx += ker.glf[q] * cos(thx * ker.glz[q]);
-        hy += ker.glf[q] * cos(thy * ker.glz[q]);
+        hf += ker.glf[q] * cos(thf * ker.glz[q]);
+        hs += ker.glf[q] * cos(ths * ker.glz[q]);
     }
 #pragma unroll
     for (int off = GROUP / 2; off > 0; off >>= 1) {
-        hx += __shfl_xor(hx, off, 64);
-        hy += __shfl_xor(hy, off, 64);
+        hf += __shfl_xor(hf, off, 64);
+        hs += __shfl_xor(hs, off, 64);
     }
-    double pr = a.sign / (hx * hy), pi_ = 0.0;
-    const double ph = sx * a.xc[0] + sy * a.xc[1];  // post-phase exp(i s . x_c)
+    double pr = 1.0 / (hf * hs), pi_ = 0.0;
+    const double ph = sf * a.xc[0] + ss * a.xc[1];  // post-phase exp(i s . x_c)
     if (ph != 0.0) {
         double sn, cs;
         sincos(ph, &sn, &cs);
@@ -337,21 +480,21 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp2d(
         pr = pr * cs;
     }
 
-    const int64_t plane_sz = (int64_t)a.n2[0] * a.n2[1];
-    const int gcol = min(j0x + g, a.n2[0] - 1);
+    const int64_t plane_sz = (int64_t)a.no[0] * a.no[1];
+    const int gcol = min(j0f + g, a.no[0] - 1);
     for (int r = 0; r < a.tpol; ++r) {
         const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * plane_sz + gcol;
         T sr = T(0), si = T(0);
 #pragma unroll
         for (int rr = 0; rr < MAX_W; ++rr) {
             if (rr < w) {
-                const cplx<T> v = plane[(int64_t)(j0y + rr) * a.n2[0]];
-                sr += v.re * ky[rr];
-                si += v.im * ky[rr];
+                const cplx<T> v = plane[(int64_t)(j0s + rr) * a.no[0]];
+                sr += v.re * ks[rr];
+                si += v.im * ks[rr];
             }
         }
-        sr *= kx;
-        si *= kx;
+        sr *= kf;
+        si *= kf;
 #pragma unroll
         for (int off = GROUP / 2; off > 0; off >>= 1) {
             sr += __shfl_xor(sr, off, 64);
@@ -377,25 +520,6 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp2d(
 // Host-side plan
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-struct RocfftPrec;
-template <>
-struct RocfftPrec<double> {
-    static constexpr rocfft_precision v = rocfft_precision_double;
-};
-template <>
-struct RocfftPrec<float> {
-    static constexpr rocfft_precision v = rocfft_precision_single;
-};
-
-struct FftPlan {
-    rocfft_plan plan = nullptr;
-    rocfft_execution_info info = nullptr;
-    size_t work_bytes = 0;
-};
-
-void ensure_rocfft();
-
-template <typename T>
 class Nufft3 {
    public:
     int dim;
@@ -403,16 +527,14 @@ class Nufft3 {
     KerParams ker;
     Geom geo;
     hipStream_t stream;
-    int64_t M = 0;  // sources currently binned
+    int64_t M = 0;            // sources currently binned
     int64_t geom_serial = 0;  // bumps whenever the source->cell mapping changes
 
     // device state
     DevBuf i0u, fu, tile_of, counts, cursor, bin_start, i0s, fs, perm, oob;
-    DevBuf dec[3];
-    DevBuf grid, work;
-    DevBuf strengths;  // [M][ntrans] sorted order
-    std::map<std::tuple<int, int, int, int>, FftPlan> fft_cache;
-    int64_t stat_spread_cells = 0;  // fine-grid cells written per trans by the last spread
+    DevBuf dec[3], tw[3];
+    DevBuf buf0, buf1;  // ping-pong: A -> (x-pass) B -> (transpose) Bt -> (y-pass) Ct
+    DevBuf strengths;   // [M][ntrans] sorted order
 
     Nufft3(int dim_, double eps_, double sigma_, hipStream_t s, int w_override = 0)
         : dim(dim_), eps(eps_), sigma(sigma_), stream(s) {
@@ -421,16 +543,9 @@ class Nufft3 {
         FV_REQUIRE(eps > 0 && eps < 1, "eps must be in (0, 1)");
         ker = make_kernel(eps, sigma, w_override);
         geo.dim = dim;
-        ensure_rocfft();
-    }
-    ~Nufft3() {
-        for (auto &kv : fft_cache) {
-            if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
-            if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
-        }
     }
 
-    // Bounds -> grid sizes, deconvolution tables.
+    // Bounds -> grid sizes, deconvolution + twiddle tables.
     void set_geometry(const double *xc, const double *X, const double *btc, const double *B,
                       double scale_max) {
         Geom old = geo;
@@ -441,17 +556,21 @@ class Nufft3 {
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
             set_dim_geom(geo.d[d], sigma, ker.w, scale_max);
-            geo.ntile[d] = (int)cdiv(geo.d[d].n2, TILE);
+            geo.ntile[d] = geo.d[d].na / TILE;
         }
         for (int d = 0; d < dim; ++d) {
-            if (old.d[d].n1 == geo.d[d].n1 && old.d[d].n2 == geo.d[d].n2 && dec[d].p) continue;
-            dec[d].reserve(sizeof(T) * geo.d[d].n2);
-            hipLaunchKernelGGL(k_deconv_table<T>, dim3(cdiv(geo.d[d].n2, 256)), dim3(256), 0,
-                               stream, geo.d[d].n1, geo.d[d].n2, ker, dec[d].as<T>());
+            const DimGeom &g = geo.d[d];
+            if (old.d[d].na == g.na && old.d[d].n2 == g.n2 && dec[d].p && !first) continue;
+            dec[d].reserve(sizeof(T) * g.na);
+            hipLaunchKernelGGL(k_deconv_table<T>, dim3(cdiv(g.na, 256)), dim3(256), 0, stream, g.na,
+                               g.n2, ker, dec[d].as<T>());
+            tw[d].reserve(sizeof(cplx<T>) * g.n2);
+            hipLaunchKernelGGL(k_twiddle_table<T>, dim3(cdiv(g.n2, 256)), dim3(256), 0, stream,
+                               g.n2, tw[d].as<cplx<T>>());
         }
         bool changed = first;
         for (int d = 0; d < dim; ++d)
-            if (old.d[d].xc != geo.d[d].xc || old.d[d].h != geo.d[d].h || old.d[d].n2 != geo.d[d].n2)
+            if (old.d[d].xc != geo.d[d].xc || old.d[d].h != geo.d[d].h || old.d[d].na != geo.d[d].na)
                 changed = true;
         if (changed) {
             ++geom_serial;
@@ -482,7 +601,7 @@ class Nufft3 {
         for (int d = 0; d < 3; ++d) {
             a.xc[d] = geo.d[d].xc;
             a.invh[d] = 1.0 / geo.d[d].h;
-            a.n2[d] = d < dim ? geo.d[d].n2 : 1;
+            a.na[d] = d < dim ? geo.d[d].na : 1;
             a.ntile[d] = geo.ntile[d];
         }
         if (M > 0) {
@@ -516,56 +635,79 @@ class Nufft3 {
         cplx<T> *cs = strengths_buffer(ntrans);
         if (M == 0) return;
         hipLaunchKernelGGL(k_load_strengths<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, ntrans,
-                           tpol, dim, cin, perm.as<int>(), i0s.as<int>(), fs.as<T>(), ker.w,
-                           geo.d[0].h, geo.d[1].h, geo.d[2].h, geo.d[0].n2, geo.d[1].n2,
-                           dim > 2 ? geo.d[2].n2 : 1, geo.d[0].btc, geo.d[1].btc, geo.d[2].btc,
+                           tpol, dim, cin, perm.as<int>(), i0s.as<int>(), fs.as<T>(), geo.d[0].h,
+                           geo.d[1].h, geo.d[2].h, geo.d[0].na, geo.d[1].na,
+                           dim > 2 ? geo.d[2].na : 1, geo.d[0].btc, geo.d[1].btc, geo.d[2].btc,
                            scale_dev, cs);
     }
 
-    FftPlan &fft_plan(int ntrans) {
-        auto key = std::make_tuple(geo.d[0].n2, geo.d[1].n2, dim > 2 ? geo.d[2].n2 : 1, ntrans);
-        auto it = fft_cache.find(key);
-        if (it != fft_cache.end()) return it->second;
-        FftPlan fp;
-        size_t lengths[3] = {(size_t)geo.d[0].n2, (size_t)geo.d[1].n2, (size_t)geo.d[2].n2};
-        FV_ROCFFT(rocfft_plan_create(&fp.plan, rocfft_placement_inplace,
-                                     rocfft_transform_type_complex_inverse, RocfftPrec<T>::v,
-                                     (size_t)dim, lengths, (size_t)ntrans, nullptr));
-        FV_ROCFFT(rocfft_plan_get_work_buffer_size(fp.plan, &fp.work_bytes));
-        FV_ROCFFT(rocfft_execution_info_create(&fp.info));
-        FV_ROCFFT(rocfft_execution_info_set_stream(fp.info, stream));
-        return fft_cache.emplace(key, fp).first->second;
+    // HBM bytes one transform's grid buffers occupy (for the caller's batching heuristic).
+    int64_t bytes_per_trans() const {
+        const DimGeom &x = geo.d[0], &y = geo.d[1];
+        const int64_t b0 = std::max((int64_t)x.na * y.na, (int64_t)x.no * y.na);
+        const int64_t b1 = std::max((int64_t)y.na * x.no, (int64_t)x.no * y.no);
+        return (b0 + b1) * (int64_t)sizeof(cplx<T>);
     }
 
     void spread(int ntrans);
-    void fft(int ntrans) {
-        FftPlan &fp = fft_plan(ntrans);
-        if (fp.work_bytes) {
-            work.reserve(fp.work_bytes);
-            FV_ROCFFT(rocfft_execution_info_set_work_buffer(fp.info, work.p, fp.work_bytes));
-        }
-        void *bufs[1] = {grid.p};
-        FV_ROCFFT(rocfft_execute(fp.plan, bufs, nullptr, fp.info));
-    }
+    void fft(int ntrans);
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
     // index list / flip flags of length N, per-group scale (device, nfg doubles).
     void interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
                 const signed char *flip, const double *scale_dev, int nfg, int tpol,
                 cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                 const int64_t *out_pol_off, bool accumulate);
+
+   private:
+    void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
+                int64_t nrows, int64_t in_pitch);
 };
 
 template <typename T>
 void Nufft3<T>::spread(int ntrans) {
-    grid.reserve(sizeof(cplx<T>) * geo.ncell() * ntrans);
     FV_REQUIRE(dim == 2, "3-D spread not built yet");
+    const DimGeom &x = geo.d[0], &y = geo.d[1];
+    buf0.reserve(sizeof(cplx<T>) * std::max((int64_t)x.na * y.na, (int64_t)x.no * y.na) * ntrans);
     constexpr int TC = sizeof(T) == 8 ? 4 : 8;  // 64 KiB of LDS accumulators per workgroup
     dim3 g(geo.ntile[0], geo.ntile[1], (unsigned)cdiv(ntrans, TC));
     hipLaunchKernelGGL((k_spread2d<T, TC>), g, dim3(SPREAD_THREADS), 0, stream, M, i0s.as<int>(),
                        fs.as<T>(), bin_start.as<int>(), strengths.as<cplx<T>>(), ntrans,
-                       dec[0].as<T>(), dec[1].as<T>(), grid.as<cplx<T>>(), geo.d[0].n2,
-                       geo.d[1].n2, geo.ntile[0], geo.ntile[1], ker.w, (T)ker.beta, (T)ker.c);
-    stat_spread_cells = geo.ncell();
+                       dec[0].as<T>(), dec[1].as<T>(), buf0.as<cplx<T>>(), x.na, y.na,
+                       geo.ntile[0], geo.ntile[1], ker.w, (T)ker.beta, (T)ker.c);
+}
+
+template <typename T>
+void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
+                       int64_t nrows, int64_t in_pitch) {
+    RowFftArgs a{};
+    a.n_in = g.na;
+    a.n_out = g.no;
+    a.n2 = g.n2;
+    a.P = g.P;
+    a.Q = g.Q;
+    a.logQ = g.logQ;
+    a.tpr = std::min(FFT_THREADS, g.Q / 2);
+    a.rpw = FFT_THREADS / a.tpr;
+    a.nrows = nrows;
+    a.in_pitch = in_pitch;
+    a.out_pitch = g.no;
+    const size_t smem = sizeof(cplx<T>) * (size_t)a.rpw * g.Q;
+    dim3 grid((unsigned)cdiv(nrows, a.rpw), (unsigned)cdiv(g.no, FFT_NOUT * a.tpr));
+    hipLaunchKernelGGL(k_rowfft<T>, grid, dim3(FFT_THREADS), smem, stream, in, out, twd, a);
+}
+
+template <typename T>
+void Nufft3<T>::fft(int ntrans) {
+    const DimGeom &x = geo.d[0], &y = geo.d[1];
+    buf1.reserve(sizeof(cplx<T>) * std::max((int64_t)y.na * x.no, (int64_t)x.no * y.no) * ntrans);
+    cplx<T> *A = buf0.as<cplx<T>>(), *Bm = buf1.as<cplx<T>>();
+    // x-pass: A [t][na_y][na_x] -> B [t][na_y][no_x]
+    rowfft(A, Bm, x, tw[0].as<cplx<T>>(), (int64_t)ntrans * y.na, x.na);
+    // transpose: B -> Bt [t][no_x][na_y]   (A is dead, reuse its storage)
+    dim3 tg((unsigned)cdiv(x.no, 32), (unsigned)cdiv(y.na, 32), (unsigned)ntrans);
+    hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, Bm, A, y.na, x.no);
+    // y-pass: Bt rows -> Ct [t][no_x][no_y]
+    rowfft(A, Bm, y, tw[1].as<cplx<T>>(), (int64_t)ntrans * x.no, y.na);
 }
 
 template <typename T>
@@ -576,17 +718,17 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     if (N == 0 || nfg == 0) return;
     FV_REQUIRE(dim == 2, "3-D interp not built yet");
     InterpArgs a{};
-    a.dim = dim;
     a.w = ker.w;
     a.tpol = tpol;
     a.nfg = nfg;
-    a.sign = 1.0;
-    for (int d = 0; d < 3; ++d) {
-        a.n2[d] = d < dim ? geo.d[d].n2 : 1;
-        a.h[d] = geo.d[d].h;
-        a.btc[d] = geo.d[d].btc;
-        a.xc[d] = geo.d[d].xc;
-        if (d < dim && ((geo.d[d].n2 / 2) & 1)) a.sign = -a.sign;
+    const int map[2] = {1, 0};  // fast dimension of Ct is y
+    for (int i = 0; i < 2; ++i) {
+        const DimGeom &g = geo.d[map[i]];
+        a.n2[i] = g.n2;
+        a.no[i] = g.no;
+        a.h[i] = g.h;
+        a.btc[i] = g.btc;
+        a.xc[i] = g.xc;
     }
     a.out_fg_stride = out_fg_stride;
     a.out_k_stride = out_k_stride;
@@ -594,7 +736,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.accumulate = accumulate ? 1 : 0;
     const int64_t items = N * nfg;
     hipLaunchKernelGGL(k_interp2d<T>, dim3(cdiv(items, INTERP_THREADS / GROUP)),
-                       dim3(INTERP_THREADS), 0, stream, grid.as<cplx<T>>(), N, btx, bty, bl_idx,
+                       dim3(INTERP_THREADS), 0, stream, buf1.as<cplx<T>>(), N, bty, btx, bl_idx,
                        flip, scale_dev, a, ker, out);
 }
 

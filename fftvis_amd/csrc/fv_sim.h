@@ -265,7 +265,7 @@ struct StrengthArgs {
     int polarized, pol_sky, same_beam;
     int dim, w;
     double h[3], btc[3];
-    int n2[3];
+    int na[3];
     BeamDesc bi, bj;
 };
 
@@ -291,7 +291,7 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ perm,
     double dot = 0.0;
     for (int d = 0; d < a.dim; ++d) {
         const double pos = (double)i0s[(int64_t)d * a.M + p] - (double)fs[(int64_t)d * a.M + p];
-        dot += a.btc[d] * (pos - 0.5 * a.n2[d]) * a.h[d];
+        dot += a.btc[d] * (pos - 0.5 * a.na[d]) * a.h[d];
     }
     cplx<double> pre = {1.0, 0.0};
     if (dot != 0.0) sincos(freq * dot, &pre.im, &pre.re);
@@ -693,19 +693,24 @@ class Sim : public SimBase {
         d_blockoff.reserve(sizeof(int) * (nblk + 1));
         d_scale.reserve(sizeof(double) * std::max(nf, 1));
 
-        // grid size estimate at the top frequency for the grouping heuristic
+        // grid-buffer cells per transform at the top frequency, for the grouping heuristic
         double cells_top = 1.0;
         {
             KerParams k = make_kernel(eps, sigma);
+            double fmax = 0;
+            for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
+            double na[3] = {1, 1, 1}, no[3] = {1, 1, 1};
             for (int d = 0; d < D; ++d) {
                 DimGeom g;
                 g.X = X[d];
                 double Bm = 0;
                 for (const Pair &p : pairs) Bm = std::max(Bm, p.B[d]);
                 g.B = Bm;
-                set_dim_geom(g, sigma, k.w, std::fabs(freqs[f1 > f0 ? f1 - 1 : f0]));
-                cells_top *= g.n2;
+                set_dim_geom(g, sigma, k.w, fmax);
+                na[d] = g.na;
+                no[d] = g.no;
             }
+            cells_top = std::max(na[0] * na[1], no[0] * na[1]) + std::max(na[1] * no[0], no[0] * no[1]);
         }
         const auto groups = freq_groups(f0, f1, cells_top);
 
@@ -766,7 +771,7 @@ class Sim : public SimBase {
                     for (int d = 0; d < 3; ++d) {
                         sa.h[d] = nufft->geo.d[d].h;
                         sa.btc[d] = d < D ? pr.btc[d] : 0.0;
-                        sa.n2[d] = d < D ? nufft->geo.d[d].n2 : 1;
+                        sa.na[d] = d < D ? nufft->geo.d[d].na : 1;
                     }
                     sa.bi = desc(pr.bi);
                     sa.bj = desc(pr.bj);
@@ -782,12 +787,15 @@ class Sim : public SimBase {
                     nufft->spread(ntrans);
                     ev_end(e3);
                     st[0] += 1;
-                    st[1] += (double)nufft->geo.ncell() * ntrans;
+                    st[1] += (double)nufft->geo.cells_a() * ntrans;
                     st[2] += (double)M * ntrans;
                     size_t e4 = ev_begin(TM_FFT);
                     nufft->fft(ntrans);
                     ev_end(e4);
-                    st[3] += (double)nufft->geo.ncell() * ntrans;
+                    {   // cells moved by the pruned FFT: read A, write+read B, write+read Bt, write Ct
+                        const DimGeom &gx = nufft->geo.d[0], &gy = nufft->geo.d[1];
+                        st[3] += ((double)gx.na * gy.na + 4.0 * gx.no * gy.na + (double)gx.no * gy.no) * ntrans;
+                    }
                     size_t e5 = ev_begin(TM_INTERP);
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
                     nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
@@ -800,7 +808,7 @@ class Sim : public SimBase {
                     st[4] += (double)pr.n * ntrans;
                     st[6] = nufft->geo.d[0].n2;
                     st[7] = nufft->geo.d[1].n2;
-                    st[8] = D > 2 ? nufft->geo.d[2].n2 : 1;
+                    st[8] = nufft->geo.d[0].na * 65536.0 + nufft->geo.d[1].na;
                     st[9] = nufft->ker.w;
                 }
             }

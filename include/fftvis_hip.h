@@ -22,7 +22,7 @@ extern "C" {
 #define FV_OK 0
 #define FV_ERR_ARG 1
 #define FV_ERR_HIP 2
-#define FV_ERR_ROCFFT 3
+#define FV_ERR_ROCFFT 3 /* reserved (library FFT no longer used) */
 #define FV_ERR_INTERNAL 4
 
 /* ---- discovery / diagnostics ------------------------------------------------------------ */
@@ -137,8 +137,9 @@ int fv_sim_sync(fv_sim *h);
 
 /* Introspection for bench/roofline: fills up to n doubles:
  * [0] spread kernel launches, [1] fine-grid cells written by spread (all trans, summed),
- * [2] source-footprint visits, [3] FFT cells, [4] interp targets x trans, [5] above-horizon
- * sources summed over times, [6] last n2x, [7] last n2y, [8] last n2z, [9] kernel width w.   */
+ * [2] source x trans visits, [3] cells moved through HBM by the pruned FFT passes,
+ * [4] interp targets x trans, [5] above-horizon sources summed over times, [6] last n2x,
+ * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w.                          */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing of the dominant kernels on the handle's stream (ms, summed since reset):
