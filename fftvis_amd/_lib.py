@@ -71,7 +71,8 @@ def build(force: bool = False) -> str:
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, os.path.join(CSRC, "fv_capi.hip"), "-o", LIB_PATH]
+    extra = os.environ.get("FFTVIS_HIP_EXTRA_FLAGS", "").split()
+    cmd = [hipcc, *HIPCC_FLAGS, *extra, os.path.join(CSRC, "fv_capi.hip"), "-o", LIB_PATH]
     subprocess.check_call(cmd)
     return LIB_PATH
 

@@ -30,8 +30,14 @@ constexpr int GROUP = 16;      // lanes cooperating on one source / one target (
 constexpr int SPREAD_THREADS = 256;
 constexpr int INTERP_THREADS = 256;
 constexpr int FFT_THREADS = 256;
-constexpr int FFT_NOUT = 16;   // outputs accumulated in registers per thread of a row-FFT
-constexpr int FFT_QMAX_LOG = 12;  // LDS row buffer: Q <= 4096 complex (64 KiB fp64)
+#ifndef FV_FFT_QMAX_LOG
+#define FV_FFT_QMAX_LOG 12
+#endif
+#ifndef FV_FFT_TPR_DIV
+#define FV_FFT_TPR_DIV 8  // threads per row >= Q / this
+#endif
+constexpr int FFT_QMAX_LOG = FV_FFT_QMAX_LOG;  // LDS row buffer: Q <= 2^this complex (70 KiB fp64 at 4096)
+constexpr int FFT_NACC = 18;  // outputs a thread of a row-FFT accumulates in registers
 
 struct DimGeom {
     double xc = 0, X = 0;    // source-coordinate centre / half-width
@@ -53,29 +59,32 @@ struct Geom {
     int64_t cells_o() const { return (int64_t)d[0].no * d[1].no * (dim > 2 ? d[2].no : 1); }
 };
 
-// Smallest n2 = P * 2^b >= nmin with 64 <= 2^b <= 4096 and P <= 16 (P unbounded at 2^b = 4096);
-// then as many factors of two as possible move from P into Q.
+// n2 = P * 2^b >= nmin with 64 <= 2^b <= 4096 and P <= 16 (P unbounded at 2^b = 4096), chosen to
+// minimise n2 * (1 + 0.03 (P - 1)): HBM traffic grows with n2, per-row work with P.  Then as many
+// factors of two as possible move from P into Q.
 inline void choose_pq(int nmin, DimGeom &g) {
-    int best = 0, bp = 0, bq = 0;
+    double best = 0;
+    int bp = 0, bq = 0;
     for (int b = 6; b <= FFT_QMAX_LOG; ++b) {
         const int q = 1 << b;
         const int p = (nmin + q - 1) / q;
         if (p > 16 && b < FFT_QMAX_LOG) continue;
-        const int n = p * q;
-        if (best == 0 || n < best) {
-            best = n;
-            bp = p;
-            bq = b;
+        int pp = p, bb = b;
+        while (pp % 2 == 0 && bb < FFT_QMAX_LOG) {
+            pp /= 2;
+            ++bb;
+        }
+        const double cost = (double)p * q * (1.0 + 0.03 * (pp - 1));
+        if (best == 0 || cost < best) {
+            best = cost;
+            bp = pp;
+            bq = bb;
         }
     }
-    while (bp % 2 == 0 && bq < FFT_QMAX_LOG) {
-        bp /= 2;
-        ++bq;
-    }
-    g.n2 = best;
     g.P = bp;
     g.Q = 1 << bq;
     g.logQ = bq;
+    g.n2 = bp << bq;
 }
 
 inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
@@ -314,16 +323,102 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
 
 // --- pruned row FFT -----------------------------------------------------------------------------
 // out[row][j] = sum_{ia < n_in} in[row][ia] exp(+2 pi i (ia - n_in/2)(j - n_out/2) / n2),
-// n2 = P * Q.  Decimation in time over the P residues of ia: for each p the subsequence
-// a' -> in[P a' + p] (zero-padded to Q) is transformed in LDS by an in-place radix-2 DIF FFT
-// (result left bit-reversed), and every kept output accumulates  tw[p l] * F_p[l mod Q]  in
-// registers.  tpr threads cooperate on a row, rpw = 256 / tpr rows share a workgroup.
+// n2 = P * Q, Q = 2^logQ.  Decimation in time over the P residues of ia: for each p the
+// subsequence a' -> in[P a' + p] (zero-padded to Q) is transformed in LDS by in-place DIF passes of
+// radix 16/8 held in registers (result left digit-reversed), and every kept output accumulates
+// tw[p l] * F_p[l mod Q] in registers.  tpr threads cooperate on a row,
+// rpw = 256 / tpr rows share a workgroup.  LDS rows are padded by one element per 16 so that the
+// unit-stride last pass does not pile 16 lanes onto one bank.
 struct RowFftArgs {
     int n_in, n_out, n2, P, Q, logQ, tpr, rpw;
+    int npass, radix_log[4];
+    int qp;              // padded LDS row length (elements)
+    int jchunk;          // outputs handled per blockIdx.y (<= tpr * FFT_NACC)
     int64_t nrows;       // rows over all transforms
     int64_t in_pitch;    // elements between consecutive input rows
     int64_t out_pitch;   // elements between consecutive output rows
 };
+
+// LDS padding: one element per 16 and one more per 256, so that the unit-stride last pass, the
+// stride-16 middle pass and the stride-256 digit-reversed read-out all spread over the banks.
+__host__ __device__ inline int fft_pidx(int i) { return i + (i >> 4) + (i >> 8); }
+
+template <typename T>
+__device__ inline cplx<T> cmul_root16(cplx<T> d, int k) {  // d * exp(+2 pi i k / 16), 0 <= k < 8
+    constexpr T C1 = T(0.92387953251128675613), S1 = T(0.38268343236508977173),
+                H = T(0.70710678118654752440);
+    switch (k) {
+        case 0: return d;
+        case 1: return {d.re * C1 - d.im * S1, d.re * S1 + d.im * C1};
+        case 2: return {(d.re - d.im) * H, (d.re + d.im) * H};
+        case 3: return {d.re * S1 - d.im * C1, d.re * C1 + d.im * S1};
+        case 4: return {-d.im, d.re};
+        case 5: return {-d.re * S1 - d.im * C1, d.re * C1 - d.im * S1};
+        case 6: return {(-d.re - d.im) * H, (d.re - d.im) * H};
+        default: return {-d.re * C1 - d.im * S1, d.re * S1 - d.im * C1};
+    }
+}
+
+// In-register radix-2 DIF network of size R (inverse sign); X[k] ends up in v[bitrev_R(k)].
+template <typename T, int R>
+__device__ inline void dif_regs(cplx<T> *v) {
+    if constexpr (R > 1) {
+        constexpr int H = R / 2;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const cplx<T> a = v[k], b = v[k + H];
+            v[k] = {a.re + b.re, a.im + b.im};
+            v[k + H] = cmul_root16<T>(cplx<T>{a.re - b.re, a.im - b.im}, k * (16 / R));
+        }
+        dif_regs<T, H>(v);
+        dif_regs<T, H>(v + H);
+    }
+}
+
+constexpr int bitrev_small(int k, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((k >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// One radix-R butterfly group of a DIF pass with current span L = R << logLR on LDS row rb.
+template <typename T, int LOGR>
+__device__ inline void fft_pass_item(cplx<T> *rb, int u, int logLR, const cplx<T> *__restrict__ tw,
+                                     int twmul) {
+    constexpr int R = 1 << LOGR;
+    const int stride = 1 << logLR;
+    const int g = u >> logLR, j = u & (stride - 1);
+    const int base = (g << (logLR + LOGR)) + j;
+    const cplx<T> w = tw[j * twmul];  // issued first: its latency hides under the LDS reads
+    cplx<T> v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = rb[fft_pidx(base + k * stride)];
+    dif_regs<T, R>(v);
+    if (logLR == 0) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) rb[fft_pidx(base + k)] = v[bitrev_small(k, LOGR)];
+    } else {
+        cplx<T> wk = w;
+        rb[fft_pidx(base)] = v[0];
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+            rb[fft_pidx(base + k * stride)] = cmul(v[bitrev_small(k, LOGR)], wk);
+            wk = cmul(wk, w);
+        }
+    }
+}
+
+// position of frequency k after the in-place DIF passes (mixed-radix digit reversal)
+__device__ inline int fft_digit_pos(int k, const RowFftArgs &a) {
+    int pos = 0, span = a.logQ;
+    for (int s = 0; s < a.npass; ++s) {
+        const int rl = a.radix_log[s];
+        span -= rl;
+        pos += (k & ((1 << rl) - 1)) << span;
+        k >>= rl;
+    }
+    return pos;
+}
 
 template <typename T>
 __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restrict__ in,
@@ -331,68 +426,84 @@ __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restric
                                                          const cplx<T> *__restrict__ tw,
                                                          RowFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
-    cplx<T> *buf = reinterpret_cast<cplx<T> *>(fft_smem);
+    cplx<T> *smem = reinterpret_cast<cplx<T> *>(fft_smem);
     const int tid = threadIdx.x;
     const int r = tid / a.tpr, lane = tid % a.tpr;
     const int64_t row = (int64_t)blockIdx.x * a.rpw + r;
     const bool valid = row < a.nrows;
-    const int j0 = blockIdx.y * (FFT_NOUT * a.tpr);
-    cplx<T> *rb = buf + (int64_t)r * a.Q;
+    cplx<T> *rb = smem + (int64_t)r * a.qp;
     const cplx<T> *rin = in + (valid ? row : 0) * a.in_pitch;
     const int Q = a.Q, half_n = a.n_out / 2;
+    const int jbeg = blockIdx.y * a.jchunk;
+    const int jend = min(a.n_out, jbeg + a.jchunk);
+    const int jfirst = jbeg + lane;
 
-    cplx<T> acc[FFT_NOUT];
+    cplx<T> acc[FFT_NACC];  // this thread's outputs j = jfirst + i * tpr
 #pragma unroll
-    for (int i = 0; i < FFT_NOUT; ++i) acc[i] = {T(0), T(0)};
+    for (int i = 0; i < FFT_NACC; ++i) acc[i] = {T(0), T(0)};
 
     for (int p = 0; p < a.P; ++p) {
         for (int q = lane; q < Q; q += a.tpr) {
             const int ia = a.P * q + p;
-            rb[q] = (valid && ia < a.n_in) ? rin[ia] : cplx<T>{T(0), T(0)};
+            rb[fft_pidx(q)] = (valid && ia < a.n_in) ? rin[ia] : cplx<T>{T(0), T(0)};
         }
         __syncthreads();
-        for (int s = 0; s < a.logQ; ++s) {
-            const int half = Q >> (s + 1);
-            const int tstride = a.P << s;  // n2 / (2 half)
-            for (int u = lane; u < (Q >> 1); u += a.tpr) {
-                const int blk = u / half, jj = u - blk * half;
-                const int i0 = blk * 2 * half + jj, i1 = i0 + half;
-                const cplx<T> x0 = rb[i0], x1 = rb[i1];
-                const cplx<T> d = {x0.re - x1.re, x0.im - x1.im};
-                rb[i0] = {x0.re + x1.re, x0.im + x1.im};
-                rb[i1] = cmul(d, tw[jj * tstride]);
+        int logL = a.logQ;
+        for (int s = 0; s < a.npass; ++s) {
+            const int rl = a.radix_log[s];
+            const int items = Q >> rl, logLR = logL - rl;
+            const int twmul = a.P << (a.logQ - logL);  // n2 / L
+            if (rl == 4) {
+                for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 4>(rb, u, logLR, tw, twmul);
+            } else if (rl == 3) {
+                for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 3>(rb, u, logLR, tw, twmul);
+            } else if (rl == 2) {
+                for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 2>(rb, u, logLR, tw, twmul);
+            } else {
+                for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 1>(rb, u, logLR, tw, twmul);
             }
             __syncthreads();
+            logL = logLR;
+        }
+        // acc[j] += tw[p l] F_p[l mod Q]; the twiddle advances by a fixed factor per step
+        cplx<T> t = {T(1), T(0)}, step = {T(1), T(0)};
+        if (p && jfirst < jend) {
+            int ti = (int)(((int64_t)p * (jfirst - half_n)) % a.n2);
+            if (ti < 0) ti += a.n2;
+            t = tw[ti];
+            step = tw[(int)(((int64_t)p * a.tpr) % a.n2)];
         }
 #pragma unroll
-        for (int i = 0; i < FFT_NOUT; ++i) {
-            const int j = j0 + lane + i * a.tpr;
-            if (j < a.n_out) {
-                const int l = j - half_n;
-                const int lq = ((l % Q) + Q) % Q;
-                const int idx = (int)(__brev((unsigned)lq) >> (32 - a.logQ));
-                cplx<T> v = rb[idx];
+        for (int i = 0; i < FFT_NACC; ++i) {
+            const int j = jfirst + i * a.tpr;
+            if (j < jend) {
+                const int lq = (j - half_n) & (Q - 1);
+                cplx<T> v = rb[fft_pidx(fft_digit_pos(lq, a))];
                 if (p) {
-                    int ti = (int)(((int64_t)p * l) % a.n2);
-                    if (ti < 0) ti += a.n2;
-                    v = cmul(v, tw[ti]);
+                    v = cmul(v, t);
+                    t = cmul(t, step);
                 }
                 acc[i].re += v.re;
                 acc[i].im += v.im;
             }
         }
-        __syncthreads();
+        if (p + 1 < a.P) __syncthreads();  // rb is reloaded for the next residue
     }
-    if (!valid) return;
+    if (!valid || jfirst >= jend) return;
+    // final phase exp(-2 pi i (n_in/2) l / n2), again by recurrence along this thread's outputs
     cplx<T> *rout = out + row * a.out_pitch;
+    int ti = (int)((-(int64_t)(a.n_in / 2) * (jfirst - half_n)) % a.n2);
+    if (ti < 0) ti += a.n2;
+    cplx<T> t = tw[ti];
+    int si = (int)((-(int64_t)(a.n_in / 2) * a.tpr) % a.n2);
+    if (si < 0) si += a.n2;
+    const cplx<T> step = tw[si];
 #pragma unroll
-    for (int i = 0; i < FFT_NOUT; ++i) {
-        const int j = j0 + lane + i * a.tpr;
-        if (j < a.n_out) {
-            const int l = j - half_n;
-            int ti = (int)((-(int64_t)(a.n_in / 2) * l) % a.n2);
-            if (ti < 0) ti += a.n2;
-            rout[j] = cmul(acc[i], tw[ti]);
+    for (int i = 0; i < FFT_NACC; ++i) {
+        const int j = jfirst + i * a.tpr;
+        if (j < jend) {
+            rout[j] = cmul(acc[i], t);
+            t = cmul(t, step);
         }
     }
 }
@@ -679,6 +790,8 @@ void Nufft3<T>::spread(int ntrans) {
 template <typename T>
 void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                        int64_t nrows, int64_t in_pitch) {
+    static const int plans[7][4] = {{3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0}, {3, 3, 3, 0},
+                                    {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 6 .. 12
     RowFftArgs a{};
     a.n_in = g.na;
     a.n_out = g.no;
@@ -686,13 +799,30 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.P = g.P;
     a.Q = g.Q;
     a.logQ = g.logQ;
-    a.tpr = std::min(FFT_THREADS, g.Q / 2);
-    a.rpw = FFT_THREADS / a.tpr;
+    FV_REQUIRE(g.logQ >= 6 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
+    a.npass = 0;
+    for (int s = 0; s < 4; ++s) {
+        a.radix_log[s] = plans[g.logQ - 6][s];
+        if (a.radix_log[s]) ++a.npass;
+    }
+    a.qp = fft_pidx(g.Q);
+    // threads per row: enough for one radix-16 item each and for <= FFT_NACC outputs each
+    int tpr = 16;
+    while (tpr < FFT_THREADS && (tpr < g.Q / FV_FFT_TPR_DIV || (int64_t)tpr * FFT_NACC < g.no)) tpr *= 2;
+    a.tpr = tpr;
+    a.rpw = FFT_THREADS / tpr;
+    a.jchunk = std::min(g.no, tpr * FFT_NACC);  // more outputs than that: extra chunks (grid.y)
     a.nrows = nrows;
     a.in_pitch = in_pitch;
     a.out_pitch = g.no;
-    const size_t smem = sizeof(cplx<T>) * (size_t)a.rpw * g.Q;
-    dim3 grid((unsigned)cdiv(nrows, a.rpw), (unsigned)cdiv(g.no, FFT_NOUT * a.tpr));
+    const size_t smem = sizeof(cplx<T>) * (size_t)a.qp * a.rpw;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)cdiv(nrows, a.rpw), (unsigned)cdiv(g.no, a.jchunk));
     hipLaunchKernelGGL(k_rowfft<T>, grid, dim3(FFT_THREADS), smem, stream, in, out, twd, a);
 }
 
