@@ -15,17 +15,20 @@
 //    over the P residues) and write no outputs; a tile transpose sits between the x- and y-pass.
 //    HBM traffic ~ 6 na^2 cells per transform instead of the >= 8 n2^2 = 32 na^2 of a full-grid
 //    library FFT (four passes) plus the zero padding the spread would have to write.
-//  * Spread is output-driven: one workgroup owns one 32x32 tile of A for TC transforms,
-//    accumulates all sources whose footprint touches it in LDS (ds_add_f64 / ds_add_f32), then
-//    writes every cell of the tile exactly once (zeros included, deconvolution applied) with 512-B
-//    row segments.  No global atomics, no separate memset pass.
+//  * Spread is a GATHER: one thread owns one cell of A for TCH transforms.  Sources are counting-
+//    sorted into 8x8-cell bins of their footprint origin, their 2w kernel weights are evaluated once
+//    per (time, geometry); a cell walks the <= 3x3 bins whose footprints can reach it, multiplies
+//    the two tabulated weights and accumulates strengths in registers, then writes its value once
+//    (zeros included, deconvolution applied), 1 KiB per wave-store.  No atomics (LDS or global), no
+//    memset pass, no LDS; the result is order-deterministic given the bin order.
 #pragma once
 
 #include "fv_eskernel.h"
 
 namespace fv {
 
-constexpr int TILE = 32;       // fine-grid tile edge (cells) owned by one spread workgroup
+constexpr int TILE = 32;       // buffer-A extents are rounded up to a multiple of this
+constexpr int BINLOG = 3;      // sources are binned by footprint origin in 8x8-cell bins
 constexpr int GROUP = 16;      // lanes cooperating on one source / one target (>= MAX_W)
 constexpr int SPREAD_THREADS = 256;
 constexpr int INTERP_THREADS = 256;
@@ -34,7 +37,7 @@ constexpr int FFT_THREADS = 256;
 #define FV_FFT_QMAX_LOG 12
 #endif
 #ifndef FV_FFT_TPR_DIV
-#define FV_FFT_TPR_DIV 8  // threads per row >= Q / this
+#define FV_FFT_TPR_DIV 16  // threads per row >= Q / this
 #endif
 constexpr int FFT_QMAX_LOG = FV_FFT_QMAX_LOG;  // LDS row buffer: Q <= 2^this complex (70 KiB fp64 at 4096)
 constexpr int FFT_NACC = 18;  // outputs a thread of a row-FFT accumulates in registers
@@ -53,8 +56,8 @@ struct DimGeom {
 struct Geom {
     int dim = 2;
     DimGeom d[3];
-    int ntile[3] = {1, 1, 1};
-    int ntiles() const { return ntile[0] * ntile[1] * ntile[2]; }
+    int nbin[3] = {1, 1, 1};
+    int nbins() const { return nbin[0] * nbin[1] * nbin[2]; }
     int64_t cells_a() const { return (int64_t)d[0].na * d[1].na * (dim > 2 ? d[2].na : 1); }
     int64_t cells_o() const { return (int64_t)d[0].no * d[1].no * (dim > 2 ? d[2].no : 1); }
 };
@@ -115,12 +118,12 @@ inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
 
 struct BinArgs {
     double xc[3], invh[3];
-    int na[3], ntile[3];
+    int na[3], nbin[3];
     int w, dim;
 };
 
 // Footprint start cell i0 = ceil(p - w/2) in buffer-A coordinates and first kernel argument
-// f = i0 - p, per dimension, plus the tile the footprint's middle cell falls in.  Positions are
+// f = i0 - p, per dimension, plus the 8x8 bin the footprint origin falls in.  Positions are
 // formed in fp64 and split into (int cell, T offset) so that fp32 runs keep sub-cell accuracy on
 // multi-thousand-cell grids.
 template <typename T>
@@ -143,10 +146,10 @@ __global__ void k_bin_count(int64_t M, const T *__restrict__ x, const T *__restr
         }
         i0u[(int64_t)d * M + j] = i0;
         fu[(int64_t)d * M + j] = (T)((double)i0 - p);
-        tl[d] = (i0 + a.w / 2) / TILE;
+        tl[d] = i0 >> BINLOG;
     }
     if (oob) atomicAdd(n_oob, 1);
-    int t = (tl[2] * a.ntile[1] + tl[1]) * a.ntile[0] + tl[0];
+    int t = (tl[2] * a.nbin[1] + tl[1]) * a.nbin[0] + tl[0];
     tile_of[j] = t;
     atomicAdd(&counts[t], 1);
 }
@@ -176,18 +179,51 @@ __global__ void k_exclusive_scan(const int *__restrict__ in, int *__restrict__ o
     if (threadIdx.x == 0) out[n] = carry;
 }
 
+// Three-phase scan for large n (hundreds of thousands of bins): per-1024-block local scans and
+// block totals, a scan of the totals (k_exclusive_scan), then the offsets are added back.
+__global__ void k_scan_blocks(const int *__restrict__ in, int *__restrict__ out,
+                              int *__restrict__ totals, int n) {
+    __shared__ int wsum[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int v = i < n ? in[i] : 0;
+    int x = v;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; ++k) base += wsum[k];
+    if (i < n) out[i] = base + x - v;
+    if (threadIdx.x == 1023) totals[blockIdx.x] = base + x;
+}
+
+__global__ void k_scan_add(int *__restrict__ out, const int *__restrict__ block_off, int n) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += block_off[blockIdx.x];
+    if (i == n - 1 || (n == 0 && i == 0)) out[n] = block_off[gridDim.x];
+}
+
+// Scatter into bin order and tabulate each source's kernel weights:
+//   kw[(d * M + pos) * w + k] = psi(f_d + k),  k < w.
 template <typename T>
 __global__ void k_bin_scatter(int64_t M, int dim, const int *__restrict__ i0u,
                               const T *__restrict__ fu, const int *__restrict__ tile_of,
                               const int *__restrict__ bin_start, int *__restrict__ cursor,
-                              int *__restrict__ i0s, T *__restrict__ fs, int *__restrict__ perm) {
+                              int *__restrict__ i0s, T *__restrict__ fs, int *__restrict__ perm,
+                              T *__restrict__ kw, int w, T beta, T c4) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
     int t = tile_of[j];
     int pos = bin_start[t] + atomicAdd(&cursor[t], 1);
     for (int d = 0; d < dim; ++d) {
+        const T f = fu[(int64_t)d * M + j];
         i0s[(int64_t)d * M + pos] = i0u[(int64_t)d * M + j];
-        fs[(int64_t)d * M + pos] = fu[(int64_t)d * M + j];
+        fs[(int64_t)d * M + pos] = f;
+        T *row = kw + ((int64_t)d * M + pos) * w;
+        for (int k = 0; k < w; ++k) row[k] = es_eval<T>(f + (T)k, beta, c4);
     }
     perm[pos] = (int)j;
 }
@@ -242,83 +278,55 @@ __global__ void k_load_strengths(int64_t M, int ntrans, int tpol, int dim,
     }
 }
 
-// --- 2-D spread -------------------------------------------------------------------------------
-// grid (ntile_x, ntile_y, ceil(ntrans / TC)); 256 threads = 16 source-groups of 16 lanes.
-// Lane g of a group owns footprint column g; the group walks the w footprint rows.
-template <typename T, int TC>
+// --- 2-D spread (gather) ------------------------------------------------------------------------
+// One wave owns one 8x8-cell block of A, aligned with the 8x8 source bins; lane = cell.  A source
+// touches cell c iff 0 <= c - i0 < w in both dimensions, so only the bins
+// (8 b - w + 1) >> 3 .. b of each dimension can reach block b (2x2 bins for w <= 9, 3x3 up to 16).
+// The wave walks those sources together: footprint origin and strengths are wave-uniform (scalar
+// loads), each lane looks up its own pair of tabulated kernel weights (0 when the source misses
+// the cell) and accumulates TCH transforms in registers.  grid (ceil(nbx / 4), nby, chunks).
+template <typename T, int TCH>
 __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
-    int64_t M, const int *__restrict__ i0s, const T *__restrict__ fs,
-    const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans,
+    int64_t M, const int *__restrict__ i0s, const T *__restrict__ kw,
+    const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans, int tbegin,
     const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid, int nax,
-    int nay, int ntx, int nty, int w, T beta, T c4) {
-    __shared__ T acc[2 * TC * TILE * TILE];  // [re|im][q][row][col]
-    const int tid = threadIdx.x;
-    const int bx = blockIdx.x, by = blockIdx.y;
-    const int t0 = blockIdx.z * TC;
-    const int x0 = bx * TILE, y0 = by * TILE;
-    for (int i = tid; i < 2 * TC * TILE * TILE; i += SPREAD_THREADS) acc[i] = T(0);
-    __syncthreads();
-
-    const int g = tid & (GROUP - 1);       // lane within group = footprint column
-    const int grp = tid / GROUP;           // group within workgroup
-    const int lane_base = (tid & 63) & ~(GROUP - 1);
+    int nay, int nbx, int w) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bx = blockIdx.x * 4 + wave, by = blockIdx.y;
+    if (bx >= nbx) return;  // wave-uniform
+    const int tbase = tbegin + blockIdx.z * TCH;  // the launcher only issues whole chunks
+    const int cx = (bx << BINLOG) + (lane & 7), cy = (by << BINLOG) + (lane >> 3);
     const int *i0x = i0s, *i0y = i0s + M;
-    const T *fx = fs, *fy = fs + M;
-
-    for (int dy = -1; dy <= 1; ++dy) {
-        int nby = by + dy;
-        if (nby < 0 || nby >= nty) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-            int nbx = bx + dx;
-            if (nbx < 0 || nbx >= ntx) continue;
-            const int b = nby * ntx + nbx;
-            const int sb = bin_start[b], se = bin_start[b + 1];
-            for (int s = sb + grp; s < se; s += SPREAD_THREADS / GROUP) {
-                const int relx = i0x[s] - x0, rely = i0y[s] - y0;
-                if (relx + w <= 0 || relx >= TILE || rely + w <= 0 || rely >= TILE) continue;
-                const T kx = g < w ? es_eval<T>(fx[s] + (T)g, beta, c4) : T(0);
-                const T kyv = g < w ? es_eval<T>(fy[s] + (T)g, beta, c4) : T(0);
-                T ky[MAX_W];
+    const T *kwx = kw, *kwy = kw + M * w;
+    T ar[TCH], ai[TCH];
 #pragma unroll
-                for (int r = 0; r < MAX_W; ++r) ky[r] = __shfl(kyv, lane_base + r, 64);
-                const int col = relx + g;
-                const bool colok = g < w && col >= 0 && col < TILE;
+    for (int q = 0; q < TCH; ++q) ar[q] = ai[q] = T(0);
+    const int bxl = max((bx << BINLOG) - w + 1, 0) >> BINLOG;
+    const int byl = max((by << BINLOG) - w + 1, 0) >> BINLOG;
+    for (int yb = byl; yb <= by; ++yb) {
+        // bins bxl .. bx of one bin row are contiguous in the sorted order
+        const int s0 = bin_start[yb * nbx + bxl], s1 = bin_start[yb * nbx + bx + 1];
+        for (int s = s0; s < s1; ++s) {
+            const int dx = cx - i0x[s], dy = cy - i0y[s];
+            T wt = T(0);
+            if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
+                wt = kwx[(int64_t)s * w + dx] * kwy[(int64_t)s * w + dy];
+            // whole chunks only: the TCH strength loads are one unconditional scalar burst
+            const cplx<T> *c = cs + (int64_t)s * ntrans + tbase;
 #pragma unroll
-                for (int q = 0; q < TC; ++q) {
-                    if (t0 + q >= ntrans) break;
-                    const cplx<T> cv = cs[(int64_t)s * ntrans + t0 + q];
-                    const T vr = cv.re * kx, vi = cv.im * kx;
-                    T *are = acc + q * TILE * TILE;
-                    T *aim = acc + (TC + q) * TILE * TILE;
-#pragma unroll
-                    for (int r = 0; r < MAX_W; ++r) {
-                        const int row = rely + r;
-                        if (r < w && colok && row >= 0 && row < TILE) {
-                            atomicAdd(&are[row * TILE + col], vr * ky[r]);
-                            atomicAdd(&aim[row * TILE + col], vi * ky[r]);
-                        }
-                    }
-                }
+            for (int q = 0; q < TCH; ++q) {
+                const cplx<T> cv = c[q];
+                ar[q] += cv.re * wt;
+                ai[q] += cv.im * wt;
             }
         }
     }
-    __syncthreads();
-
-    // write-out: every cell of the tile once, deconvolved; a wave covers 2 rows x 512 B.
-    const int col = tid & (TILE - 1);
-    const int gx = x0 + col;
-    const T dxv = decx[gx];
-    for (int q = 0; q < TC; ++q) {
-        if (t0 + q >= ntrans) break;
-        const T *are = acc + q * TILE * TILE;
-        const T *aim = acc + (TC + q) * TILE * TILE;
-        cplx<T> *plane = grid + (int64_t)(t0 + q) * nay * nax;
-        for (int row = tid / TILE; row < TILE; row += SPREAD_THREADS / TILE) {
-            const int gy = y0 + row;
-            const T f = dxv * decy[gy];
-            plane[(int64_t)gy * nax + gx] = {are[row * TILE + col] * f, aim[row * TILE + col] * f};
-        }
-    }
+    const T f = decx[cx] * decy[cy];
+    const int64_t plane = (int64_t)nay * nax;
+    cplx<T> *o = grid + (int64_t)tbase * plane + (int64_t)cy * nax + cx;
+#pragma unroll
+    for (int q = 0; q < TCH; ++q) o[q * plane] = {ar[q] * f, ai[q] * f};
 }
 
 // --- pruned row FFT -----------------------------------------------------------------------------
@@ -334,8 +342,13 @@ struct RowFftArgs {
     int npass, radix_log[4];
     int qp;              // padded LDS row length (elements)
     int jchunk;          // outputs handled per blockIdx.y (<= tpr * FFT_NACC)
+    int lds_row;         // LDS elements between the rows of a workgroup (odd: bank spread)
+    int colmode;         // 1: rows are COLUMNS of the input planes (fused transpose)
     int64_t nrows;       // rows over all transforms
-    int64_t in_pitch;    // elements between consecutive input rows
+    int64_t rpp;         // rows per input plane
+    int64_t in_plane;    // elements between input planes
+    int64_t in_row;      // elements between consecutive rows of a plane
+    int64_t in_elem;     // elements between consecutive inputs of a row
     int64_t out_pitch;   // elements between consecutive output rows
 };
 
@@ -429,10 +442,10 @@ __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restric
     cplx<T> *smem = reinterpret_cast<cplx<T> *>(fft_smem);
     const int tid = threadIdx.x;
     const int r = tid / a.tpr, lane = tid % a.tpr;
-    const int64_t row = (int64_t)blockIdx.x * a.rpw + r;
+    const int64_t row0 = (int64_t)blockIdx.x * a.rpw;
+    const int64_t row = row0 + r;
     const bool valid = row < a.nrows;
-    cplx<T> *rb = smem + (int64_t)r * a.qp;
-    const cplx<T> *rin = in + (valid ? row : 0) * a.in_pitch;
+    cplx<T> *rb = smem + (int64_t)r * a.lds_row;
     const int Q = a.Q, half_n = a.n_out / 2;
     const int jbeg = blockIdx.y * a.jchunk;
     const int jend = min(a.n_out, jbeg + a.jchunk);
@@ -443,9 +456,24 @@ __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restric
     for (int i = 0; i < FFT_NACC; ++i) acc[i] = {T(0), T(0)};
 
     for (int p = 0; p < a.P; ++p) {
-        for (int q = lane; q < Q; q += a.tpr) {
-            const int ia = a.P * q + p;
-            rb[fft_pidx(q)] = (valid && ia < a.n_in) ? rin[ia] : cplx<T>{T(0), T(0)};
+        if (a.colmode) {
+            // rows of this workgroup are adjacent columns: lanes run over the rows first so that
+            // each input index reads rpw * 16 contiguous bytes (rpw is a power of two <= 16)
+            const int rr = tid & (a.rpw - 1), qstep = FFT_THREADS / a.rpw;
+            const int64_t rw = row0 + rr;
+            const bool ok = rw < a.nrows;
+            const cplx<T> *cin = in + (ok ? (rw / a.rpp) * a.in_plane + (rw % a.rpp) * a.in_row : 0);
+            cplx<T> *crb = smem + (int64_t)rr * a.lds_row;
+            for (int q = tid / a.rpw; q < Q; q += qstep) {
+                const int ia = a.P * q + p;
+                crb[fft_pidx(q)] = (ok && ia < a.n_in) ? cin[(int64_t)ia * a.in_elem] : cplx<T>{T(0), T(0)};
+            }
+        } else {
+            const cplx<T> *rin = in + (valid ? (row / a.rpp) * a.in_plane + (row % a.rpp) * a.in_row : 0);
+            for (int q = lane; q < Q; q += a.tpr) {
+                const int ia = a.P * q + p;
+                rb[fft_pidx(q)] = (valid && ia < a.n_in) ? rin[(int64_t)ia * a.in_elem] : cplx<T>{T(0), T(0)};
+            }
         }
         __syncthreads();
         int logL = a.logQ;
@@ -642,7 +670,7 @@ class Nufft3 {
     int64_t geom_serial = 0;  // bumps whenever the source->cell mapping changes
 
     // device state
-    DevBuf i0u, fu, tile_of, counts, cursor, bin_start, i0s, fs, perm, oob;
+    DevBuf i0u, fu, tile_of, counts, cursor, bin_start, i0s, fs, perm, oob, kw, scan_tot, scan_off;
     DevBuf dec[3], tw[3];
     DevBuf buf0, buf1;  // ping-pong: A -> (x-pass) B -> (transpose) Bt -> (y-pass) Ct
     DevBuf strengths;   // [M][ntrans] sorted order
@@ -667,7 +695,7 @@ class Nufft3 {
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
             set_dim_geom(geo.d[d], sigma, ker.w, scale_max);
-            geo.ntile[d] = geo.d[d].na / TILE;
+            geo.nbin[d] = geo.d[d].na >> BINLOG;
         }
         for (int d = 0; d < dim; ++d) {
             const DimGeom &g = geo.d[d];
@@ -689,22 +717,25 @@ class Nufft3 {
         }
     }
 
-    // Bin-sort the sources for the current geometry (device pointers, length M each).
+    // Bin-sort the sources for the current geometry (device pointers, length M each) and
+    // tabulate their kernel weights.
     void set_sources(int64_t M_, const T *x, const T *y, const T *z) {
         M = M_;
-        const int nt = geo.ntiles();
-        i0u.reserve(sizeof(int) * 3 * std::max<int64_t>(M, 1));
-        fu.reserve(sizeof(T) * 3 * std::max<int64_t>(M, 1));
-        i0s.reserve(sizeof(int) * 3 * std::max<int64_t>(M, 1));
-        fs.reserve(sizeof(T) * 3 * std::max<int64_t>(M, 1));
-        tile_of.reserve(sizeof(int) * std::max<int64_t>(M, 1));
-        perm.reserve(sizeof(int) * std::max<int64_t>(M, 1));
-        counts.reserve(sizeof(int) * (nt + 1));
-        cursor.reserve(sizeof(int) * (nt + 1));
-        bin_start.reserve(sizeof(int) * (nt + 1));
+        const int nb = geo.nbins();
+        const int64_t M1 = std::max<int64_t>(M, 1);
+        i0u.reserve(sizeof(int) * 3 * M1);
+        fu.reserve(sizeof(T) * 3 * M1);
+        i0s.reserve(sizeof(int) * 3 * M1);
+        fs.reserve(sizeof(T) * 3 * M1);
+        kw.reserve(sizeof(T) * 3 * M1 * ker.w);
+        tile_of.reserve(sizeof(int) * M1);
+        perm.reserve(sizeof(int) * M1);
+        counts.reserve(sizeof(int) * (nb + 1));
+        cursor.reserve(sizeof(int) * (nb + 1));
+        bin_start.reserve(sizeof(int) * (nb + 1));
         oob.reserve(sizeof(int));
-        FV_HIP(hipMemsetAsync(counts.p, 0, sizeof(int) * (nt + 1), stream));
-        FV_HIP(hipMemsetAsync(cursor.p, 0, sizeof(int) * (nt + 1), stream));
+        FV_HIP(hipMemsetAsync(counts.p, 0, sizeof(int) * (nb + 1), stream));
+        FV_HIP(hipMemsetAsync(cursor.p, 0, sizeof(int) * (nb + 1), stream));
         FV_HIP(hipMemsetAsync(oob.p, 0, sizeof(int), stream));
         BinArgs a{};
         a.w = ker.w;
@@ -713,19 +744,32 @@ class Nufft3 {
             a.xc[d] = geo.d[d].xc;
             a.invh[d] = 1.0 / geo.d[d].h;
             a.na[d] = d < dim ? geo.d[d].na : 1;
-            a.ntile[d] = geo.ntile[d];
+            a.nbin[d] = geo.nbin[d];
         }
         if (M > 0) {
             hipLaunchKernelGGL(k_bin_count<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, x, y,
                                z, a, i0u.as<int>(), fu.as<T>(), tile_of.as<int>(),
                                counts.as<int>(), oob.as<int>());
         }
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, counts.as<int>(),
-                           bin_start.as<int>(), nt);
+        if (nb <= 4096) {
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, counts.as<int>(),
+                               bin_start.as<int>(), nb);
+        } else {
+            const int nblk = (int)cdiv(nb, 1024);
+            scan_tot.reserve(sizeof(int) * (nblk + 1));
+            scan_off.reserve(sizeof(int) * (nblk + 1));
+            hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(1024), 0, stream, counts.as<int>(),
+                               bin_start.as<int>(), scan_tot.as<int>(), nb);
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
+                               scan_tot.as<int>(), scan_off.as<int>(), nblk);
+            hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(1024), 0, stream, bin_start.as<int>(),
+                               scan_off.as<int>(), nb);
+        }
         if (M > 0) {
             hipLaunchKernelGGL(k_bin_scatter<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, dim,
                                i0u.as<int>(), fu.as<T>(), tile_of.as<int>(), bin_start.as<int>(),
-                               cursor.as<int>(), i0s.as<int>(), fs.as<T>(), perm.as<int>());
+                               cursor.as<int>(), i0s.as<int>(), fs.as<T>(), perm.as<int>(),
+                               kw.as<T>(), ker.w, (T)ker.beta, (T)ker.c);
         }
     }
 
@@ -761,6 +805,8 @@ class Nufft3 {
     }
 
     void spread(int ntrans);
+    template <int TCH>
+    int launch_spread(int ntrans, int tbegin);
     void fft(int ntrans);
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
     // index list / flip flags of length N, per-group scale (device, nfg doubles).
@@ -771,25 +817,49 @@ class Nufft3 {
 
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
-                int64_t nrows, int64_t in_pitch);
+                int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row, int64_t in_elem);
+    cplx<T> *grid_out = nullptr;  // where the last fft() left Ct
 };
+
+template <typename T>
+template <int TCH>
+int Nufft3<T>::launch_spread(int ntrans, int tbegin) {
+    const int nchunk = (ntrans - tbegin) / TCH;
+    if (nchunk == 0) return tbegin;
+    const DimGeom &x = geo.d[0], &y = geo.d[1];
+    dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)nchunk);
+    hipLaunchKernelGGL((k_spread2d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, M, i0s.as<int>(),
+                       kw.as<T>(), bin_start.as<int>(), strengths.as<cplx<T>>(), ntrans, tbegin,
+                       dec[0].as<T>(), dec[1].as<T>(), buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0],
+                       ker.w);
+    return tbegin + nchunk * TCH;
+}
 
 template <typename T>
 void Nufft3<T>::spread(int ntrans) {
     FV_REQUIRE(dim == 2, "3-D spread not built yet");
     const DimGeom &x = geo.d[0], &y = geo.d[1];
-    buf0.reserve(sizeof(cplx<T>) * std::max((int64_t)x.na * y.na, (int64_t)x.no * y.na) * ntrans);
-    constexpr int TC = sizeof(T) == 8 ? 4 : 8;  // 64 KiB of LDS accumulators per workgroup
-    dim3 g(geo.ntile[0], geo.ntile[1], (unsigned)cdiv(ntrans, TC));
-    hipLaunchKernelGGL((k_spread2d<T, TC>), g, dim3(SPREAD_THREADS), 0, stream, M, i0s.as<int>(),
-                       fs.as<T>(), bin_start.as<int>(), strengths.as<cplx<T>>(), ntrans,
-                       dec[0].as<T>(), dec[1].as<T>(), buf0.as<cplx<T>>(), x.na, y.na,
-                       geo.ntile[0], geo.ntile[1], ker.w, (T)ker.beta, (T)ker.c);
+    buf0.reserve(sizeof(cplx<T>) * std::max({(int64_t)x.na * y.na, (int64_t)x.no * y.na, (int64_t)x.no * y.no}) * ntrans);
+    // whole chunks of 16 transforms per thread, then the binary remainder (<= 4 more launches)
+    int t = launch_spread<16>(ntrans, 0);
+    t = launch_spread<8>(ntrans, t);
+    t = launch_spread<4>(ntrans, t);
+    t = launch_spread<2>(ntrans, t);
+    launch_spread<1>(ntrans, t);
 }
 
+// Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision).
+inline void rowfft_shape(const DimGeom &g, int &tpr, int &rpw) {
+    tpr = 16;
+    while (tpr < FFT_THREADS && (tpr < g.Q / FV_FFT_TPR_DIV || (int64_t)tpr * FFT_NACC < g.no)) tpr *= 2;
+    rpw = FFT_THREADS / tpr;
+}
+
+// rows = nplanes * rpp; element ia of row (plane, k) sits at plane*in_plane + k*in_row + ia*in_elem.
 template <typename T>
 void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
-                       int64_t nrows, int64_t in_pitch) {
+                       int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row,
+                       int64_t in_elem) {
     static const int plans[7][4] = {{3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0}, {3, 3, 3, 0},
                                     {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 6 .. 12
     RowFftArgs a{};
@@ -806,23 +876,24 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         if (a.radix_log[s]) ++a.npass;
     }
     a.qp = fft_pidx(g.Q);
-    // threads per row: enough for one radix-16 item each and for <= FFT_NACC outputs each
-    int tpr = 16;
-    while (tpr < FFT_THREADS && (tpr < g.Q / FV_FFT_TPR_DIV || (int64_t)tpr * FFT_NACC < g.no)) tpr *= 2;
-    a.tpr = tpr;
-    a.rpw = FFT_THREADS / tpr;
-    a.jchunk = std::min(g.no, tpr * FFT_NACC);  // more outputs than that: extra chunks (grid.y)
-    a.nrows = nrows;
-    a.in_pitch = in_pitch;
+    a.lds_row = a.qp | 1;
+    rowfft_shape(g, a.tpr, a.rpw);
+    a.jchunk = std::min(g.no, a.tpr * FFT_NACC);  // more outputs than that: extra chunks (grid.y)
+    a.colmode = in_elem != 1;
+    a.nrows = nplanes * rpp;
+    a.rpp = rpp;
+    a.in_plane = in_plane;
+    a.in_row = in_row;
+    a.in_elem = in_elem;
     a.out_pitch = g.no;
-    const size_t smem = sizeof(cplx<T>) * (size_t)a.qp * a.rpw;
+    const size_t smem = sizeof(cplx<T>) * (size_t)a.lds_row * a.rpw;
     static bool attr_set = false;
     if (!attr_set) {
         FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid((unsigned)cdiv(nrows, a.rpw), (unsigned)cdiv(g.no, a.jchunk));
+    dim3 grid((unsigned)cdiv(a.nrows, a.rpw), (unsigned)cdiv(g.no, a.jchunk));
     hipLaunchKernelGGL(k_rowfft<T>, grid, dim3(FFT_THREADS), smem, stream, in, out, twd, a);
 }
 
@@ -832,12 +903,21 @@ void Nufft3<T>::fft(int ntrans) {
     buf1.reserve(sizeof(cplx<T>) * std::max((int64_t)y.na * x.no, (int64_t)x.no * y.no) * ntrans);
     cplx<T> *A = buf0.as<cplx<T>>(), *Bm = buf1.as<cplx<T>>();
     // x-pass: A [t][na_y][na_x] -> B [t][na_y][no_x]
-    rowfft(A, Bm, x, tw[0].as<cplx<T>>(), (int64_t)ntrans * y.na, x.na);
-    // transpose: B -> Bt [t][no_x][na_y]   (A is dead, reuse its storage)
-    dim3 tg((unsigned)cdiv(x.no, 32), (unsigned)cdiv(y.na, 32), (unsigned)ntrans);
-    hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, Bm, A, y.na, x.no);
-    // y-pass: Bt rows -> Ct [t][no_x][no_y]
-    rowfft(A, Bm, y, tw[1].as<cplx<T>>(), (int64_t)ntrans * x.no, y.na);
+    rowfft(A, Bm, x, tw[0].as<cplx<T>>(), ntrans, y.na, (int64_t)y.na * x.na, x.na, 1);
+    int tpr, rpw;
+    rowfft_shape(y, tpr, rpw);
+    if (rpw >= 4) {
+        // short columns: the y-pass reads rpw adjacent columns of B at once (64-128 B segments),
+        // which fuses the transpose.  B -> Ct [t][no_x][no_y] lands in A's storage.
+        rowfft(Bm, A, y, tw[1].as<cplx<T>>(), ntrans, x.no, (int64_t)y.na * x.no, 1, x.no);
+        grid_out = A;
+    } else {
+        // long columns: explicit tile transpose B -> Bt [t][no_x][na_y], then contiguous rows
+        dim3 tg((unsigned)cdiv(x.no, 32), (unsigned)cdiv(y.na, 32), (unsigned)ntrans);
+        hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, Bm, A, y.na, x.no);
+        rowfft(A, Bm, y, tw[1].as<cplx<T>>(), ntrans, x.no, (int64_t)x.no * y.na, y.na, 1);
+        grid_out = Bm;
+    }
 }
 
 template <typename T>
@@ -866,7 +946,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.accumulate = accumulate ? 1 : 0;
     const int64_t items = N * nfg;
     hipLaunchKernelGGL(k_interp2d<T>, dim3(cdiv(items, INTERP_THREADS / GROUP)),
-                       dim3(INTERP_THREADS), 0, stream, buf1.as<cplx<T>>(), N, bty, btx, bl_idx,
+                       dim3(INTERP_THREADS), 0, stream, grid_out, N, bty, btx, bl_idx,
                        flip, scale_dev, a, ker, out);
 }
 
