@@ -25,6 +25,9 @@
 
 #include "fv_eskernel.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace fv {
 
 constexpr int TILE = 32;       // buffer-A extents are rounded up to a multiple of this
@@ -127,12 +130,13 @@ struct BinArgs {
 // formed in fp64 and split into (int cell, T offset) so that fp32 runs keep sub-cell accuracy on
 // multi-thousand-cell grids.
 template <typename T>
-__global__ void k_bin_count(int64_t M, const T *__restrict__ x, const T *__restrict__ y,
-                            const T *__restrict__ z, BinArgs a, int *__restrict__ i0u,
-                            T *__restrict__ fu, int *__restrict__ tile_of, int *__restrict__ counts,
-                            int *__restrict__ n_oob) {
+__global__ void k_bin_count(int64_t M, const int *__restrict__ Mp, const T *__restrict__ x,
+                            const T *__restrict__ y, const T *__restrict__ z, BinArgs a,
+                            int *__restrict__ i0u, T *__restrict__ fu, int *__restrict__ tile_of,
+                            int *__restrict__ counts, int *__restrict__ n_oob) {
+    // M = capacity (array stride, launch bound); *Mp = live count when it is only known on device
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
+    if (j >= (Mp ? (int64_t)*Mp : M)) return;
     const T *src[3] = {x, y, z};
     int tl[3] = {0, 0, 0};
     bool oob = false;
@@ -209,13 +213,13 @@ __global__ void k_scan_add(int *__restrict__ out, const int *__restrict__ block_
 // Scatter into bin order and tabulate each source's kernel weights:
 //   kw[(d * M + pos) * w + k] = psi(f_d + k),  k < w.
 template <typename T>
-__global__ void k_bin_scatter(int64_t M, int dim, const int *__restrict__ i0u,
-                              const T *__restrict__ fu, const int *__restrict__ tile_of,
-                              const int *__restrict__ bin_start, int *__restrict__ cursor,
-                              int *__restrict__ i0s, T *__restrict__ fs, int *__restrict__ perm,
-                              T *__restrict__ kw, int w, T beta, T c4) {
+__global__ void k_bin_scatter(int64_t M, const int *__restrict__ Mp, int dim,
+                              const int *__restrict__ i0u, const T *__restrict__ fu,
+                              const int *__restrict__ tile_of, const int *__restrict__ bin_start,
+                              int *__restrict__ cursor, int *__restrict__ i0s, T *__restrict__ fs,
+                              int *__restrict__ perm, T *__restrict__ kw, int w, T beta, T c4) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
+    if (j >= (Mp ? (int64_t)*Mp : M)) return;
     int t = tile_of[j];
     int pos = bin_start[t] + atomicAdd(&cursor[t], 1);
     for (int d = 0; d < dim; ++d) {
@@ -251,14 +255,14 @@ __global__ void k_twiddle_table(int n2, cplx<T> *__restrict__ tw) {
 // Gather user-order strengths (ntrans, M) into sorted order [M][ntrans] and apply the type-3
 // pre-phase exp(i s_c(g) . x'_j); x'_j is rebuilt from the sorted grid coordinates.
 template <typename T>
-__global__ void k_load_strengths(int64_t M, int ntrans, int tpol, int dim,
+__global__ void k_load_strengths(int64_t M, const int *__restrict__ Mp, int ntrans, int tpol, int dim,
                                  const cplx<T> *__restrict__ cin, const int *__restrict__ perm,
                                  const int *__restrict__ i0s, const T *__restrict__ fs, double h0,
                                  double h1, double h2, int na0, int na1, int na2, double btc0,
                                  double btc1, double btc2, const double *__restrict__ scale,
                                  cplx<T> *__restrict__ cs) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= M) return;
+    if (p >= (Mp ? (int64_t)*Mp : M)) return;
     const double h[3] = {h0, h1, h2}, btc[3] = {btc0, btc1, btc2};
     const int na[3] = {na0, na1, na2};
     double dot = 0.0;  // btc . x'
@@ -433,7 +437,7 @@ __device__ inline int fft_digit_pos(int k, const RowFftArgs &a) {
     return pos;
 }
 
-template <typename T>
+template <typename T, bool DIRECT>
 __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restrict__ in,
                                                          cplx<T> *__restrict__ out,
                                                          const cplx<T> *__restrict__ tw,
@@ -451,9 +455,10 @@ __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restric
     const int jend = min(a.n_out, jbeg + a.jchunk);
     const int jfirst = jbeg + lane;
 
-    cplx<T> acc[FFT_NACC];  // this thread's outputs j = jfirst + i * tpr
+    // this thread's outputs j = jfirst + i * tpr (P > 1 only; P == 1 reads them straight from LDS)
+    cplx<T> acc[DIRECT ? 1 : FFT_NACC];
 #pragma unroll
-    for (int i = 0; i < FFT_NACC; ++i) acc[i] = {T(0), T(0)};
+    for (int i = 0; i < (DIRECT ? 1 : FFT_NACC); ++i) acc[i] = {T(0), T(0)};
 
     for (int p = 0; p < a.P; ++p) {
         if (a.colmode) {
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restric
             __syncthreads();
             logL = logLR;
         }
+        if constexpr (DIRECT) break;  // single residue: the write-out below reads rb directly
         // acc[j] += tw[p l] F_p[l mod Q]; the twiddle advances by a fixed factor per step
         cplx<T> t = {T(1), T(0)}, step = {T(1), T(0)};
         if (p && jfirst < jend) {
@@ -501,18 +507,20 @@ __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restric
             t = tw[ti];
             step = tw[(int)(((int64_t)p * a.tpr) % a.n2)];
         }
+        if constexpr (!DIRECT) {
 #pragma unroll
-        for (int i = 0; i < FFT_NACC; ++i) {
-            const int j = jfirst + i * a.tpr;
-            if (j < jend) {
-                const int lq = (j - half_n) & (Q - 1);
-                cplx<T> v = rb[fft_pidx(fft_digit_pos(lq, a))];
-                if (p) {
-                    v = cmul(v, t);
-                    t = cmul(t, step);
+            for (int i = 0; i < FFT_NACC; ++i) {
+                const int j = jfirst + i * a.tpr;
+                if (j < jend) {
+                    const int lq = (j - half_n) & (Q - 1);
+                    cplx<T> v = rb[fft_pidx(fft_digit_pos(lq, a))];
+                    if (p) {
+                        v = cmul(v, t);
+                        t = cmul(t, step);
+                    }
+                    acc[i].re += v.re;
+                    acc[i].im += v.im;
                 }
-                acc[i].re += v.re;
-                acc[i].im += v.im;
             }
         }
         if (p + 1 < a.P) __syncthreads();  // rb is reloaded for the next residue
@@ -526,13 +534,130 @@ __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restric
     int si = (int)((-(int64_t)(a.n_in / 2) * a.tpr) % a.n2);
     if (si < 0) si += a.n2;
     const cplx<T> step = tw[si];
-#pragma unroll
-    for (int i = 0; i < FFT_NACC; ++i) {
-        const int j = jfirst + i * a.tpr;
-        if (j < jend) {
-            rout[j] = cmul(acc[i], t);
+    if constexpr (DIRECT) {
+        for (int j = jfirst; j < jend; j += a.tpr) {
+            const int lq = (j - half_n) & (Q - 1);
+            rout[j] = cmul(rb[fft_pidx(fft_digit_pos(lq, a))], t);
             t = cmul(t, step);
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < FFT_NACC; ++i) {
+            const int j = jfirst + i * a.tpr;
+            if (j < jend) {
+                rout[j] = cmul(acc[i], t);
+                t = cmul(t, step);
+            }
+        }
+    }
+}
+
+// --- pruned row FFT, whole row resident in LDS ---------------------------------------------------
+// Same transform as k_rowfft, for rows whose n2 = P * Q elements fit the CU's LDS (n2 <~ 9000
+// in fp64).  The radix-P stage is done as decimation in FREQUENCY while loading:
+//     sub_p[q] = sum_k in[q + k Q] tw[(q + k Q) p]      (inputs beyond n_in are zero, so k < ~P/2)
+// after which X[P k' + p] = FFT_Q(sub_p)[k'].  All P sub-arrays then go through the radix-16/8
+// DIF passes together (n2 / R butterfly groups per pass over up to 1024 threads), and every kept
+// output is read straight from LDS: no accumulators, one contiguous store per output.
+struct RowFftFullArgs {
+    int n_in, n_out, n2, P, Q, logQ, tpr, rpw;
+    int npass, radix_log[4];
+    int sa;              // LDS elements between the P sub-arrays of a row
+    int lds_row;         // LDS elements between rows of a workgroup
+    int colmode;
+    int64_t nrows, rpp, in_plane, in_row, in_elem, out_pitch;
+};
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_rowfft_full(const cplx<T> *__restrict__ in,
+                                                       cplx<T> *__restrict__ out,
+                                                       const cplx<T> *__restrict__ tw,
+                                                       RowFftFullArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
+    cplx<T> *smem = reinterpret_cast<cplx<T> *>(fft_smem);
+    const int tid = threadIdx.x;
+    const int Q = a.Q, n2 = a.n2;
+    const int64_t row0 = (int64_t)blockIdx.x * a.rpw;
+
+    // ---- load + radix-P decimation in frequency -------------------------------------------------
+    {
+        // colmode: lanes run over the rpw adjacent columns first (rpw * 16 contiguous bytes)
+        const int rr = a.colmode ? (tid & (a.rpw - 1)) : tid / a.tpr;
+        const int e0 = a.colmode ? tid / a.rpw : tid % a.tpr;
+        const int64_t rw = row0 + rr;
+        const bool ok = rw < a.nrows;
+        const cplx<T> *rin = in + (ok ? (rw / a.rpp) * a.in_plane + (rw % a.rpp) * a.in_row : 0);
+        cplx<T> *rb = smem + (int64_t)rr * a.lds_row;
+        for (int e = e0; e < n2; e += a.tpr) {
+            const int p = e >> a.logQ, q = e & (Q - 1);
+            T sr = T(0), si = T(0);
+            if (ok) {
+                int r = 0;  // (k p) mod P
+                for (int ia = q; ia < a.n_in; ia += Q) {
+                    const cplx<T> x = rin[(int64_t)ia * a.in_elem];
+                    if (p) {
+                        int ti = q * p + Q * r;  // ((q + k Q) p) mod n2
+                        if (ti >= n2) ti -= n2;
+                        const cplx<T> t = tw[ti];
+                        sr += x.re * t.re - x.im * t.im;
+                        si += x.re * t.im + x.im * t.re;
+                        r += p;
+                        if (r >= a.P) r -= a.P;
+                    } else {
+                        sr += x.re;
+                        si += x.im;
+                    }
+                }
+            }
+            rb[p * a.sa + fft_pidx(q)] = {sr, si};
+        }
+    }
+    __syncthreads();
+
+    // ---- power-of-two passes over all P sub-arrays ----------------------------------------------
+    const int r = tid / a.tpr, lane = tid % a.tpr;
+    cplx<T> *rb = smem + (int64_t)r * a.lds_row;
+    int logL = a.logQ;
+    for (int s = 0; s < a.npass; ++s) {
+        const int rl = a.radix_log[s];
+        const int logLR = logL - rl;
+        const int ipp = a.logQ - rl;          // log2(items per sub-array)
+        const int items = n2 >> rl;
+        const int twmul = a.P << (a.logQ - logL);  // n2 / L
+        for (int u = lane; u < items; u += a.tpr) {
+            cplx<T> *sb = rb + (u >> ipp) * a.sa;
+            const int ul = u & ((1 << ipp) - 1);
+            if (rl == 4) fft_pass_item<T, 4>(sb, ul, logLR, tw, twmul);
+            else if (rl == 3) fft_pass_item<T, 3>(sb, ul, logLR, tw, twmul);
+            else if (rl == 2) fft_pass_item<T, 2>(sb, ul, logLR, tw, twmul);
+            else fft_pass_item<T, 1>(sb, ul, logLR, tw, twmul);
+        }
+        __syncthreads();
+        logL = logLR;
+    }
+
+    // ---- kept outputs: X[l], l = j - n_out/2, times exp(-2 pi i (n_in/2) l / n2) ------------------
+    const int64_t row = row0 + r;
+    if (row >= a.nrows || lane >= a.n_out) return;
+    const int half_n = a.n_out / 2;
+    cplx<T> *rout = out + row * a.out_pitch;
+    int ti = (int)((-(int64_t)(a.n_in / 2) * (lane - half_n)) % n2);
+    if (ti < 0) ti += n2;
+    cplx<T> t = tw[ti];
+    int si2 = (int)((-(int64_t)(a.n_in / 2) * a.tpr) % n2);
+    if (si2 < 0) si2 += n2;
+    const cplx<T> step = tw[si2];
+    RowFftArgs da{};  // digit-position helper reuses the DIT kernel's descriptor fields
+    da.logQ = a.logQ;
+    da.npass = a.npass;
+    for (int k = 0; k < 4; ++k) da.radix_log[k] = a.radix_log[k];
+    for (int j = lane; j < a.n_out; j += a.tpr) {
+        int lm = j - half_n;
+        if (lm < 0) lm += n2;
+        const int kq = lm / a.P, p = lm - kq * a.P;
+        const cplx<T> v = rb[p * a.sa + fft_pidx(fft_digit_pos(kq, da))];
+        rout[j] = cmul(v, t);
+        t = cmul(t, step);
     }
 }
 
@@ -670,7 +795,9 @@ class Nufft3 {
     int64_t geom_serial = 0;  // bumps whenever the source->cell mapping changes
 
     // device state
-    DevBuf i0u, fu, tile_of, counts, cursor, bin_start, i0s, fs, perm, oob, kw, scan_tot, scan_off;
+    DevBuf i0u, fu, tile_of, binmeta, bin_start, i0s, fs, perm, kw, scan_tot, scan_off;
+    const int *Mp = nullptr;   // device-side live source count (optional)
+    int *oob_ptr = nullptr;
     DevBuf dec[3], tw[3];
     DevBuf buf0, buf1;  // ping-pong: A -> (x-pass) B -> (transpose) Bt -> (y-pass) Ct
     DevBuf strengths;   // [M][ntrans] sorted order
@@ -719,8 +846,11 @@ class Nufft3 {
 
     // Bin-sort the sources for the current geometry (device pointers, length M each) and
     // tabulate their kernel weights.
-    void set_sources(int64_t M_, const T *x, const T *y, const T *z) {
+    // M_ is the live count, or -- when Mdev is given -- the capacity, with the live count read
+    // from device memory by the kernels (no host round trip).
+    void set_sources(int64_t M_, const T *x, const T *y, const T *z, const int *Mdev = nullptr) {
         M = M_;
+        Mp = Mdev;
         const int nb = geo.nbins();
         const int64_t M1 = std::max<int64_t>(M, 1);
         i0u.reserve(sizeof(int) * 3 * M1);
@@ -730,13 +860,11 @@ class Nufft3 {
         kw.reserve(sizeof(T) * 3 * M1 * ker.w);
         tile_of.reserve(sizeof(int) * M1);
         perm.reserve(sizeof(int) * M1);
-        counts.reserve(sizeof(int) * (nb + 1));
-        cursor.reserve(sizeof(int) * (nb + 1));
         bin_start.reserve(sizeof(int) * (nb + 1));
-        oob.reserve(sizeof(int));
-        FV_HIP(hipMemsetAsync(counts.p, 0, sizeof(int) * (nb + 1), stream));
-        FV_HIP(hipMemsetAsync(cursor.p, 0, sizeof(int) * (nb + 1), stream));
-        FV_HIP(hipMemsetAsync(oob.p, 0, sizeof(int), stream));
+        binmeta.reserve(sizeof(int) * (2 * (size_t)(nb + 1) + 1));  // counts | cursor | oob
+        int *counts_p = binmeta.as<int>(), *cursor_p = counts_p + (nb + 1), *oob_p = cursor_p + (nb + 1);
+        oob_ptr = oob_p;
+        FV_HIP(hipMemsetAsync(binmeta.p, 0, sizeof(int) * (2 * (size_t)(nb + 1) + 1), stream));
         BinArgs a{};
         a.w = ker.w;
         a.dim = dim;
@@ -747,18 +875,18 @@ class Nufft3 {
             a.nbin[d] = geo.nbin[d];
         }
         if (M > 0) {
-            hipLaunchKernelGGL(k_bin_count<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, x, y,
-                               z, a, i0u.as<int>(), fu.as<T>(), tile_of.as<int>(),
-                               counts.as<int>(), oob.as<int>());
+            hipLaunchKernelGGL(k_bin_count<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, Mp, x,
+                               y, z, a, i0u.as<int>(), fu.as<T>(), tile_of.as<int>(), counts_p,
+                               oob_p);
         }
         if (nb <= 4096) {
-            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, counts.as<int>(),
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, counts_p,
                                bin_start.as<int>(), nb);
         } else {
             const int nblk = (int)cdiv(nb, 1024);
             scan_tot.reserve(sizeof(int) * (nblk + 1));
             scan_off.reserve(sizeof(int) * (nblk + 1));
-            hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(1024), 0, stream, counts.as<int>(),
+            hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(1024), 0, stream, counts_p,
                                bin_start.as<int>(), scan_tot.as<int>(), nb);
             hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
                                scan_tot.as<int>(), scan_off.as<int>(), nblk);
@@ -766,16 +894,17 @@ class Nufft3 {
                                scan_off.as<int>(), nb);
         }
         if (M > 0) {
-            hipLaunchKernelGGL(k_bin_scatter<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, dim,
-                               i0u.as<int>(), fu.as<T>(), tile_of.as<int>(), bin_start.as<int>(),
-                               cursor.as<int>(), i0s.as<int>(), fs.as<T>(), perm.as<int>(),
-                               kw.as<T>(), ker.w, (T)ker.beta, (T)ker.c);
+            hipLaunchKernelGGL(k_bin_scatter<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, Mp,
+                               dim, i0u.as<int>(), fu.as<T>(), tile_of.as<int>(),
+                               bin_start.as<int>(), cursor_p, i0s.as<int>(), fs.as<T>(),
+                               perm.as<int>(), kw.as<T>(), ker.w, (T)ker.beta, (T)ker.c);
         }
     }
 
     int out_of_box_count() {
         int v = 0;
-        FV_HIP(hipMemcpyAsync(&v, oob.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (!oob_ptr) return 0;
+        FV_HIP(hipMemcpyAsync(&v, oob_ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
         FV_HIP(hipStreamSynchronize(stream));
         return v;
     }
@@ -789,7 +918,7 @@ class Nufft3 {
     void load_strengths(const cplx<T> *cin, int ntrans, int tpol, const double *scale_dev) {
         cplx<T> *cs = strengths_buffer(ntrans);
         if (M == 0) return;
-        hipLaunchKernelGGL(k_load_strengths<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, ntrans,
+        hipLaunchKernelGGL(k_load_strengths<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, Mp, ntrans,
                            tpol, dim, cin, perm.as<int>(), i0s.as<int>(), fs.as<T>(), geo.d[0].h,
                            geo.d[1].h, geo.d[2].h, geo.d[0].na, geo.d[1].na,
                            dim > 2 ? geo.d[2].na : 1, geo.d[0].btc, geo.d[1].btc, geo.d[2].btc,
@@ -851,8 +980,27 @@ void Nufft3<T>::spread(int ntrans) {
 // Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision).
 inline void rowfft_shape(const DimGeom &g, int &tpr, int &rpw) {
     tpr = 16;
-    while (tpr < FFT_THREADS && (tpr < g.Q / FV_FFT_TPR_DIV || (int64_t)tpr * FFT_NACC < g.no)) tpr *= 2;
+    while (tpr < FFT_THREADS &&
+           (tpr < g.Q / FV_FFT_TPR_DIV || (g.P > 1 && (int64_t)tpr * FFT_NACC < g.no)))
+        tpr *= 2;
     rpw = FFT_THREADS / tpr;
+}
+
+#ifndef FV_FFT_ITEMS
+#define FV_FFT_ITEMS 8  // whole-row kernel: threads per row ~ n2 / this
+#endif
+
+// Whole-row kernel geometry; returns false when a row does not fit the LDS.
+inline bool rowfft_full_shape(const DimGeom &g, size_t elem, int &tpr, int &rpw, int &sa, int &lds_row) {
+    sa = fft_pidx(g.Q) | 1;
+    lds_row = g.P * sa;
+    if ((size_t)lds_row * elem > 150 * 1024) return false;
+    tpr = 64;
+    while (tpr < 1024 && tpr * FV_FFT_ITEMS < g.n2) tpr *= 2;
+    const int wgt = std::max(256, tpr);
+    rpw = wgt / tpr;
+    while (rpw > 1 && (size_t)rpw * lds_row * elem > 64 * 1024) rpw /= 2;
+    return true;
 }
 
 // rows = nplanes * rpp; element ia of row (plane, k) sits at plane*in_plane + k*in_row + ia*in_elem.
@@ -862,6 +1010,44 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
                        int64_t in_elem) {
     static const int plans[7][4] = {{3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0}, {3, 3, 3, 0},
                                     {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 6 .. 12
+    FV_REQUIRE(g.logQ >= 6 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
+    int ftpr, frpw, fsa, flds;
+    static const bool use_full = std::getenv("FFTVIS_HIP_FFT_FULL") && std::atoi(std::getenv("FFTVIS_HIP_FFT_FULL"));
+    if (use_full && rowfft_full_shape(g, sizeof(cplx<T>), ftpr, frpw, fsa, flds)) {
+        RowFftFullArgs a{};
+        a.n_in = g.na;
+        a.n_out = g.no;
+        a.n2 = g.n2;
+        a.P = g.P;
+        a.Q = g.Q;
+        a.logQ = g.logQ;
+        a.npass = 0;
+        for (int s = 0; s < 4; ++s) {
+            a.radix_log[s] = plans[g.logQ - 6][s];
+            if (a.radix_log[s]) ++a.npass;
+        }
+        a.tpr = ftpr;
+        a.rpw = frpw;
+        a.sa = fsa;
+        a.lds_row = flds;
+        a.colmode = in_elem != 1;
+        a.nrows = nplanes * rpp;
+        a.rpp = rpp;
+        a.in_plane = in_plane;
+        a.in_row = in_row;
+        a.in_elem = in_elem;
+        a.out_pitch = g.no;
+        const size_t smem = sizeof(cplx<T>) * (size_t)flds * frpw;
+        static bool attr_set_full = false;
+        if (!attr_set_full) {
+            FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft_full<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set_full = true;
+        }
+        hipLaunchKernelGGL(k_rowfft_full<T>, dim3((unsigned)cdiv(a.nrows, frpw)), dim3(ftpr * frpw),
+                           smem, stream, in, out, twd, a);
+        return;
+    }
     RowFftArgs a{};
     a.n_in = g.na;
     a.n_out = g.no;
@@ -869,7 +1055,6 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.P = g.P;
     a.Q = g.Q;
     a.logQ = g.logQ;
-    FV_REQUIRE(g.logQ >= 6 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
     a.npass = 0;
     for (int s = 0; s < 4; ++s) {
         a.radix_log[s] = plans[g.logQ - 6][s];
@@ -878,7 +1063,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.qp = fft_pidx(g.Q);
     a.lds_row = a.qp | 1;
     rowfft_shape(g, a.tpr, a.rpw);
-    a.jchunk = std::min(g.no, a.tpr * FFT_NACC);  // more outputs than that: extra chunks (grid.y)
+    a.jchunk = g.P == 1 ? g.no : std::min(g.no, a.tpr * FFT_NACC);  // beyond: extra chunks (grid.y)
     a.colmode = in_elem != 1;
     a.nrows = nplanes * rpp;
     a.rpp = rpp;
@@ -889,12 +1074,17 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     const size_t smem = sizeof(cplx<T>) * (size_t)a.lds_row * a.rpw;
     static bool attr_set = false;
     if (!attr_set) {
-        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft<T>),
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft<T, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft<T, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     dim3 grid((unsigned)cdiv(a.nrows, a.rpw), (unsigned)cdiv(g.no, a.jchunk));
-    hipLaunchKernelGGL(k_rowfft<T>, grid, dim3(FFT_THREADS), smem, stream, in, out, twd, a);
+    if (g.P == 1)
+        hipLaunchKernelGGL((k_rowfft<T, true>), grid, dim3(FFT_THREADS), smem, stream, in, out, twd, a);
+    else
+        hipLaunchKernelGGL((k_rowfft<T, false>), grid, dim3(FFT_THREADS), smem, stream, in, out, twd, a);
 }
 
 template <typename T>
@@ -904,8 +1094,9 @@ void Nufft3<T>::fft(int ntrans) {
     cplx<T> *A = buf0.as<cplx<T>>(), *Bm = buf1.as<cplx<T>>();
     // x-pass: A [t][na_y][na_x] -> B [t][na_y][no_x]
     rowfft(A, Bm, x, tw[0].as<cplx<T>>(), ntrans, y.na, (int64_t)y.na * x.na, x.na, 1);
-    int tpr, rpw;
-    rowfft_shape(y, tpr, rpw);
+    int tpr, rpw, sa_, lds_;
+    static const bool use_full = std::getenv("FFTVIS_HIP_FFT_FULL") && std::atoi(std::getenv("FFTVIS_HIP_FFT_FULL"));
+    if (!(use_full && rowfft_full_shape(y, sizeof(cplx<T>), tpr, rpw, sa_, lds_))) rowfft_shape(y, tpr, rpw);
     if (rpw >= 4) {
         // short columns: the y-pass reads rpw adjacent columns of B at once (64-128 B segments),
         // which fuses the transpose.  B -> Ct [t][no_x][no_y] lands in A's storage.

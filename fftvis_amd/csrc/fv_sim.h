@@ -258,7 +258,7 @@ __global__ void k_inplace_rot(Rot9 r, T *__restrict__ b, int64_t n) {
 }
 
 struct StrengthArgs {
-    int64_t M;          // above-horizon sources
+    int64_t M;          // capacity of the per-time arrays (stride); live count is *Mp
     int nfg;            // frequencies in this group
     int f_first;        // catalog index of the group's first frequency
     int nfreq;          // catalog frequency count (flux row length)
@@ -272,13 +272,13 @@ struct StrengthArgs {
 // thread <-> (sorted source p, frequency fgi); fgi fastest so a wave reads flux rows contiguously
 // and writes its tpol strengths back to back:  cs[p][fgi * tpol + r].
 template <typename T>
-__global__ void k_strengths(StrengthArgs a, const int *__restrict__ perm,
+__global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const int *__restrict__ perm,
                             const int *__restrict__ src_idx, const T *__restrict__ az,
                             const T *__restrict__ za, const void *__restrict__ flux,
                             const double *__restrict__ freqs, const int *__restrict__ i0s,
                             const T *__restrict__ fs, cplx<T> *__restrict__ cs) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.M * a.nfg) return;
+    if (idx >= (int64_t)*Mp * a.nfg) return;
     const int64_t p = idx / a.nfg;
     const int fgi = (int)(idx % a.nfg);
     const int fidx = a.f_first + fgi;
@@ -439,7 +439,9 @@ class Sim : public SimBase {
     std::vector<Pair> pairs;
 
     // per-time scratch
-    DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scale, d_out;
+    DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scale, d_out, d_mhist,
+        d_scan_tot, d_scan_off;
+    std::vector<std::pair<int, double>> mhist_log;  // (time index, transforms spread) per processed time
     std::unique_ptr<Nufft3<T>> nufft;
 
     // stats / timing
@@ -719,25 +721,36 @@ class Sim : public SimBase {
         for (int ti = t0; ti < t1; ++ti) {
             // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
             size_t e0 = ev_begin(TM_PREP);
-            int M = 0;
-            if (nsrc > 0) {
-                // either R_t . eq on the fly, or topocentric vectors the caller computed
-                const T *vec = ntimes_topo ? d_topo.as<T>() + (size_t)ti * 3 * nsrc : d_eq.as<T>();
-                hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, nsrc,
-                                   vec, rots[ti], d_blockcnt.as<int>());
+            if (nsrc == 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
+            // either R_t . eq on the fly, or topocentric vectors the caller computed
+            const T *vec = ntimes_topo ? d_topo.as<T>() + (size_t)ti * 3 * nsrc : d_eq.as<T>();
+            hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
+                               rots[ti], d_blockcnt.as<int>());
+            if (nblk <= 4096) {
                 hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
                                    d_blockcnt.as<int>(), d_blockoff.as<int>(), nblk);
-                hipLaunchKernelGGL(k_horizon_compact<T>, dim3(nblk), dim3(256), 0, stream, nsrc,
-                                   vec, rots[ti], rplane, d_blockoff.as<int>(),
-                                   d_xyz.as<T>(), cap, d_az.as<T>(), d_za.as<T>(),
-                                   d_srcidx.as<int>());
-                FV_HIP(hipMemcpyAsync(&M, d_blockoff.as<int>() + nblk, sizeof(int),
-                                      hipMemcpyDeviceToHost, stream));
-                FV_HIP(hipStreamSynchronize(stream));
+            } else {
+                const int nb2 = (int)cdiv(nblk, 1024);
+                d_scan_tot.reserve(sizeof(int) * (nb2 + 1));
+                d_scan_off.reserve(sizeof(int) * (nb2 + 1));
+                hipLaunchKernelGGL(k_scan_blocks, dim3(nb2), dim3(1024), 0, stream,
+                                   d_blockcnt.as<int>(), d_blockoff.as<int>(), d_scan_tot.as<int>(), nblk);
+                hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
+                                   d_scan_tot.as<int>(), d_scan_off.as<int>(), nb2);
+                hipLaunchKernelGGL(k_scan_add, dim3(nb2), dim3(1024), 0, stream,
+                                   d_blockoff.as<int>(), d_scan_off.as<int>(), nblk);
             }
+            hipLaunchKernelGGL(k_horizon_compact<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
+                               rots[ti], rplane, d_blockoff.as<int>(), d_xyz.as<T>(), cap,
+                               d_az.as<T>(), d_za.as<T>(), d_srcidx.as<int>());
+            // The live count M stays on the device (no host round trip): kernels read *Mp.
+            const int *Mp = d_blockoff.as<int>() + nblk;
+            const int64_t M = cap;  // capacity: array stride and launch bound
+            d_mhist.reserve(sizeof(int) * rots.size());
+            FV_HIP(hipMemcpyAsync(d_mhist.as<int>() + ti, Mp, sizeof(int), hipMemcpyDeviceToDevice, stream));
             ev_end(e0);
-            st[5] += M;
-            if (M == 0) continue;  // cpu_simulate.py:945-946
+            size_t hist_slot = mhist_log.size();
+            mhist_log.push_back({ti, 0.0});
 
             for (const auto &grp : groups) {
                 const int fa = grp.first, fb = grp.second, nfg = fb - fa;
@@ -751,7 +764,7 @@ class Sim : public SimBase {
                     nufft->set_geometry(xc, X, pr.btc, pr.B, smax);
                     if (binned_ti != ti || binned_serial != nufft->geom_serial || nufft->M != M) {
                         nufft->set_sources(M, d_xyz.as<T>(), d_xyz.as<T>() + cap,
-                                           D > 2 ? d_xyz.as<T>() + 2 * cap : nullptr);
+                                           D > 2 ? d_xyz.as<T>() + 2 * cap : nullptr, Mp);
                         binned_ti = ti;
                         binned_serial = nufft->geom_serial;
                     }
@@ -777,7 +790,7 @@ class Sim : public SimBase {
                     sa.bj = desc(pr.bj);
                     cplx<T> *cs = nufft->strengths_buffer(ntrans);
                     hipLaunchKernelGGL(k_strengths<T>, dim3(cdiv((int64_t)M * nfg, 256)), dim3(256),
-                                       0, stream, sa, nufft->perm.template as<int>(),
+                                       0, stream, sa, Mp, nufft->perm.template as<int>(),
                                        d_srcidx.as<int>(), d_az.as<T>(), d_za.as<T>(), d_flux.p,
                                        d_freqs.as<double>(), nufft->i0s.template as<int>(),
                                        nufft->fs.template as<T>(), cs);
@@ -788,7 +801,7 @@ class Sim : public SimBase {
                     ev_end(e3);
                     st[0] += 1;
                     st[1] += (double)nufft->geo.cells_a() * ntrans;
-                    st[2] += (double)M * ntrans;
+                    mhist_log[hist_slot].second += ntrans;
                     size_t e4 = ev_begin(TM_FFT);
                     nufft->fft(ntrans);
                     ev_end(e4);
@@ -840,11 +853,24 @@ class Sim : public SimBase {
         if (timing_on) ev_collect();
     }
     void stats(double *v, int n) override {
+        // above-horizon counts were left on the device during run(); fold them in now
+        if (!mhist_log.empty()) {
+            FV_HIP(hipSetDevice(device));
+            std::vector<int> mh(rots.size());
+            FV_HIP(hipMemcpyAsync(mh.data(), d_mhist.p, sizeof(int) * mh.size(), hipMemcpyDeviceToHost, stream));
+            FV_HIP(hipStreamSynchronize(stream));
+            for (const auto &e : mhist_log) {
+                st[5] += mh[e.first];
+                st[2] += (double)mh[e.first] * e.second;
+            }
+            mhist_log.clear();
+        }
         for (int i = 0; i < n && i < 10; ++i) v[i] = st[i];
     }
     void reset_stats() override {
         for (double &x : st) x = 0;
         for (double &x : tm) x = 0;
+        mhist_log.clear();
         ev_used = 0;
     }
     void enable_timing(int on) override { timing_on = on != 0; }
