@@ -30,7 +30,6 @@
 
 namespace fv {
 
-constexpr int TILE = 32;       // buffer-A extents are rounded up to a multiple of this
 constexpr int BINLOG = 3;      // sources are binned by footprint origin in 8x8-cell bins
 constexpr int GROUP = 16;      // lanes cooperating on one source / one target (>= MAX_W)
 constexpr int SPREAD_THREADS = 256;
@@ -51,7 +50,7 @@ struct DimGeom {
     double S = 0;            // scale_max * B
     double h = 1;            // x-space grid spacing: xi = (x - xc) / h
     int n1 = 2;              // cells the sources can touch
-    int na = 32;             // n1 rounded up to whole tiles: extent of buffer A
+    int na = 8;              // n1 rounded up to whole 8-cell bins: extent of buffer A
     int n2 = 64, P = 1, Q = 64, logQ = 6;  // FFT length n2 = P * Q
     int no = 2;              // transform outputs kept (centred on mode 0)
 };
@@ -65,13 +64,13 @@ struct Geom {
     int64_t cells_o() const { return (int64_t)d[0].no * d[1].no * (dim > 2 ? d[2].no : 1); }
 };
 
-// n2 = P * 2^b >= nmin with 64 <= 2^b <= 4096 and P <= 16 (P unbounded at 2^b = 4096), chosen to
+// n2 = P * 2^b >= nmin with 16 <= 2^b <= 4096 and P <= 16 (P unbounded at 2^b = 4096), chosen to
 // minimise n2 * (1 + 0.03 (P - 1)): HBM traffic grows with n2, per-row work with P.  Then as many
 // factors of two as possible move from P into Q.
 inline void choose_pq(int nmin, DimGeom &g) {
     double best = 0;
     int bp = 0, bq = 0;
-    for (int b = 6; b <= FFT_QMAX_LOG; ++b) {
+    for (int b = 4; b <= FFT_QMAX_LOG; ++b) {
         const int q = 1 << b;
         const int p = (nmin + q - 1) / q;
         if (p > 16 && b < FFT_QMAX_LOG) continue;
@@ -107,7 +106,7 @@ inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
     int n1 = (int)std::ceil(2.0 * sigma * Ss * Xs / M_PI + w + 1);
     n1 += n1 % 2;
     g.n1 = n1;
-    g.na = (int)cdiv(n1, TILE) * TILE;
+    g.na = (int)cdiv(n1, 1 << BINLOG) << BINLOG;  // whole source bins
     choose_pq(std::max(g.na, (int)std::ceil(sigma * n1)), g);
     g.h = M_PI / (sigma * Ss);
     // targets sit at |eta| <= n2/(2 sigma) (in transform cells); keep the footprint around them
@@ -329,6 +328,58 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
     const T f = decx[cx] * decy[cy];
     const int64_t plane = (int64_t)nay * nax;
     cplx<T> *o = grid + (int64_t)tbase * plane + (int64_t)cy * nax + cx;
+#pragma unroll
+    for (int q = 0; q < TCH; ++q) o[q * plane] = {ar[q] * f, ai[q] * f};
+}
+
+// --- 3-D spread (gather): as k_spread2d, one wave per 8x8 (x, y) block of ONE z-plane of A ------
+// grid (ceil(nbx / 4), nby, na_z * chunks); bin index = (bz * nby + by) * nbx + bx.
+template <typename T, int TCH>
+__global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
+    int64_t M, const int *__restrict__ i0s, const T *__restrict__ kw,
+    const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans, int tbegin,
+    int nchunk, const T *__restrict__ decx, const T *__restrict__ decy,
+    const T *__restrict__ decz, cplx<T> *__restrict__ grid, int nax, int nay, int naz, int nbx,
+    int nby, int w) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bx = blockIdx.x * 4 + wave, by = blockIdx.y;
+    if (bx >= nbx) return;  // wave-uniform
+    const int cz = blockIdx.z / nchunk;
+    const int tbase = tbegin + (blockIdx.z % nchunk) * TCH;
+    const int cx = (bx << BINLOG) + (lane & 7), cy = (by << BINLOG) + (lane >> 3);
+    const int *i0x = i0s, *i0y = i0s + M, *i0z = i0s + 2 * M;
+    const T *kwx = kw, *kwy = kw + M * w, *kwz = kw + 2 * M * w;
+    T ar[TCH], ai[TCH];
+#pragma unroll
+    for (int q = 0; q < TCH; ++q) ar[q] = ai[q] = T(0);
+    const int bxl = max((bx << BINLOG) - w + 1, 0) >> BINLOG;
+    const int byl = max((by << BINLOG) - w + 1, 0) >> BINLOG;
+    const int bzl = max(cz - w + 1, 0) >> BINLOG, bzh = cz >> BINLOG;
+    for (int zb = bzl; zb <= bzh; ++zb) {
+        for (int yb = byl; yb <= by; ++yb) {
+            const int rowb = (zb * nby + yb) * nbx;
+            const int s0 = bin_start[rowb + bxl], s1 = bin_start[rowb + bx + 1];
+            for (int s = s0; s < s1; ++s) {
+                const int dz = cz - i0z[s];  // wave-uniform
+                if ((unsigned)dz >= (unsigned)w) continue;
+                const int dx = cx - i0x[s], dy = cy - i0y[s];
+                T wt = T(0);
+                if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
+                    wt = kwx[(int64_t)s * w + dx] * kwy[(int64_t)s * w + dy] * kwz[(int64_t)s * w + dz];
+                const cplx<T> *c = cs + (int64_t)s * ntrans + tbase;
+#pragma unroll
+                for (int q = 0; q < TCH; ++q) {
+                    const cplx<T> cv = c[q];
+                    ar[q] += cv.re * wt;
+                    ai[q] += cv.im * wt;
+                }
+            }
+        }
+    }
+    const T f = decx[cx] * decy[cy] * decz[cz];
+    const int64_t plane = (int64_t)naz * nay * nax;
+    cplx<T> *o = grid + (int64_t)tbase * plane + ((int64_t)cz * nay + cy) * nax + cx;
 #pragma unroll
     for (int q = 0; q < TCH; ++q) o[q * plane] = {ar[q] * f, ai[q] * f};
 }
@@ -679,24 +730,25 @@ __global__ void k_transpose(const cplx<T> *__restrict__ in, cplx<T> *__restrict_
     }
 }
 
-// --- 2-D gather (interp) ------------------------------------------------------------------------
-// The transformed grid arrives TRANSPOSED from the second FFT pass: [trans][lx][ly], y contiguous.
-// Index 0 of the per-dimension arrays below is the contiguous ("fast") dimension.
+// --- gather (interp), 2-D and 3-D ---------------------------------------------------------------
+// The transformed grid arrives with its dimensions reversed by the FFT passes: 2-D [trans][lx][ly],
+// 3-D [trans][lx][ly][lz].  Index 0 of the per-dimension arrays below is the contiguous ("fast")
+// dimension (y in 2-D, z in 3-D), index 1 the next one, index 2 (3-D only) the slowest.
 struct InterpArgs {
     int w, tpol, nfg;             // tpol transforms per frequency group, nfg groups
-    int n2[2], no[2];
-    double h[2];                  // theta = h * s'
-    double btc[2], xc[2];
+    int n2[3], no[3];
+    double h[3];                  // theta = h * s'
+    double btc[3], xc[3];
     int64_t out_fg_stride;        // output element strides
     int64_t out_k_stride;
     int64_t out_pol_off[16];      // offset of polarisation product r (r < tpol <= 16); beyond: r * out_pol_off[1]
     int accumulate;               // out += instead of out =
 };
 
-template <typename T>
-__global__ __launch_bounds__(INTERP_THREADS) void k_interp2d(
-    const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ bt_fast,
-    const T *__restrict__ bt_slow, const int *__restrict__ bl_idx,
+template <typename T, int DIM>
+__global__ __launch_bounds__(INTERP_THREADS) void k_interp(
+    const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ bt0,
+    const T *__restrict__ bt1, const T *__restrict__ bt2, const int *__restrict__ bl_idx,
     const signed char *__restrict__ flip, const double *__restrict__ scale, InterpArgs a,
     KerParams ker, cplx<T> *__restrict__ out) {
     const int tid = threadIdx.x;
@@ -709,34 +761,46 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp2d(
     const int64_t k = bl_idx ? bl_idx[kl] : kl;
     const double sg = (flip && flip[kl]) ? -1.0 : 1.0;
     const double sc = scale[fg];
-    const double sf = sc * sg * (double)bt_fast[k], ss = sc * sg * (double)bt_slow[k];  // target
-    const double thf = a.h[0] * (sf - sc * a.btc[0]), ths = a.h[1] * (ss - sc * a.btc[1]);
-    const double ef = thf * a.n2[0] * (0.5 / M_PI) + 0.5 * a.no[0];
-    const double es = ths * a.n2[1] * (0.5 / M_PI) + 0.5 * a.no[1];
     const int w = a.w;
-    int j0f = (int)ceil(ef - 0.5 * w), j0s = (int)ceil(es - 0.5 * w);
-    j0f = max(0, min(a.no[0] - w, j0f));
-    j0s = max(0, min(a.no[1] - w, j0s));
     const T beta = (T)ker.beta, c4 = (T)ker.c;
-    const T kf = g < w ? es_eval<T>((T)((double)(j0f + g) - ef), beta, c4) : T(0);
-    const T ksv = g < w ? es_eval<T>((T)((double)(j0s + g) - es), beta, c4) : T(0);
-    T ks[MAX_W];
+    const T *bt[3] = {bt0, bt1, bt2};
+    double sv[DIM], th[DIM];
+    int j0[DIM];
+    T kv[DIM];  // this lane's kernel value along each dimension (lane = footprint offset)
 #pragma unroll
-    for (int r = 0; r < MAX_W; ++r) ks[r] = __shfl(ksv, lane_base + r, 64);
+    for (int d = 0; d < DIM; ++d) {
+        sv[d] = sc * sg * (double)bt[d][k];                     // actual target coordinate
+        th[d] = a.h[d] * (sv[d] - sc * a.btc[d]);               // theta = h (s - s_c)
+        const double e = th[d] * a.n2[d] * (0.5 / M_PI) + 0.5 * a.no[d];
+        int j = (int)ceil(e - 0.5 * w);
+        j = max(0, min(a.no[d] - w, j));
+        j0[d] = j;
+        kv[d] = g < w ? es_eval<T>((T)((double)(j + g) - e), beta, c4) : T(0);
+    }
+    T k1[MAX_W];
+#pragma unroll
+    for (int r = 0; r < MAX_W; ++r) k1[r] = __shfl(kv[1], lane_base + r, 64);
 
-    // psi_1_hat at both thetas: quadrature nodes split over the 16 lanes
-    double hf = 0.0, hs = 0.0;
+    // psi_1_hat at every theta: quadrature nodes split over the 16 lanes
+    double hh[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) hh[d] = 0.0;
     for (int q = g; q < ker.nq; q += GROUP) {
-        hf += ker.glf[q] * cos(thf * ker.glz[q]);
-        hs += ker.glf[q] * cos(ths * ker.glz[q]);
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) hh[d] += ker.glf[q] * cos(th[d] * ker.glz[q]);
     }
 #pragma unroll
     for (int off = GROUP / 2; off > 0; off >>= 1) {
-        hf += __shfl_xor(hf, off, 64);
-        hs += __shfl_xor(hs, off, 64);
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) hh[d] += __shfl_xor(hh[d], off, 64);
     }
-    double pr = 1.0 / (hf * hs), pi_ = 0.0;
-    const double ph = sf * a.xc[0] + ss * a.xc[1];  // post-phase exp(i s . x_c)
+    double den = 1.0, ph = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        den *= hh[d];
+        ph += sv[d] * a.xc[d];  // post-phase exp(i s . x_c)
+    }
+    double pr = 1.0 / den, pi_ = 0.0;
     if (ph != 0.0) {
         double sn, cs;
         sincos(ph, &sn, &cs);
@@ -744,21 +808,35 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp2d(
         pr = pr * cs;
     }
 
-    const int64_t plane_sz = (int64_t)a.no[0] * a.no[1];
-    const int gcol = min(j0f + g, a.no[0] - 1);
+    const int64_t row_sz = a.no[0];
+    const int64_t slab_sz = row_sz * a.no[1];
+    const int64_t plane_sz = DIM == 3 ? slab_sz * a.no[2] : slab_sz;
+    const int gcol = min(j0[0] + g, a.no[0] - 1);
+    const int nouter = DIM == 3 ? w : 1;
     for (int r = 0; r < a.tpol; ++r) {
         const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * plane_sz + gcol;
         T sr = T(0), si = T(0);
-#pragma unroll
-        for (int rr = 0; rr < MAX_W; ++rr) {
-            if (rr < w) {
-                const cplx<T> v = plane[(int64_t)(j0s + rr) * a.no[0]];
-                sr += v.re * ks[rr];
-                si += v.im * ks[rr];
+        for (int ro = 0; ro < nouter; ++ro) {
+            T k2 = T(1);
+            const cplx<T> *slab = plane;
+            if (DIM == 3) {
+                k2 = __shfl(kv[DIM - 1], lane_base + ro, 64);
+                slab += (int64_t)(j0[DIM - 1] + ro) * slab_sz;
             }
+            T tr = T(0), ti = T(0);
+#pragma unroll
+            for (int rr = 0; rr < MAX_W; ++rr) {
+                if (rr < w) {
+                    const cplx<T> v = slab[(int64_t)(j0[1] + rr) * row_sz];
+                    tr += v.re * k1[rr];
+                    ti += v.im * k1[rr];
+                }
+            }
+            sr += tr * k2;
+            si += ti * k2;
         }
-        sr *= kf;
-        si *= kf;
+        sr *= kv[0];
+        si *= kv[0];
 #pragma unroll
         for (int off = GROUP / 2; off > 0; off >>= 1) {
             sr += __shfl_xor(sr, off, 64);
@@ -823,6 +901,7 @@ class Nufft3 {
             geo.d[d].B = B[d];
             set_dim_geom(geo.d[d], sigma, ker.w, scale_max);
             geo.nbin[d] = geo.d[d].na >> BINLOG;
+        for (int d = dim; d < 3; ++d) geo.nbin[d] = 1;
         }
         for (int d = 0; d < dim; ++d) {
             const DimGeom &g = geo.d[d];
@@ -925,17 +1004,10 @@ class Nufft3 {
                            scale_dev, cs);
     }
 
-    // HBM bytes one transform's grid buffers occupy (for the caller's batching heuristic).
-    int64_t bytes_per_trans() const {
-        const DimGeom &x = geo.d[0], &y = geo.d[1];
-        const int64_t b0 = std::max((int64_t)x.na * y.na, (int64_t)x.no * y.na);
-        const int64_t b1 = std::max((int64_t)y.na * x.no, (int64_t)x.no * y.no);
-        return (b0 + b1) * (int64_t)sizeof(cplx<T>);
-    }
-
     void spread(int ntrans);
     template <int TCH>
     int launch_spread(int ntrans, int tbegin);
+    void buffer_cells(int64_t &c0, int64_t &c1) const;
     void fft(int ntrans);
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
     // index list / flip flags of length N, per-group scale (device, nfg doubles).
@@ -955,20 +1027,40 @@ template <int TCH>
 int Nufft3<T>::launch_spread(int ntrans, int tbegin) {
     const int nchunk = (ntrans - tbegin) / TCH;
     if (nchunk == 0) return tbegin;
-    const DimGeom &x = geo.d[0], &y = geo.d[1];
-    dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)nchunk);
-    hipLaunchKernelGGL((k_spread2d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, M, i0s.as<int>(),
-                       kw.as<T>(), bin_start.as<int>(), strengths.as<cplx<T>>(), ntrans, tbegin,
-                       dec[0].as<T>(), dec[1].as<T>(), buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0],
-                       ker.w);
+    const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
+    if (dim == 2) {
+        dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)nchunk);
+        hipLaunchKernelGGL((k_spread2d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, M,
+                           i0s.as<int>(), kw.as<T>(), bin_start.as<int>(),
+                           strengths.as<cplx<T>>(), ntrans, tbegin, dec[0].as<T>(), dec[1].as<T>(),
+                           buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0], ker.w);
+    } else {
+        dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)(z.na * nchunk));
+        hipLaunchKernelGGL((k_spread3d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, M,
+                           i0s.as<int>(), kw.as<T>(), bin_start.as<int>(),
+                           strengths.as<cplx<T>>(), ntrans, tbegin, nchunk, dec[0].as<T>(),
+                           dec[1].as<T>(), dec[2].as<T>(), buf0.as<cplx<T>>(), x.na, y.na, z.na,
+                           geo.nbin[0], geo.nbin[1], ker.w);
+    }
     return tbegin + nchunk * TCH;
+}
+
+// Largest buffer (cells per transform) each ping-pong buffer has to hold during spread + fft.
+template <typename T>
+void Nufft3<T>::buffer_cells(int64_t &c0, int64_t &c1) const {
+    const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
+    const int64_t zin = dim > 2 ? z.na : 1, zout = dim > 2 ? z.no : 1;
+    const int64_t A = zin * y.na * x.na, B = zin * y.na * x.no, C = zin * x.no * y.no,
+                  D = zout * x.no * y.no;
+    c0 = std::max({A, B, C, D});  // either buffer may end up holding any stage (transpose or not)
+    c1 = c0;
 }
 
 template <typename T>
 void Nufft3<T>::spread(int ntrans) {
-    FV_REQUIRE(dim == 2, "3-D spread not built yet");
-    const DimGeom &x = geo.d[0], &y = geo.d[1];
-    buf0.reserve(sizeof(cplx<T>) * std::max({(int64_t)x.na * y.na, (int64_t)x.no * y.na, (int64_t)x.no * y.no}) * ntrans);
+    int64_t c0, c1;
+    buffer_cells(c0, c1);
+    buf0.reserve(sizeof(cplx<T>) * c0 * ntrans);
     // whole chunks of 16 transforms per thread, then the binary remainder (<= 4 more launches)
     int t = launch_spread<16>(ntrans, 0);
     t = launch_spread<8>(ntrans, t);
@@ -1008,9 +1100,9 @@ template <typename T>
 void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                        int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row,
                        int64_t in_elem) {
-    static const int plans[7][4] = {{3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0}, {3, 3, 3, 0},
-                                    {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 6 .. 12
-    FV_REQUIRE(g.logQ >= 6 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
+    static const int plans[9][4] = {{4, 0, 0, 0}, {3, 2, 0, 0}, {3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0},
+                                    {3, 3, 3, 0}, {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 4 .. 12
+    FV_REQUIRE(g.logQ >= 4 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
     int ftpr, frpw, fsa, flds;
     static const bool use_full = std::getenv("FFTVIS_HIP_FFT_FULL") && std::atoi(std::getenv("FFTVIS_HIP_FFT_FULL"));
     if (use_full && rowfft_full_shape(g, sizeof(cplx<T>), ftpr, frpw, fsa, flds)) {
@@ -1023,7 +1115,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         a.logQ = g.logQ;
         a.npass = 0;
         for (int s = 0; s < 4; ++s) {
-            a.radix_log[s] = plans[g.logQ - 6][s];
+            a.radix_log[s] = plans[g.logQ - 4][s];
             if (a.radix_log[s]) ++a.npass;
         }
         a.tpr = ftpr;
@@ -1057,7 +1149,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.logQ = g.logQ;
     a.npass = 0;
     for (int s = 0; s < 4; ++s) {
-        a.radix_log[s] = plans[g.logQ - 6][s];
+        a.radix_log[s] = plans[g.logQ - 4][s];
         if (a.radix_log[s]) ++a.npass;
     }
     a.qp = fft_pidx(g.Q);
@@ -1089,26 +1181,38 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
 
 template <typename T>
 void Nufft3<T>::fft(int ntrans) {
-    const DimGeom &x = geo.d[0], &y = geo.d[1];
-    buf1.reserve(sizeof(cplx<T>) * std::max((int64_t)y.na * x.no, (int64_t)x.no * y.no) * ntrans);
-    cplx<T> *A = buf0.as<cplx<T>>(), *Bm = buf1.as<cplx<T>>();
-    // x-pass: A [t][na_y][na_x] -> B [t][na_y][no_x]
-    rowfft(A, Bm, x, tw[0].as<cplx<T>>(), ntrans, y.na, (int64_t)y.na * x.na, x.na, 1);
+    const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
+    int64_t c0, c1;
+    buffer_cells(c0, c1);
+    buf1.reserve(sizeof(cplx<T>) * c1 * ntrans);
+    cplx<T> *cur = buf0.as<cplx<T>>(), *oth = buf1.as<cplx<T>>();
+    const int64_t zin = dim > 2 ? z.na : 1;       // planes per transform before the z-pass
+    const int64_t np = (int64_t)ntrans * zin;     // (trans, z) planes
+    // x-pass: A [p][na_y][na_x] -> B [p][na_y][no_x]
+    rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1);
+    std::swap(cur, oth);
     int tpr, rpw, sa_, lds_;
     static const bool use_full = std::getenv("FFTVIS_HIP_FFT_FULL") && std::atoi(std::getenv("FFTVIS_HIP_FFT_FULL"));
     if (!(use_full && rowfft_full_shape(y, sizeof(cplx<T>), tpr, rpw, sa_, lds_))) rowfft_shape(y, tpr, rpw);
     if (rpw >= 4) {
-        // short columns: the y-pass reads rpw adjacent columns of B at once (64-128 B segments),
-        // which fuses the transpose.  B -> Ct [t][no_x][no_y] lands in A's storage.
-        rowfft(Bm, A, y, tw[1].as<cplx<T>>(), ntrans, x.no, (int64_t)y.na * x.no, 1, x.no);
-        grid_out = A;
+        // short columns: the y-pass reads rpw adjacent columns of B at once (64-256 B segments),
+        // which fuses the transpose:  B -> C [p][no_x][no_y]
+        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, x.no, (int64_t)y.na * x.no, 1, x.no);
+        std::swap(cur, oth);
     } else {
-        // long columns: explicit tile transpose B -> Bt [t][no_x][na_y], then contiguous rows
-        dim3 tg((unsigned)cdiv(x.no, 32), (unsigned)cdiv(y.na, 32), (unsigned)ntrans);
-        hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, Bm, A, y.na, x.no);
-        rowfft(A, Bm, y, tw[1].as<cplx<T>>(), ntrans, x.no, (int64_t)x.no * y.na, y.na, 1);
-        grid_out = Bm;
+        // long columns: explicit tile transpose B -> Bt [p][no_x][na_y], then contiguous rows
+        dim3 tg((unsigned)cdiv(x.no, 32), (unsigned)cdiv(y.na, 32), (unsigned)np);
+        hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, cur, oth, y.na, x.no);
+        rowfft(oth, cur, y, tw[1].as<cplx<T>>(), np, x.no, (int64_t)x.no * y.na, y.na, 1);
     }
+    if (dim > 2) {
+        // z-pass: C [t][na_z][nc] (nc = no_x no_y) -> D [t][nc][no_z]; adjacent (lx, ly) columns
+        // are adjacent in memory, so the column-mode load is coalesced whenever rpw >= 4.
+        const int64_t nc = (int64_t)x.no * y.no;
+        rowfft(cur, oth, z, tw[2].as<cplx<T>>(), ntrans, nc, (int64_t)z.na * nc, 1, nc);
+        std::swap(cur, oth);
+    }
+    grid_out = cur;
 }
 
 template <typename T>
@@ -1117,28 +1221,36 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
                        cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                        const int64_t *out_pol_off, bool accumulate) {
     if (N == 0 || nfg == 0) return;
-    FV_REQUIRE(dim == 2, "3-D interp not built yet");
     InterpArgs a{};
     a.w = ker.w;
     a.tpol = tpol;
     a.nfg = nfg;
-    const int map[2] = {1, 0};  // fast dimension of Ct is y
-    for (int i = 0; i < 2; ++i) {
+    // grid dimensions from fastest to slowest: 2-D (y, x), 3-D (z, y, x)
+    const int map2[3] = {1, 0, 0}, map3[3] = {2, 1, 0};
+    const int *map = dim == 2 ? map2 : map3;
+    const T *bts[3] = {btx, bty, btz};
+    const T *bt[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < dim; ++i) {
         const DimGeom &g = geo.d[map[i]];
         a.n2[i] = g.n2;
         a.no[i] = g.no;
         a.h[i] = g.h;
         a.btc[i] = g.btc;
         a.xc[i] = g.xc;
+        bt[i] = bts[map[i]];
     }
     a.out_fg_stride = out_fg_stride;
     a.out_k_stride = out_k_stride;
     for (int r = 0; r < 16; ++r) a.out_pol_off[r] = out_pol_off ? out_pol_off[r] : 0;
     a.accumulate = accumulate ? 1 : 0;
     const int64_t items = N * nfg;
-    hipLaunchKernelGGL(k_interp2d<T>, dim3(cdiv(items, INTERP_THREADS / GROUP)),
-                       dim3(INTERP_THREADS), 0, stream, grid_out, N, bty, btx, bl_idx,
-                       flip, scale_dev, a, ker, out);
+    const dim3 grid((unsigned)cdiv(items, INTERP_THREADS / GROUP));
+    if (dim == 2)
+        hipLaunchKernelGGL((k_interp<T, 2>), grid, dim3(INTERP_THREADS), 0, stream, grid_out, N,
+                           bt[0], bt[1], bt[2], bl_idx, flip, scale_dev, a, ker, out);
+    else
+        hipLaunchKernelGGL((k_interp<T, 3>), grid, dim3(INTERP_THREADS), 0, stream, grid_out, N,
+                           bt[0], bt[1], bt[2], bl_idx, flip, scale_dev, a, ker, out);
 }
 
 }  // namespace fv

@@ -712,7 +712,8 @@ class Sim : public SimBase {
                 na[d] = g.na;
                 no[d] = g.no;
             }
-            cells_top = std::max(na[0] * na[1], no[0] * na[1]) + std::max(na[1] * no[0], no[0] * no[1]);
+            cells_top = 2.0 * std::max({na[2] * na[1] * na[0], na[2] * na[1] * no[0], na[2] * no[0] * no[1],
+                                         no[2] * no[0] * no[1]});
         }
         const auto groups = freq_groups(f0, f1, cells_top);
 
@@ -807,7 +808,8 @@ class Sim : public SimBase {
                     ev_end(e4);
                     {   // cells moved by the pruned FFT: read A, write+read B, write+read Bt, write Ct
                         const DimGeom &gx = nufft->geo.d[0], &gy = nufft->geo.d[1];
-                        st[3] += ((double)gx.na * gy.na + 4.0 * gx.no * gy.na + (double)gx.no * gy.no) * ntrans;
+                        const double zz = D > 2 ? nufft->geo.d[2].na : 1;
+                        st[3] += zz * ((double)gx.na * gy.na + 4.0 * gx.no * gy.na + (double)gx.no * gy.no) * ntrans;
                     }
                     size_t e5 = ev_begin(TM_INTERP);
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;

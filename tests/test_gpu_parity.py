@@ -10,7 +10,7 @@ import pytest
 
 import fftvis_amd
 from fftvis_amd import synth
-from fftvis_amd.gpu import GPUBeamEvaluator, gpu_nufft2d
+from fftvis_amd.gpu import GPUBeamEvaluator, gpu_nufft2d, gpu_nufft3d
 from fftvis_amd.gpu.nufft import gpu_nudft_direct
 from fftvis_amd.gpu.utils import inplace_rot
 from oracle import fftvis_oracle as orc
@@ -88,6 +88,25 @@ def test_nufft2d_shapes_and_edge_cases(gpu):
     xo, yo = x + 11.0, y - 7.0
     so, to = s + 300.0, t - 120.0
     assert rel_l2(gpu_nufft2d(xo, yo, c, so, to, 1e-9), nudft.nudft_type3([xo, yo], c, [so, to])) < 2e-8
+
+
+@pytest.mark.parametrize("eps", [1e-3, 6e-8, 1e-12])
+def test_nufft3d_meets_eps(gpu, eps):
+    """gpu_nufft3d vs the exact sum (reference cpu/nufft.py:62-118 -> finufft.nufft3d3), for a
+    thin third dimension (the non-coplanar-array case) and a cubic one."""
+    rng = np.random.default_rng(11)
+    for M, N, S, Sz in [(4000, 600, 60.0, 1.5), (1500, 300, 12.0, 12.0)]:
+        x, y = rng.uniform(-2 * np.pi, 2 * np.pi, (2, M))
+        z = rng.uniform(0, 2 * np.pi, M)
+        c = rng.normal(size=(3, M)) + 1j * rng.normal(size=(3, M))
+        s, t = rng.uniform(-S, S, (2, N))
+        u = rng.uniform(-Sz, Sz, N)
+        ex = nudft.nudft_type3([x, y, z], c, [s, t, u])
+        got = gpu_nufft3d(x, y, z, c, s, t, u, eps)
+        assert got.shape == (3, N) and rel_l2(got, ex) < max(5 * eps, 2e-11)
+    got32 = gpu_nufft3d(*(a.astype(np.float32) for a in (x, y, z)), c.astype(np.complex64),
+                        *(a.astype(np.float32) for a in (s, t, u)), 1e-4)
+    assert got32.dtype == np.complex64 and rel_l2(got32, ex) < 1e-3
 
 
 def test_nufft2d_linearity_and_brute_force_at_scale(gpu):
@@ -231,6 +250,8 @@ def _variants():
     bidx = np.array([0, 1, 0, 1, 1, 0, 1])
     bls = c1["baselines"] + [(3, 0), (6, 1), (2, 2)]  # flipped pairs and an auto
     tilted = {k: np.array([v[0], v[1], 0.01 * v[0] - 0.02 * v[1]]) for k, v in c1["ants"].items()}
+    hrng = np.random.default_rng(5)
+    rough = {k: np.array([v[0], v[1], 1.5 * hrng.normal()]) for k, v in c1["ants"].items()}
     return {
         "pol_table": dict(c1, polarized=True, beam=tab),
         "unpol_table": dict(c1, beam=tab),
@@ -241,6 +262,10 @@ def _variants():
                                beam_idx=bidx, baselines=bls),
         "tilted_array": dict(c1, ants=tilted),
         "default_baselines": dict(c1, baselines=None),
+        # antenna heights scatter by metres: not coplanar even after the plane fit -> 3-D type 3
+        # (reference cpu_simulate.py:655, tests/test_cpu_simulate.py "tilted" parametrisation)
+        "non_coplanar_unpol": dict(c1, ants=rough),
+        "non_coplanar_pol_table": dict(c1, ants=rough, polarized=True, beam=tab),
         "upsample_1p25": dict(c1, upsample_factor=1.25),
     }
 
