@@ -49,6 +49,7 @@ SYMBOLS = {
     "fv_sim_set_beam_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p]),
     "fv_sim_set_beam_pairs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
+    "fv_sim_set_basis": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fv_sim_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "fv_sim_sync": (c_int, [c_void_p]),
     "fv_sim_stats": (c_int, [c_void_p, c_void_p, c_int]),

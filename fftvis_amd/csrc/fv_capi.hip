@@ -346,6 +346,10 @@ int fv_sim_set_beam_pairs(fv_sim *h, int npairs, const int *bi, const int *bj, c
                           const int *idx, const signed char *flipped) {
     FV_SIM_CALL(FV_REQUIRE(npairs >= 1 && bi && bj && off, "bad pairs"); h->impl->set_beam_pairs(npairs, bi, bj, off, idx, flipped));
 }
+int fv_sim_set_basis(fv_sim *h, int nant, int nbasis, int nfreq, const void *coefs, const int *ant1,
+                     const int *ant2) {
+    FV_SIM_CALL(FV_REQUIRE(nant >= 1 && nbasis >= 1 && coefs && ant1 && ant2, "bad basis"); h->impl->set_basis(nant, nbasis, nfreq, coefs, ant1, ant2));
+}
 int fv_sim_run(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int out_on_device) {
     FV_SIM_CALL(FV_REQUIRE(out, "null output"); h->impl->run(t0, t1, f0, f1, out, out_on_device));
 }

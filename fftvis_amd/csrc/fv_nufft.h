@@ -743,6 +743,10 @@ struct InterpArgs {
     int64_t out_k_stride;
     int64_t out_pol_off[16];      // offset of polarisation product r (r < tpol <= 16); beyond: r * out_pol_off[1]
     int accumulate;               // out += instead of out =
+    // eigenbeam contraction (cpu_simulate.py:461-468): when basis != 0 every value is added as
+    //   conj(C[a1,kk,f]) C[a2,ll,f] V_r            at polarisation slot r, and (kk != ll) as
+    //   conj(C[a1,ll,f]) C[a2,kk,f] V_r            at the feed-transposed slot.
+    int basis, kk, ll, nbasis, ncoef_freq, f_first;
 };
 
 template <typename T, int DIM>
@@ -750,7 +754,8 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ bt0,
     const T *__restrict__ bt1, const T *__restrict__ bt2, const int *__restrict__ bl_idx,
     const signed char *__restrict__ flip, const double *__restrict__ scale, InterpArgs a,
-    KerParams ker, cplx<T> *__restrict__ out) {
+    KerParams ker, cplx<T> *__restrict__ out, const cplx<T> *__restrict__ coef,
+    const int *__restrict__ ant1, const int *__restrict__ ant2) {
     const int tid = threadIdx.x;
     const int g = tid & (GROUP - 1);
     const int lane_base = (tid & 63) & ~(GROUP - 1);
@@ -847,8 +852,30 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
             double vi = (double)sr * pi_ + (double)si * pr;
             if (sg < 0) vi = -vi;  // conj for flipped baselines (cpu_simulate.py:298)
             const int64_t po = r < 16 ? a.out_pol_off[r] : (int64_t)r * a.out_pol_off[1];
-            cplx<T> *o = out + (int64_t)fg * a.out_fg_stride + po + k * a.out_k_stride;
-            if (a.accumulate) {
+            cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + k * a.out_k_stride;
+            cplx<T> *o = ob + po;
+            if (a.basis) {
+                const int f = a.f_first + fg;
+                const int64_t cs1 = (int64_t)ant1[k] * a.nbasis, cs2 = (int64_t)ant2[k] * a.nbasis;
+                const cplx<T> c1k = coef[(cs1 + a.kk) * a.ncoef_freq + f];
+                const cplx<T> c2l = coef[(cs2 + a.ll) * a.ncoef_freq + f];
+                const cplx<double> w1 = cmul(cplx<double>{(double)c1k.re, -(double)c1k.im},
+                                             cplx<double>{(double)c2l.re, (double)c2l.im});
+                const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
+                o->re += (T)v1.re;
+                o->im += (T)v1.im;
+                if (a.kk != a.ll) {
+                    const cplx<T> c1l = coef[(cs1 + a.ll) * a.ncoef_freq + f];
+                    const cplx<T> c2k = coef[(cs2 + a.kk) * a.ncoef_freq + f];
+                    const cplx<double> w2 = cmul(cplx<double>{(double)c1l.re, -(double)c1l.im},
+                                                 cplx<double>{(double)c2k.re, (double)c2k.im});
+                    const cplx<double> v2 = cmul(w2, cplx<double>{vr, vi});
+                    const int rs = (r & 1) * 2 + (r >> 1);  // feed-transposed slot (V.swapaxes(1, 2))
+                    cplx<T> *o2 = ob + a.out_pol_off[rs];
+                    o2->re += (T)v2.re;
+                    o2->im += (T)v2.im;
+                }
+            } else if (a.accumulate) {
                 o->re += (T)vr;
                 o->im += (T)vi;
             } else {
@@ -861,6 +888,13 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
 // ---------------------------------------------------------------------------------------------
 // Host-side plan
 // ---------------------------------------------------------------------------------------------
+// One (k, l) term of the eigenbeam contraction, handed to Nufft3::interp.
+struct BasisTerm {
+    const void *coef;   // device (nant, K, nfreq) complex
+    const int *ant1, *ant2;  // device (nbls) antenna index of each baseline
+    int kk, ll, nbasis, nfreq, f_first;
+};
+
 template <typename T>
 class Nufft3 {
    public:
@@ -1014,7 +1048,7 @@ class Nufft3 {
     void interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
                 const signed char *flip, const double *scale_dev, int nfg, int tpol,
                 cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
-                const int64_t *out_pol_off, bool accumulate);
+                const int64_t *out_pol_off, bool accumulate, const struct BasisTerm *basis = nullptr);
 
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
@@ -1219,9 +1253,22 @@ template <typename T>
 void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
                        const signed char *flip, const double *scale_dev, int nfg, int tpol,
                        cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
-                       const int64_t *out_pol_off, bool accumulate) {
+                       const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis) {
     if (N == 0 || nfg == 0) return;
     InterpArgs a{};
+    const cplx<T> *coef = nullptr;
+    const int *ant1 = nullptr, *ant2 = nullptr;
+    if (basis) {
+        a.basis = 1;
+        a.kk = basis->kk;
+        a.ll = basis->ll;
+        a.nbasis = basis->nbasis;
+        a.ncoef_freq = basis->nfreq;
+        a.f_first = basis->f_first;
+        coef = (const cplx<T> *)basis->coef;
+        ant1 = basis->ant1;
+        ant2 = basis->ant2;
+    }
     a.w = ker.w;
     a.tpol = tpol;
     a.nfg = nfg;
@@ -1247,10 +1294,10 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     const dim3 grid((unsigned)cdiv(items, INTERP_THREADS / GROUP));
     if (dim == 2)
         hipLaunchKernelGGL((k_interp<T, 2>), grid, dim3(INTERP_THREADS), 0, stream, grid_out, N,
-                           bt[0], bt[1], bt[2], bl_idx, flip, scale_dev, a, ker, out);
+                           bt[0], bt[1], bt[2], bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2);
     else
         hipLaunchKernelGGL((k_interp<T, 3>), grid, dim3(INTERP_THREADS), 0, stream, grid_out, N,
-                           bt[0], bt[1], bt[2], bl_idx, flip, scale_dev, a, ker, out);
+                           bt[0], bt[1], bt[2], bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2);
 }
 
 }  // namespace fv

@@ -385,6 +385,8 @@ struct SimBase {
                                 const void *table) = 0;
     virtual void set_beam_pairs(int npairs, const int *bi, const int *bj, const int64_t *off,
                                 const int *idx, const signed char *flipped) = 0;
+    virtual void set_basis(int nant, int K, int nfreq, const void *coefs, const int *ant1,
+                           const int *ant2) = 0;
     virtual void run(int t0, int t1, int f0, int f1, void *out, int out_on_device) = 0;
     virtual void sync() = 0;
     virtual void stats(double *v, int n) = 0;
@@ -437,6 +439,8 @@ class Sim : public SimBase {
         double btc[3], B[3];
     };
     std::vector<Pair> pairs;
+    int nbasis = 0;  // > 0: eigenbeam mode
+    DevBuf d_coefs, d_ant1, d_ant2;
 
     // per-time scratch
     DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scale, d_out, d_mhist,
@@ -542,6 +546,7 @@ class Sim : public SimBase {
         FV_HIP(hipSetDevice(device));
         std::memcpy(rplane.m, R, 9 * sizeof(double));
         nbls = nb;
+        nbasis = 0;
         coplanar = cop != 0;
         h_bls.assign(bls, bls + 3 * nb);
         std::vector<T> tmp(3 * nb);
@@ -608,6 +613,37 @@ class Sim : public SimBase {
             }
             pairs.push_back(std::move(pr));
         }
+    }
+
+    // Eigenbeam mode (cpu_simulate.py:303-470): beams 0..K-1 are basis beams; every (k <= l) term
+    // runs over ALL baselines without flips (:402-404) and is contracted with the coefficients.
+    void set_basis(int nant, int K, int nfreq, const void *coefs, const int *ant1,
+                   const int *ant2) override {
+        FV_HIP(hipSetDevice(device));
+        FV_REQUIRE(polarized, "basis beams need a polarized engine (wrapper.py:280-283)");
+        FV_REQUIRE(nbls > 0 && K >= 1 && K == (int)beams.size(), "set_array and the K basis beams first");
+        FV_REQUIRE(nfreq == (int)freqs.size(), "beam_coefs frequency axis != freqs");
+        for (int64_t b = 0; b < nbls; ++b)
+            FV_REQUIRE(ant1[b] >= 0 && ant1[b] < nant && ant2[b] >= 0 && ant2[b] < nant, "antenna index out of range");
+        nbasis = K;
+        upload(d_coefs, coefs, sizeof(cplx<T>) * (size_t)nant * K * nfreq, 0);
+        upload(d_ant1, ant1, sizeof(int) * nbls, 0);
+        upload(d_ant2, ant2, sizeof(int) * nbls, 0);
+        std::vector<int> bi, bj, idx(nbls);
+        std::vector<int64_t> off(1, 0);
+        std::vector<int> all;
+        std::vector<signed char> fl;
+        for (int k = 0; k < K; ++k)
+            for (int l = k; l < K; ++l) {
+                bi.push_back(k);
+                bj.push_back(l);
+                for (int64_t b = 0; b < nbls; ++b) {
+                    all.push_back((int)b);
+                    fl.push_back(0);
+                }
+                off.push_back((int64_t)all.size());
+            }
+        set_beam_pairs((int)bi.size(), bi.data(), bj.data(), off.data(), all.data(), fl.data());
     }
 
     // Tight box of {2 pi R_plane v : |v| = 1, v_up >= 0} per coordinate.
@@ -813,12 +849,14 @@ class Sim : public SimBase {
                     }
                     size_t e5 = ev_begin(TM_INTERP);
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
+                    BasisTerm bt{d_coefs.p, d_ant1.as<int>(), d_ant2.as<int>(), pr.bi, pr.bj, nbasis,
+                                 (int)freqs.size(), fa};
                     nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
                                   D > 2 ? d_bls.as<T>() + 2 * nbls : nullptr,
                                   pr.trivial ? nullptr : pr.idx->template as<int>(),
                                   pr.trivial ? nullptr : pr.flip->template as<signed char>(),
                                   d_freqs.as<double>() + fa, nfg, tpol, obase,
-                                  (int64_t)nt * per_tf, 1, pol_off, false);
+                                  (int64_t)nt * per_tf, 1, pol_off, false, nbasis ? &bt : nullptr);
                     ev_end(e5);
                     st[4] += (double)pr.n * ntrans;
                     st[6] = nufft->geo.d[0].n2;

@@ -107,6 +107,13 @@ class SimHandle:
         _lib.check(self._L.fv_sim_set_beam_pairs(self._h, len(pairs), _lib.ptr(bi), _lib.ptr(bj),
                                                  _lib.ptr(off), _lib.ptr(idx), _lib.ptr(flp)))
 
+    def set_basis(self, beam_coefs, ant1_idxs, ant2_idxs):
+        c = np.ascontiguousarray(beam_coefs, dtype=self.cdt)
+        a1 = np.ascontiguousarray(ant1_idxs, dtype=np.int32)
+        a2 = np.ascontiguousarray(ant2_idxs, dtype=np.int32)
+        _lib.check(self._L.fv_sim_set_basis(self._h, c.shape[0], c.shape[1], c.shape[2],
+                                            _lib.ptr(c), _lib.ptr(a1), _lib.ptr(a2)))
+
     # -- execution ----------------------------------------------------------------------------
     def out_shape(self, nt, nf):
         return (nf, nt, 2, 2, self.nbls) if self.polarized else (nf, nt, self.nbls)
@@ -211,13 +218,13 @@ class GPUSimulationEngine(SimulationEngine):
         * ``nprocesses/nthreads/force_use_ray/trace_mem/nchunks/source_buffer`` are CPU
           scheduling / memory knobs with no effect on one GPU (``n_threads`` "not used in GPU
           implementation", reference gpu/nufft.py:38);
+        * ``beam_coefs`` (eigenbeams): like the reference, the (l, k) term reuses V_kl transposed
+          (exact for real-valued basis beams, reference cpu_simulate.py:464-468);
         * ``beam_spline_opts`` must ask for order 1 (or be None): higher spline orders are not
           built yet;
         * ``time_idx`` / ``freq_idx`` (extra) restrict the run to a block, which is how ranks
           shard a simulation across GPUs.
         """
-        if beam_coefs is not None:
-            raise NotImplementedError("basis-beam (beam_coefs) path is not built on the GPU yet")
         order = (beam_spline_opts or {}).get("order", 1)
         if order != 1:
             raise NotImplementedError("GPU beam interpolation supports spline order 1 only")
@@ -242,7 +249,20 @@ class GPUSimulationEngine(SimulationEngine):
 
         R, bls, is_coplanar = prepare_array(ants, baselines, flat_array_tol, real_dtype)
         antnums = list(ants.keys())
-        pairs, pair_idx, pair_flip = utils.prepare_beam_evaluation(antnums, baselines, beam_idx)
+        use_basis = beam_coefs is not None
+        if use_basis:
+            if not polarized:  # reference wrapper.py:280-283
+                raise ValueError(
+                    "Basis decomposition is not compatible with unpolarized simulations. Set polarized=True to use beam_coefs."
+                )
+            beam_coefs = np.asarray(beam_coefs)
+            if beam_coefs.shape != (nant, nbeam, nfreqs):
+                raise ValueError("beam_coefs must have shape (nant, nbasis, nfreqs)")
+            # per-baseline antenna rows of beam_coefs (reference cpu_simulate.py:920-921)
+            ant1_idxs = np.array([antnums.index(bl[0]) for bl in baselines])
+            ant2_idxs = np.array([antnums.index(bl[1]) for bl in baselines])
+        else:
+            pairs, pair_idx, pair_flip = utils.prepare_beam_evaluation(antnums, baselines, beam_idx)
 
         h = SimHandle(self.device, precision, eps, upsample_factor, polarized)
         try:
@@ -262,7 +282,10 @@ class GPUSimulationEngine(SimulationEngine):
             h.set_freqs(freqs.astype(float))
             h.set_array(R.astype(float), bls.astype(float), is_coplanar)
             h.set_beams(beam_list, freqs.astype(float))
-            h.set_beam_pairs(pairs, pair_idx, pair_flip)
+            if use_basis:
+                h.set_basis(beam_coefs, ant1_idxs, ant2_idxs)
+            else:
+                h.set_beam_pairs(pairs, pair_idx, pair_flip)
             t0, t1, _ = time_idx.indices(ntimes)
             f0, f1, _ = freq_idx.indices(nfreqs)
             vis = h.run(t0, t1, f0, f1)

@@ -127,6 +127,16 @@ int fv_sim_set_beam_table(fv_sim *h, int beam, int nfreq_tab, int nza, int naz, 
 int fv_sim_set_beam_pairs(fv_sim *h, int npairs, const int *bi, const int *bj, const int64_t *off,
                           const int *idx, const signed char *flipped);
 
+/* Eigenbeam ("basis") mode, _compute_basis_visibilities (cpu_simulate.py:303-470): the handle's
+ * beams 0..nbasis-1 are the K basis beams (E-field; polarized engine only, wrapper.py:280-283);
+ * coefs is beam_coefs (nant, nbasis, nfreq) complex of the handle's precision; ant1/ant2 (nbls)
+ * give each baseline's antenna indices into coefs (:920-921).  Replaces any beam pairs: every
+ * (k <= l) term runs over all baselines without flips (:402-404) and is contracted as
+ * conj(c[a1,k]) c[a2,l] V_kl + [l != k] conj(c[a1,l]) c[a2,k] V_kl^T (:461-468).
+ * Call after fv_sim_set_array, fv_sim_set_freqs and the beams.                                */
+int fv_sim_set_basis(fv_sim *h, int nant, int nbasis, int nfreq, const void *coefs, const int *ant1,
+                     const int *ant2);
+
 /* Run times [t0, t1) x freqs [f0, f1).  Result layout is the reference's FINAL layout
  * (cpu_simulate.py:850-854): polarized (nf_here, nt_here, 2, 2, nbls), else (nf_here, nt_here,
  * nbls), complex of the handle's precision.  out_on_device = 0: `out` is a host buffer (the

@@ -25,5 +25,5 @@ def oracle_simulate(cfg):
     return orc.simulate(
         cfg["ants"], cfg["freqs"], cfg["fluxes"], ob, cfg["ra"], cfg["dec"], cfg["times"],
         cfg["telescope_loc"], baselines=cfg.get("baselines"), beam_idx=cfg.get("beam_idx"),
-        polarized=cfg["polarized"],
+        polarized=cfg["polarized"], beam_coefs=cfg.get("beam_coefs"),
     )
