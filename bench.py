@@ -195,6 +195,16 @@ def main():
         ach = spread_bytes / spread_s / 1e9 if spread_s > 0 else 0.0
         fft_bytes = st["fft_cells"] * 2 * R8  # cells the three pruned-FFT kernels move through HBM
         interp_bytes = st["interp_items"] * 2 * R8
+        # HBM traffic of the spread kernel from the committed PMC run (rocprofv3 counters cannot be
+        # read from inside this process): only for the workload that run was taken on.
+        traffic = None
+        try:
+            if a.workload == "C2" and not (a.nsrc or a.nfreq or a.ntimes):
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
+                k = pm["counters"]["c2"]["k_spread2d"]
+                traffic = (2 * k["FETCH_SIZE_KB_avg_per_launch"] + k["WRITE_SIZE_KB_avg_per_launch"]) * 1024
+        except Exception:
+            traffic = None
         kern = {
             "spread_ms_per_launch": tm["spread"] / launches,
             "fft_ms_per_launch": tm["fft"] / launches,
@@ -234,7 +244,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)" if traffic else None,
                 "algorithmic_bytes_per_launch": spread_bytes / launches,
                 "avg_launch_ms": tm["spread"] / launches,
             },
