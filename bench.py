@@ -50,7 +50,8 @@ def parse():
 
 def cpu_baseline(cfg, seconds: float):
     """Time the CPU port of the reference's per-slice work (oracle/: numpy beam + coherency,
-    type-3 NUFFT port with scipy.fft on all host cores) on a bounded sample of slices."""
+    type-3 NUFFT port = C/OpenMP spread + interp around scipy.fft on all host cores) on a bounded
+    sample of slices, one NUFFT call per (time, frequency) as the reference does."""
     from oracle import cpu_nufft
     from oracle import fftvis_oracle as orc
     from tests.helpers import oracle_beam
@@ -90,8 +91,9 @@ def cpu_baseline(cfg, seconds: float):
         "unit": "visibilities/s",
         "cores": os.cpu_count(),
         "kind": "port",
-        "sample": f"{nslices} (time,freq) slices of the workload in {t_used:.1f} s; numpy "
-                  "spread/interp (1 thread) + scipy.fft on all cores -- CPU restatement, not finufft",
+        "sample": f"{nslices} (time,freq) slices of the workload in {t_used:.1f} s; C/OpenMP "
+                  "spread + interp (oracle/cpu_nufft.c), scipy.fft on all cores, numpy beam/coherency "
+                  "-- CPU restatement of the type-3 NUFFT path, not finufft",
     }
 
 

@@ -14,8 +14,38 @@ Only tests/ and bench.py's cpu_baseline leg may import this.
 
 from __future__ import annotations
 
+import ctypes
+import os
+import subprocess
+
 import numpy as np
 import scipy.fft as sfft
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CLIB = None
+
+
+def _clib():
+    """oracle/libcpunufft.so (C/OpenMP spread + interp); built on demand with oracle/Makefile."""
+    global _CLIB
+    if _CLIB is None:
+        path = os.path.join(_HERE, "libcpunufft.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libcpunufft.so"])
+        _CLIB = ctypes.CDLL(path)
+        _CLIB.cn_spread2d.restype = None
+        _CLIB.cn_interp2d.restype = None
+    return _CLIB
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _nthreads(work: int) -> int:
+    """OpenMP threads for a spread/interp call: one per ~2e6 kernel-cell updates (forking a team
+    for less costs more than it saves), capped at the host's cores."""
+    return int(max(1, min(os.cpu_count() or 1, work // 2_000_000)))
 
 
 def next235even(n: int) -> int:
@@ -76,7 +106,7 @@ def _geom(X, S, sigma, w):
     return n1, n2, h
 
 
-def nufft_type3(coords, c, targets, eps=1e-9, sigma=2.0, isign=+1, workers=-1):
+def nufft_type3(coords, c, targets, eps=1e-9, sigma=2.0, isign=+1, workers=-1, use_c_kernels=True):
     """f[t,k] ~= sum_j c[t,j] exp(isign i s_k.x_j) to relative accuracy ~eps.
 
     coords / targets: lists of d (2 or 3) 1-D arrays; c: (M,) or (ntrans, M).
@@ -108,9 +138,20 @@ def nufft_type3(coords, c, targets, eps=1e-9, sigma=2.0, isign=+1, workers=-1):
         z = a[:, None] + np.arange(w)[None, :] - p[:, None]
         i0.append(a)
         ker.append(es_eval(z, w, beta))
-    grid = np.zeros((ntr,) + tuple(n2[::-1]), dtype=complex)  # [t][(z)][y][x]
     ar = np.arange(w)
-    if d == 2:
+    use_c = d == 2 and use_c_kernels
+    if use_c:
+        pxy = [np.ascontiguousarray((X[i] - xc[i]) / h[i] + n2[i] // 2) for i in range(2)]
+        grid = np.empty((ntr, n2[1], n2[0]), dtype=complex)
+        cpc = np.ascontiguousarray(cp)
+        _clib().cn_spread2d(ctypes.c_int64(M), _vp(pxy[0]), _vp(pxy[1]), _vp(cpc), ctypes.c_int(ntr),
+                            ctypes.c_int(w), ctypes.c_double(beta), ctypes.c_int(n2[0]),
+                            ctypes.c_int(n2[1]), _vp(grid), ctypes.c_int(_nthreads(M * ntr * w * w)))
+    else:
+        grid = np.zeros((ntr,) + tuple(n2[::-1]), dtype=complex)  # [t][(z)][y][x]
+    if use_c:
+        pass
+    elif d == 2:
         wt = ker[1][:, :, None] * ker[0][:, None, :]
         iy = (i0[1][:, None] + ar)[:, :, None] + np.zeros((1, 1, w), np.int64)
         ix = (i0[0][:, None] + ar)[:, None, :] + np.zeros((1, w, 1), np.int64)
@@ -156,7 +197,13 @@ def nufft_type3(coords, c, targets, eps=1e-9, sigma=2.0, isign=+1, workers=-1):
     for i in range(d):
         sgn *= 1.0 - 2.0 * ((n2[i] // 2) % 2)
     out = np.empty((ntr, N), dtype=complex)
-    if d == 2:
+    if use_c:
+        eta = [np.ascontiguousarray((S[i] - sc[i]) * h[i] * n2[i] / (2 * np.pi) + n2[i] // 2) for i in range(2)]
+        gridc = np.ascontiguousarray(grid)
+        _clib().cn_interp2d(ctypes.c_int64(N), _vp(eta[0]), _vp(eta[1]), ctypes.c_int(ntr),
+                            ctypes.c_int(w), ctypes.c_double(beta), ctypes.c_int(n2[0]),
+                            ctypes.c_int(n2[1]), _vp(gridc), _vp(out), ctypes.c_int(_nthreads(N * ntr * w * w)))
+    elif d == 2:
         iy = (j0[1][:, None] + ar)[:, :, None] + np.zeros((1, 1, w), np.int64)
         ix = (j0[0][:, None] + ar)[:, None, :] + np.zeros((1, w, 1), np.int64)
         wt = kq[1][:, :, None] * kq[0][:, None, :]
