@@ -25,6 +25,8 @@
 
 #include "fv_eskernel.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -1038,9 +1040,9 @@ class Nufft3 {
                            scale_dev, cs);
     }
 
-    void spread(int ntrans);
+    void spread(int ntrans, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
     template <int TCH>
-    int launch_spread(int ntrans, int tbegin);
+    int launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e1);
     void buffer_cells(int64_t &c0, int64_t &c1) const;
     void fft(int ntrans);
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
@@ -1058,23 +1060,31 @@ class Nufft3 {
 
 template <typename T>
 template <int TCH>
-int Nufft3<T>::launch_spread(int ntrans, int tbegin) {
+int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e1) {
     const int nchunk = (ntrans - tbegin) / TCH;
     if (nchunk == 0) return tbegin;
     const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
+    // events (profiling only) ride on the dispatch itself: start on the first spread launch of a
+    // transform batch, stop on the last -- no separate marker packets in the queue
+    hipEvent_t es = tbegin == 0 ? e0 : nullptr;
+    hipEvent_t ee = tbegin + nchunk * TCH == ntrans ? e1 : nullptr;
     if (dim == 2) {
         dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)nchunk);
-        hipLaunchKernelGGL((k_spread2d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, M,
-                           i0s.as<int>(), kw.as<T>(), bin_start.as<int>(),
-                           strengths.as<cplx<T>>(), ntrans, tbegin, dec[0].as<T>(), dec[1].as<T>(),
-                           buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0], ker.w);
+        hipExtLaunchKernelGGL((k_spread2d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
+                              (const int *)i0s.as<int>(), (const T *)kw.as<T>(),
+                              (const int *)bin_start.as<int>(),
+                              (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin,
+                              (const T *)dec[0].as<T>(), (const T *)dec[1].as<T>(),
+                              buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0], ker.w);
     } else {
         dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)(z.na * nchunk));
-        hipLaunchKernelGGL((k_spread3d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, M,
-                           i0s.as<int>(), kw.as<T>(), bin_start.as<int>(),
-                           strengths.as<cplx<T>>(), ntrans, tbegin, nchunk, dec[0].as<T>(),
-                           dec[1].as<T>(), dec[2].as<T>(), buf0.as<cplx<T>>(), x.na, y.na, z.na,
-                           geo.nbin[0], geo.nbin[1], ker.w);
+        hipExtLaunchKernelGGL((k_spread3d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
+                              (const int *)i0s.as<int>(), (const T *)kw.as<T>(),
+                              (const int *)bin_start.as<int>(),
+                              (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin, nchunk,
+                              (const T *)dec[0].as<T>(), (const T *)dec[1].as<T>(),
+                              (const T *)dec[2].as<T>(), buf0.as<cplx<T>>(), x.na, y.na, z.na,
+                              geo.nbin[0], geo.nbin[1], ker.w);
     }
     return tbegin + nchunk * TCH;
 }
@@ -1091,16 +1101,16 @@ void Nufft3<T>::buffer_cells(int64_t &c0, int64_t &c1) const {
 }
 
 template <typename T>
-void Nufft3<T>::spread(int ntrans) {
+void Nufft3<T>::spread(int ntrans, hipEvent_t e0, hipEvent_t e1) {
     int64_t c0, c1;
     buffer_cells(c0, c1);
     buf0.reserve(sizeof(cplx<T>) * c0 * ntrans);
     // whole chunks of 16 transforms per thread, then the binary remainder (<= 4 more launches)
-    int t = launch_spread<16>(ntrans, 0);
-    t = launch_spread<8>(ntrans, t);
-    t = launch_spread<4>(ntrans, t);
-    t = launch_spread<2>(ntrans, t);
-    launch_spread<1>(ntrans, t);
+    int t = launch_spread<16>(ntrans, 0, e0, e1);
+    t = launch_spread<8>(ntrans, t, e0, e1);
+    t = launch_spread<4>(ntrans, t, e0, e1);
+    t = launch_spread<2>(ntrans, t, e0, e1);
+    launch_spread<1>(ntrans, t, e0, e1);
 }
 
 // Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision).

@@ -450,7 +450,7 @@ class Sim : public SimBase {
 
     // stats / timing
     double st[10] = {0};
-    bool timing_on = false;
+    int timing_level = 0;  // 1: spread only (events ride on the dispatches), 2: every kernel family
     struct Ev {
         hipEvent_t a, b;
         int kind;
@@ -461,8 +461,19 @@ class Sim : public SimBase {
 
     int dim() const { return coplanar ? 2 : 3; }
 
+    size_t ev_slot(int kind) {
+        if (ev_used == ev_pool.size()) {
+            Ev e;
+            FV_HIP(hipEventCreate(&e.a));
+            FV_HIP(hipEventCreate(&e.b));
+            e.kind = kind;
+            ev_pool.push_back(e);
+        }
+        ev_pool[ev_used].kind = kind;
+        return ev_used++;
+    }
     size_t ev_begin(int kind) {
-        if (!timing_on) return (size_t)-1;
+        if (timing_level < 2) return (size_t)-1;
         if (ev_used == ev_pool.size()) {
             Ev e;
             FV_HIP(hipEventCreate(&e.a));
@@ -833,9 +844,12 @@ class Sim : public SimBase {
                                        nufft->fs.template as<T>(), cs);
                     ev_end(e2);
                     // ---- NUFFT ----------------------------------------------------------
-                    size_t e3 = ev_begin(TM_SPREAD);
-                    nufft->spread(ntrans);
-                    ev_end(e3);
+                    if (timing_level >= 1) {
+                        const size_t e3 = ev_slot(TM_SPREAD);
+                        nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b);
+                    } else {
+                        nufft->spread(ntrans);
+                    }
                     st[0] += 1;
                     st[1] += (double)nufft->geo.cells_a() * ntrans;
                     mhist_log[hist_slot].second += ntrans;
@@ -869,7 +883,7 @@ class Sim : public SimBase {
         if (!out_on_device) {
             FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
             FV_HIP(hipStreamSynchronize(stream));
-            if (timing_on) ev_collect();
+            if (timing_level) ev_collect();
         }
     }
 
@@ -890,7 +904,7 @@ class Sim : public SimBase {
     void sync() override {
         FV_HIP(hipSetDevice(device));
         FV_HIP(hipStreamSynchronize(stream));
-        if (timing_on) ev_collect();
+        if (timing_level) ev_collect();
     }
     void stats(double *v, int n) override {
         // above-horizon counts were left on the device during run(); fold them in now
@@ -913,7 +927,7 @@ class Sim : public SimBase {
         mhist_log.clear();
         ev_used = 0;
     }
-    void enable_timing(int on) override { timing_on = on != 0; }
+    void enable_timing(int level) override { timing_level = level; }
     void timing(double *ms, int n) override {
         for (int i = 0; i < n && i < TM_COUNT; ++i) ms[i] = tm[i];
     }

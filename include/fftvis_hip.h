@@ -152,9 +152,11 @@ int fv_sim_sync(fv_sim *h);
  * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w.                          */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
-/* HIP-event timing of the dominant kernels on the handle's stream (ms, summed since reset):
- * [0] spread, [1] fft, [2] interp, [3] strengths(beam+coherency), [4] rotate/sort; enable first. */
-int fv_sim_enable_timing(fv_sim *h, int on);
+/* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,
+ * [2] interp, [3] strengths (beam + coherency), [4] rotate/sort.  level 0: off; 1: spread only,
+ * events attached to the spread dispatches themselves (no extra queue packets -- cheap enough
+ * for a timed region); 2: every family, bracketed by event records (adds ~10 us bubbles each). */
+int fv_sim_enable_timing(fv_sim *h, int level);
 int fv_sim_timing(fv_sim *h, double *ms, int n);
 
 #ifdef __cplusplus
