@@ -41,7 +41,10 @@ constexpr int FFT_THREADS = 256;
 #define FV_FFT_QMAX_LOG 12
 #endif
 #ifndef FV_FFT_TPR_DIV
-#define FV_FFT_TPR_DIV 16  // threads per row >= Q / this
+#define FV_FFT_TPR_DIV 16  // threads per row >= Q / this (P > 1)
+#endif
+#ifndef FV_FFT_TPR_DIV1
+#define FV_FFT_TPR_DIV1 8  // ... and for single-residue rows (P == 1)
 #endif
 constexpr int FFT_QMAX_LOG = FV_FFT_QMAX_LOG;  // LDS row buffer: Q <= 2^this complex (70 KiB fp64 at 4096)
 constexpr int FFT_NACC = 18;  // outputs a thread of a row-FFT accumulates in registers
@@ -1115,9 +1118,11 @@ void Nufft3<T>::spread(int ntrans, hipEvent_t e0, hipEvent_t e1) {
 
 // Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision).
 inline void rowfft_shape(const DimGeom &g, int &tpr, int &rpw) {
+    // P == 1 (lean kernel, 108 VGPRs): Q/8 threads per row halves the LDS per wave, which is what
+    // limits occupancy there (measured 1.3x on the C2 FFT).  P > 1 is register-bound either way.
+    const int div = g.P == 1 ? FV_FFT_TPR_DIV1 : FV_FFT_TPR_DIV;
     tpr = 16;
-    while (tpr < FFT_THREADS &&
-           (tpr < g.Q / FV_FFT_TPR_DIV || (g.P > 1 && (int64_t)tpr * FFT_NACC < g.no)))
+    while (tpr < FFT_THREADS && (tpr < g.Q / div || (g.P > 1 && (int64_t)tpr * FFT_NACC < g.no)))
         tpr *= 2;
     rpw = FFT_THREADS / tpr;
 }
