@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--ntimes", type=int, default=None)
     p.add_argument("--eps", type=float, default=6e-8)
     p.add_argument("--upsample", type=float, default=2.0)
+    p.add_argument("--path", default="type3", choices=["type3", "type1"],
+                   help="type3 = the benchmarked NUFFT path (BASELINE.json); type1 = the lattice path "
+                        "the reference takes by default on these arrays (reported for comparison)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     return p.parse_args()
@@ -150,7 +153,15 @@ def main():
     h.set_sources_device(nsrc, nfreq, eq.data_ptr(), flux.data_ptr(), pol_sky)
     h.set_times(SiderealRotation(my_times, cfg["telescope_loc"]).matrices())
     h.set_freqs(freqs)
-    h.set_array(R, bls, coplanar)
+    if a.path == "type1":
+        from fftvis_amd.core.antenna_gridding import check_antpos_griddability
+
+        ok, grid, basis = check_antpos_griddability(cfg["ants"])
+        assert ok, "workload array is not a lattice"
+        bint = np.round(np.array([grid[b[1]] - grid[b[0]] for b in baselines]).T).astype(int)
+        h.set_array_type1(basis / utils.speed_of_light, bint, 2 * int(np.abs(bint).max()) + 1)
+    else:
+        h.set_array(R, bls, coplanar)
     h.set_beams([cfg["beam"]], freqs)
     h.set_beam_pairs(pairs, pidx, pflip)
     out = torch.empty(h.out_shape(ntimes, nfreq), dtype=torch.complex128, device=dev)
@@ -245,7 +256,7 @@ def main():
                 "workload": f"{a.workload}: {synth.CONFIGS[a.workload][0]}, {nsrc} sources, "
                             f"{nfreq} freqs, {ntimes} times/GPU, {nbls} baselines, "
                             f"{'polarized table beam' if pol else 'unpolarized Airy beam'}, "
-                            f"type-3 NUFFT eps={a.eps:g} upsampfac={a.upsample:g}",
+                            f"{a.path} NUFFT eps={a.eps:g} upsampfac={a.upsample:g}",
                 "slices_per_step": nfreq * ntimes,
                 "finite_output": finite,
             },

@@ -44,6 +44,7 @@ SYMBOLS = {
     "fv_sim_set_topo": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int]),
     "fv_sim_set_freqs": (c_int, [c_void_p, c_int, c_void_p]),
     "fv_sim_set_array": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
+    "fv_sim_set_array_type1": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
     "fv_sim_set_nbeams": (c_int, [c_void_p, c_int]),
     "fv_sim_set_beam_airy": (c_int, [c_void_p, c_int, c_double]),
     "fv_sim_set_beam_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p]),

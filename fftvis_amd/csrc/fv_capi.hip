@@ -332,6 +332,10 @@ int fv_sim_set_freqs(fv_sim *h, int nfreq, const double *freqs) {
 int fv_sim_set_array(fv_sim *h, const double *R, int64_t nbls, const double *bls, int is_coplanar) {
     FV_SIM_CALL(FV_REQUIRE(R && nbls >= 1 && bls, "bad array"); h->impl->set_array(R, nbls, bls, is_coplanar));
 }
+int fv_sim_set_array_type1(fv_sim *h, const double *basis_matrix, int64_t nbls, const int *bls_int,
+                           int n_modes) {
+    FV_SIM_CALL(FV_REQUIRE(basis_matrix && nbls >= 1 && bls_int, "bad lattice array"); h->impl->set_array_type1(basis_matrix, nbls, bls_int, n_modes));
+}
 int fv_sim_set_nbeams(fv_sim *h, int nbeams) {
     FV_SIM_CALL(FV_REQUIRE(nbeams >= 1, "need at least one beam"); h->impl->set_nbeams(nbeams));
 }

@@ -912,7 +912,7 @@ class Nufft3 {
     int64_t geom_serial = 0;  // bumps whenever the source->cell mapping changes
 
     // device state
-    DevBuf i0u, fu, tile_of, binmeta, bin_start, i0s, fs, perm, kw, scan_tot, scan_off;
+    DevBuf i0u, fu, tile_of, binmeta, bin_start, i0s, fs, perm, kw, scan_tot, scan_off, scan_tot2, scan_off2;
     const int *Mp = nullptr;   // device-side live source count (optional)
     int *oob_ptr = nullptr;
     DevBuf dec[3], tw[3];
@@ -997,20 +997,7 @@ class Nufft3 {
                                y, z, a, i0u.as<int>(), fu.as<T>(), tile_of.as<int>(), counts_p,
                                oob_p);
         }
-        if (nb <= 4096) {
-            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, counts_p,
-                               bin_start.as<int>(), nb);
-        } else {
-            const int nblk = (int)cdiv(nb, 1024);
-            scan_tot.reserve(sizeof(int) * (nblk + 1));
-            scan_off.reserve(sizeof(int) * (nblk + 1));
-            hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(1024), 0, stream, counts_p,
-                               bin_start.as<int>(), scan_tot.as<int>(), nb);
-            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
-                               scan_tot.as<int>(), scan_off.as<int>(), nblk);
-            hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(1024), 0, stream, bin_start.as<int>(),
-                               scan_off.as<int>(), nb);
-        }
+        exclusive_scan(counts_p, bin_start.as<int>(), nb);
         if (M > 0) {
             hipLaunchKernelGGL(k_bin_scatter<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, Mp,
                                dim, i0u.as<int>(), fu.as<T>(), tile_of.as<int>(),
@@ -1018,6 +1005,55 @@ class Nufft3 {
                                perm.as<int>(), kw.as<T>(), ker.w, (T)ker.beta, (T)ker.c);
         }
     }
+
+    // Exclusive scan of n device ints (n + 1 outputs) on the plan's stream.
+    void exclusive_scan(const int *counts_p, int *out, int n) {
+        if (n <= 4096) {
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, counts_p, out, n);
+            return;
+        }
+        const int nblk = (int)cdiv(n, 1024);
+        FV_REQUIRE(nblk <= 1024 * 1024, "scan too large");
+        scan_tot.reserve(sizeof(int) * (nblk + 1));
+        scan_off.reserve(sizeof(int) * (nblk + 1));
+        hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(1024), 0, stream, counts_p, out,
+                           scan_tot.as<int>(), n);
+        if (nblk <= 4096) {
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, scan_tot.as<int>(),
+                               scan_off.as<int>(), nblk);
+        } else {  // one more level (n > 4M)
+            const int nb2 = (int)cdiv(nblk, 1024);
+            scan_tot2.reserve(sizeof(int) * (nb2 + 1));
+            scan_off2.reserve(sizeof(int) * (nb2 + 1));
+            hipLaunchKernelGGL(k_scan_blocks, dim3(nb2), dim3(1024), 0, stream, scan_tot.as<int>(),
+                               scan_off.as<int>(), scan_tot2.as<int>(), nblk);
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, scan_tot2.as<int>(),
+                               scan_off2.as<int>(), nb2);
+            hipLaunchKernelGGL(k_scan_add, dim3(nb2), dim3(1024), 0, stream, scan_off.as<int>(),
+                               scan_off2.as<int>(), nblk);
+        }
+        hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(1024), 0, stream, out, scan_off.as<int>(), n);
+    }
+
+    // Use this plan only as a pruned 2-D FFT engine (type-1 path): geometry given directly.
+    void set_fft_geometry(const DimGeom &gx, const DimGeom &gy) {
+        const DimGeom g[2] = {gx, gy};
+        for (int d = 0; d < 2; ++d) {
+            const bool same = geo.d[d].n2 == g[d].n2 && tw[d].p;
+            geo.d[d] = g[d];
+            if (same) continue;
+            tw[d].reserve(sizeof(cplx<T>) * g[d].n2);
+            hipLaunchKernelGGL(k_twiddle_table<T>, dim3(cdiv(g[d].n2, 256)), dim3(256), 0, stream,
+                               g[d].n2, tw[d].as<cplx<T>>());
+        }
+    }
+    cplx<T> *fft_input(int ntrans) {
+        int64_t c0, c1;
+        buffer_cells(c0, c1);
+        buf0.reserve(sizeof(cplx<T>) * c0 * ntrans);
+        return buf0.as<cplx<T>>();
+    }
+    const cplx<T> *fft_output() const { return grid_out; }
 
     int out_of_box_count() {
         int v = 0;

@@ -269,33 +269,16 @@ struct StrengthArgs {
     BeamDesc bi, bj;
 };
 
-// thread <-> (sorted source p, frequency fgi); fgi fastest so a wave reads flux rows contiguously
-// and writes its tpol strengths back to back:  cs[p][fgi * tpol + r].
+// Strengths of compacted source jc at catalog frequency fidx for one beam pair, times `pre`:
+// tpol values written to dst.
 template <typename T>
-__global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const int *__restrict__ perm,
-                            const int *__restrict__ src_idx, const T *__restrict__ az,
-                            const T *__restrict__ za, const void *__restrict__ flux,
-                            const double *__restrict__ freqs, const int *__restrict__ i0s,
-                            const T *__restrict__ fs, cplx<T> *__restrict__ cs) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)*Mp * a.nfg) return;
-    const int64_t p = idx / a.nfg;
-    const int fgi = (int)(idx % a.nfg);
-    const int fidx = a.f_first + fgi;
+__device__ inline void strength_eval(const StrengthArgs &a, int jc, int fidx, cplx<double> pre,
+                                     const int *__restrict__ src_idx, const T *__restrict__ az,
+                                     const T *__restrict__ za, const void *__restrict__ flux,
+                                     const double *__restrict__ freqs, cplx<T> *__restrict__ dst) {
     const double freq = freqs[fidx];
-    const int jc = perm[p];           // compacted index
     const int64_t js = src_idx[jc];   // catalog index
     const double azv = az[jc], zav = za[jc];
-
-    // type-3 pre-phase exp(i nu btc . x'), x' rebuilt from the sorted grid coordinates
-    double dot = 0.0;
-    for (int d = 0; d < a.dim; ++d) {
-        const double pos = (double)i0s[(int64_t)d * a.M + p] - (double)fs[(int64_t)d * a.M + p];
-        dot += a.btc[d] * (pos - 0.5 * a.na[d]) * a.h[d];
-    }
-    cplx<double> pre = {1.0, 0.0};
-    if (dot != 0.0) sincos(freq * dot, &pre.im, &pre.re);
-
     if (!a.polarized) {
         // cpu_simulate.py:183-187: sqrt(B_i B_j) * I   (principal square root)
         const double bi = eval_power(a.bi, fidx, freq, azv, zav);
@@ -303,7 +286,7 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const in
         const double I = (double)((const T *)flux)[js * a.nfreq + fidx];
         cplx<double> c = cscale(csqrt_principal(cplx<double>{bi * bj, 0.0}), I);
         c = cmul(c, pre);
-        cs[p * a.nfg + fgi] = {(T)c.re, (T)c.im};
+        dst[0] = {(T)c.re, (T)c.im};
         return;
     }
     cplx<double> Ai[4], Aj[4];
@@ -326,10 +309,189 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const in
         const cplx<double> Fj[4] = {Aj[2], Aj[3], Aj[0], Aj[1]};
         coh_AhCB(Fi, C, Fj, o);
     }
-    cplx<T> *dst = cs + (p * a.nfg + fgi) * 4;
     for (int r = 0; r < 4; ++r) {
         const cplx<double> v = cmul(o[r], pre);
         dst[r] = {(T)v.re, (T)v.im};
+    }
+}
+
+// thread <-> (sorted source p, frequency fgi); fgi fastest so a wave reads flux rows contiguously
+// and writes its tpol strengths back to back:  cs[p][fgi * tpol + r].
+template <typename T>
+__global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const int *__restrict__ perm,
+                            const int *__restrict__ src_idx, const T *__restrict__ az,
+                            const T *__restrict__ za, const void *__restrict__ flux,
+                            const double *__restrict__ freqs, const int *__restrict__ i0s,
+                            const T *__restrict__ fs, cplx<T> *__restrict__ cs) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)*Mp * a.nfg) return;
+    const int64_t p = idx / a.nfg;
+    const int fgi = (int)(idx % a.nfg);
+    const int fidx = a.f_first + fgi;
+    // type-3 pre-phase exp(i nu btc . x'), x' rebuilt from the sorted grid coordinates
+    double dot = 0.0;
+    for (int d = 0; d < a.dim; ++d) {
+        const double pos = (double)i0s[(int64_t)d * a.M + p] - (double)fs[(int64_t)d * a.M + p];
+        dot += a.btc[d] * (pos - 0.5 * a.na[d]) * a.h[d];
+    }
+    cplx<double> pre = {1.0, 0.0};
+    if (dot != 0.0) sincos(freqs[fidx] * dot, &pre.im, &pre.re);
+    const int tp = a.polarized ? 4 : 1;
+    strength_eval<T>(a, perm[p], fidx, pre, src_idx, az, za, flux, freqs, cs + (p * a.nfg + fgi) * tp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Type-1 path (lattice arrays): cpu_nufft2d_type1 (cpu/nufft.py:120-175), set-up
+// cpu_simulate.py:661-681, per-slice :964-965,990-992,259-269.
+// Visibility of the integer baseline (bx, by) at frequency nu is mode (bx, by) of a type-1
+// transform of the sources at angles (tx, ty) = nu * 2 pi B^T topo.  Positions depend on nu, so
+// every (source, frequency) pair becomes an entry of its own on that frequency's periodic
+// n2 x n2 grid; entries whose footprint crosses the edge get periodic images.  Spread (same
+// gather scheme as k_spread2d), pruned FFT keeping the n_modes central outputs, then modes are
+// picked and deconvolved -- no gather at non-uniform targets at all.
+// ---------------------------------------------------------------------------------------------
+constexpr int T1_PAD = 16;  // origins run from -PAD .. n2: bins are offset by PAD cells
+
+struct T1Args {
+    int n2, nb1, w, nfg, f_first;
+    int64_t cap;       // stride of xyz
+    int64_t ecap;      // entry capacity
+};
+
+// Footprint origin (and first kernel argument) of compacted source p at frequency f.
+template <typename T>
+__device__ inline void t1_origin(const T1Args &a, const T *__restrict__ xyz, int64_t p, double freq,
+                                 int &i0x, int &i0y, double &fx, double &fy) {
+    const double inv2pi = 0.5 / M_PI;
+    double ux = (double)xyz[p] * freq * inv2pi, uy = (double)xyz[a.cap + p] * freq * inv2pi;
+    ux -= floor(ux + 0.5);  // [-0.5, 0.5)
+    uy -= floor(uy + 0.5);
+    const double px = (ux + 0.5) * a.n2, py = (uy + 0.5) * a.n2;
+    i0x = (int)ceil(px - 0.5 * a.w);
+    i0y = (int)ceil(py - 0.5 * a.w);
+    fx = (double)i0x - px;
+    fy = (double)i0y - py;
+}
+
+// COUNT = true: histogram of entries per (frequency, bin); false: scatter + tabulate weights.
+template <typename T, bool COUNT>
+__global__ void k_t1_bin(T1Args a, const int *__restrict__ Mp, const T *__restrict__ xyz,
+                         const double *__restrict__ freqs, int *__restrict__ counts,
+                         const int *__restrict__ bin_start, int *__restrict__ cursor,
+                         int *__restrict__ i0s, T *__restrict__ kw, int *__restrict__ ent, T beta,
+                         T c4, int *__restrict__ overflow) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)*Mp * a.nfg) return;
+    const int64_t p = idx / a.nfg;
+    const int f = (int)(idx % a.nfg);
+    int i0x, i0y;
+    double fx, fy;
+    t1_origin<T>(a, xyz, p, freqs[a.f_first + f], i0x, i0y, fx, fy);
+    // periodic images: every origin congruent mod n2 whose footprint reaches [0, n2)
+    const int ox[2] = {0, i0x < 0 ? a.n2 : (i0x + a.w > a.n2 ? -a.n2 : 0)};
+    const int oy[2] = {0, i0y < 0 ? a.n2 : (i0y + a.w > a.n2 ? -a.n2 : 0)};
+    for (int iy = 0; iy < (oy[1] ? 2 : 1); ++iy)
+        for (int ix = 0; ix < (ox[1] ? 2 : 1); ++ix) {
+            const int jx = i0x + ox[ix], jy = i0y + oy[iy];
+            const int bin = (f * a.nb1 + ((jy + T1_PAD) >> BINLOG)) * a.nb1 + ((jx + T1_PAD) >> BINLOG);
+            if (COUNT) {
+                atomicAdd(&counts[bin], 1);
+            } else {
+                const int64_t pos = bin_start[bin] + atomicAdd(&cursor[bin], 1);
+                if (pos >= a.ecap) {
+                    atomicAdd(overflow, 1);
+                    continue;
+                }
+                i0s[pos] = jx;
+                i0s[a.ecap + pos] = jy;
+                ent[pos] = (int)idx;  // p * nfg + f
+                T *rx = kw + pos * a.w, *ry = kw + (a.ecap + pos) * a.w;
+                for (int k = 0; k < a.w; ++k) {
+                    rx[k] = es_eval<T>((T)(fx + k), beta, c4);
+                    ry[k] = es_eval<T>((T)(fy + k), beta, c4);
+                }
+            }
+        }
+}
+
+template <typename T>
+__global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent,
+                               const int *__restrict__ ent, const int *__restrict__ src_idx,
+                               const T *__restrict__ az, const T *__restrict__ za,
+                               const void *__restrict__ flux, const double *__restrict__ freqs,
+                               cplx<T> *__restrict__ cs) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *nent) return;
+    const int id = ent[e];
+    const int tp = a.polarized ? 4 : 1;
+    strength_eval<T>(a, id / a.nfg, a.f_first + id % a.nfg, cplx<double>{1.0, 0.0}, src_idx, az, za,
+                     flux, freqs, cs + e * tp);
+}
+
+// One wave per 8x8 cell block of one frequency plane; TP = transforms per plane (1 or 4).
+template <typename T, int TP>
+__global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
+    T1Args a, const int *__restrict__ i0s, const T *__restrict__ kw,
+    const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, cplx<T> *__restrict__ grid) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nbc = a.n2 >> BINLOG;
+    const int bx = blockIdx.x * 4 + wave, by = blockIdx.y, f = blockIdx.z;
+    if (bx >= nbc) return;
+    const int cx = (bx << BINLOG) + (lane & 7), cy = (by << BINLOG) + (lane >> 3);
+    const int *i0x = i0s, *i0y = i0s + a.ecap;
+    const T *kwx = kw, *kwy = kw + a.ecap * a.w;
+    T ar[TP], ai[TP];
+#pragma unroll
+    for (int q = 0; q < TP; ++q) ar[q] = ai[q] = T(0);
+    const int w = a.w;
+    const int bxl = ((bx << BINLOG) - w + 1 + T1_PAD) >> BINLOG, bxh = ((bx << BINLOG) + 7 + T1_PAD) >> BINLOG;
+    const int byl = ((by << BINLOG) - w + 1 + T1_PAD) >> BINLOG, byh = ((by << BINLOG) + 7 + T1_PAD) >> BINLOG;
+    for (int yb = byl; yb <= byh; ++yb) {
+        const int rowb = (f * a.nb1 + yb) * a.nb1;
+        const int s0 = bin_start[rowb + bxl], s1 = bin_start[rowb + bxh + 1];
+        for (int s = s0; s < s1; ++s) {
+            const int dx = cx - i0x[s], dy = cy - i0y[s];
+            T wt = T(0);
+            if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
+                wt = kwx[(int64_t)s * w + dx] * kwy[(int64_t)s * w + dy];
+            const cplx<T> *c = cs + (int64_t)s * TP;
+#pragma unroll
+            for (int q = 0; q < TP; ++q) {
+                const cplx<T> cv = c[q];
+                ar[q] += cv.re * wt;
+                ai[q] += cv.im * wt;
+            }
+        }
+    }
+    const int64_t plane = (int64_t)a.n2 * a.n2;
+    cplx<T> *o = grid + (int64_t)f * TP * plane + (int64_t)cy * a.n2 + cx;
+#pragma unroll
+    for (int q = 0; q < TP; ++q) o[q * plane] = {ar[q], ai[q]};
+}
+
+// vis[f][pol][k] = X_{f,pol}[bx_k][by_k] / (psi_hat(bx) psi_hat(by)); flipped baselines take the
+// negated mode and are conjugated (cpu_simulate.py:259,298).  X is stored [plane][lx][ly].
+template <typename T>
+__global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int nfg, int tp,
+                          const int *__restrict__ blx, const int *__restrict__ bly, int64_t N,
+                          const int *__restrict__ bl_idx, const signed char *__restrict__ flip,
+                          const T *__restrict__ dec, cplx<T> *__restrict__ out,
+                          int64_t out_fg_stride, int64_t p0, int64_t p1, int64_t p2, int64_t p3) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * nfg) return;
+    const int f = (int)(idx / N);
+    const int64_t kl = idx % N;
+    const int64_t k = bl_idx ? bl_idx[kl] : kl;
+    const bool fl = flip && flip[kl];
+    const int mx = fl ? -blx[k] : blx[k], my = fl ? -bly[k] : bly[k];
+    const int lx = mx + no / 2, ly = my + no / 2;
+    const T d = dec[lx] * dec[ly];
+    const int64_t pol[4] = {p0, p1, p2, p3};
+    for (int r = 0; r < tp; ++r) {
+        cplx<T> v = X[(((int64_t)f * tp + r) * no + lx) * no + ly];
+        v = {v.re * d, fl ? -v.im * d : v.im * d};
+        out[(int64_t)f * out_fg_stride + pol[r] + k] = v;
     }
 }
 
@@ -379,6 +541,7 @@ struct SimBase {
     virtual void set_topo(int ntimes, int64_t nsrc, const void *topo, int on_device) = 0;
     virtual void set_freqs(int nfreq, const double *freqs) = 0;
     virtual void set_array(const double *R, int64_t nbls, const double *bls, int coplanar) = 0;
+    virtual void set_array_type1(const double *basis, int64_t nbls, const int *bls_int, int n_modes) = 0;
     virtual void set_nbeams(int n) = 0;
     virtual void set_beam_airy(int b, double diameter) = 0;
     virtual void set_beam_table(int b, int nfreq_tab, int nza, int naz, double za_max,
@@ -440,6 +603,12 @@ class Sim : public SimBase {
     };
     std::vector<Pair> pairs;
     int nbasis = 0;  // > 0: eigenbeam mode
+    // type-1 (lattice) mode
+    bool type1 = false;
+    int t1_nmodes = 0;
+    DevBuf d_blint;  // (2, nbls) int
+    DevBuf t1_meta, t1_binstart, t1_i0s, t1_kw, t1_ent, t1_cs, t1_dec;
+    std::unique_ptr<Nufft3<T>> t1fft;
     DevBuf d_coefs, d_ant1, d_ant2;
 
     // per-time scratch
@@ -558,11 +727,34 @@ class Sim : public SimBase {
         std::memcpy(rplane.m, R, 9 * sizeof(double));
         nbls = nb;
         nbasis = 0;
+        type1 = false;
         coplanar = cop != 0;
         h_bls.assign(bls, bls + 3 * nb);
         std::vector<T> tmp(3 * nb);
         for (int64_t i = 0; i < 3 * nb; ++i) tmp[i] = (T)bls[i];
         upload(d_bls, tmp.data(), sizeof(T) * 3 * nb, 0);
+        pairs.clear();
+    }
+    // Lattice array (cpu_simulate.py:661-681): integer baselines, n_modes = 2 max|bl| + 1 and the
+    // basis matrix in seconds; topo is rotated by basis^T instead of the plane rotation (:964-965).
+    void set_array_type1(const double *basis, int64_t nb, const int *bls_int, int n_modes) override {
+        FV_HIP(hipSetDevice(device));
+        FV_REQUIRE(n_modes >= 1 && n_modes % 2 == 1, "n_modes must be odd");
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) rplane.m[3 * i + j] = basis[3 * j + i];  // basis^T
+        nbls = nb;
+        nbasis = 0;
+        coplanar = true;
+        type1 = true;
+        t1_nmodes = n_modes;
+        h_bls.assign(3 * nb, 0.0);
+        for (int64_t k = 0; k < nb; ++k) {
+            FV_REQUIRE(std::abs(bls_int[k]) <= n_modes / 2 && std::abs(bls_int[nb + k]) <= n_modes / 2,
+                       "integer baseline outside the mode range");
+            h_bls[k] = bls_int[k];
+            h_bls[nb + k] = bls_int[nb + k];
+        }
+        upload(d_blint, bls_int, sizeof(int) * 2 * nb, 0);
         pairs.clear();
     }
     void set_nbeams(int n) override {
@@ -657,6 +849,189 @@ class Sim : public SimBase {
         set_beam_pairs((int)bi.size(), bi.data(), bj.data(), off.data(), all.data(), fl.data());
     }
 
+    // rotate -> horizon cut -> az/za -> 2 pi R topo for time ti; returns the device address of the
+    // live above-horizon count (it never visits the host inside the loop).
+    const int *horizon_step(int ti, int64_t cap, int nblk) {
+        // either R_t . eq on the fly, or topocentric vectors the caller computed
+        const T *vec = ntimes_topo ? d_topo.as<T>() + (size_t)ti * 3 * nsrc : d_eq.as<T>();
+        hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
+                           rots[ti], d_blockcnt.as<int>());
+        if (nblk <= 4096) {
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
+                               d_blockcnt.as<int>(), d_blockoff.as<int>(), nblk);
+        } else {
+            const int nb2 = (int)cdiv(nblk, 1024);
+            d_scan_tot.reserve(sizeof(int) * (nb2 + 1));
+            d_scan_off.reserve(sizeof(int) * (nb2 + 1));
+            hipLaunchKernelGGL(k_scan_blocks, dim3(nb2), dim3(1024), 0, stream,
+                               d_blockcnt.as<int>(), d_blockoff.as<int>(), d_scan_tot.as<int>(), nblk);
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
+                               d_scan_tot.as<int>(), d_scan_off.as<int>(), nb2);
+            hipLaunchKernelGGL(k_scan_add, dim3(nb2), dim3(1024), 0, stream,
+                               d_blockoff.as<int>(), d_scan_off.as<int>(), nblk);
+        }
+        hipLaunchKernelGGL(k_horizon_compact<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
+                           rots[ti], rplane, d_blockoff.as<int>(), d_xyz.as<T>(), cap,
+                           d_az.as<T>(), d_za.as<T>(), d_srcidx.as<int>());
+        const int *Mp = d_blockoff.as<int>() + nblk;
+        d_mhist.reserve(sizeof(int) * rots.size());
+        FV_HIP(hipMemcpyAsync(d_mhist.as<int>() + ti, Mp, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        return Mp;
+    }
+
+    // ---- type-1 run: per time, per frequency batch: bin (source, freq) entries on periodic
+    // n2 x n2 planes, strengths, gather-spread, pruned FFT to the n_modes central modes, pick.
+    void run_type1(int t0, int t1, int f0, int f1, void *out, int out_on_device) {
+        const int nt = t1 - t0, nf = f1 - f0;
+        const int64_t per_tf = (int64_t)tpol * nbls;
+        const size_t out_bytes = sizeof(cplx<T>) * (size_t)nf * nt * per_tf;
+        cplx<T> *dout;
+        if (out_on_device) {
+            dout = (cplx<T> *)out;
+        } else {
+            d_out.reserve(std::max<size_t>(out_bytes, 16));
+            dout = d_out.as<cplx<T>>();
+        }
+        FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
+        if (!t1fft) t1fft.reset(new Nufft3<T>(2, eps, sigma, stream));
+        const KerParams &ker = t1fft->ker;
+        // grid: n2 = P Q >= sigma n_modes (and >= 2 w), all n2 inputs live, n_modes + 1 outputs kept
+        DimGeom g;
+        g.n1 = t1_nmodes;
+        choose_pq(std::max((int)std::ceil(sigma * t1_nmodes), 2 * ker.w + 16), g);
+        g.na = g.n2;
+        g.no = t1_nmodes + 1;
+        t1fft->set_fft_geometry(g, g);
+        t1_dec.reserve(sizeof(T) * g.no);
+        hipLaunchKernelGGL(k_deconv_table<T>, dim3(cdiv(g.no, 256)), dim3(256), 0, stream, g.no,
+                           g.n2, ker, t1_dec.as<T>());
+        const int nb1 = (g.n2 + T1_PAD) >> BINLOG;
+        int64_t pol_off[4] = {0, 0, 0, 0};
+        if (polarized)
+            for (int r = 0; r < 4; ++r) pol_off[r] = (int64_t)((r % 2) * 2 + r / 2) * nbls;
+
+        const int64_t cap = std::max<int64_t>(nsrc, 1);
+        d_xyz.reserve(sizeof(T) * 3 * cap);
+        d_az.reserve(sizeof(T) * cap);
+        d_za.reserve(sizeof(T) * cap);
+        d_srcidx.reserve(sizeof(int) * cap);
+        const int nblk = (int)cdiv(cap, 256);
+        d_blockcnt.reserve(sizeof(int) * (nblk + 1));
+        d_blockoff.reserve(sizeof(int) * (nblk + 1));
+        // frequencies per batch: bounded by entries (~1.3 per (source, freq)) and by grid bytes
+        const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
+        const double budget = eb ? std::atof(eb) : 8.0 * 1024 * 1024 * 1024;
+        const double plane_bytes = 2.0 * g.n2 * (double)g.n2 * tpol * sizeof(cplx<T>);
+        int nfb = (int)std::max(1.0, std::min({(double)nf, budget / plane_bytes, 24.0e6 / (1.3 * cap)}));
+        const int64_t ecap = (int64_t)(1.3 * cap * nfb) + 4096;
+        const int nbins = nfb * nb1 * nb1;
+        t1_meta.reserve(sizeof(int) * (2 * (size_t)(nbins + 1) + 2));
+        t1_binstart.reserve(sizeof(int) * (nbins + 1));
+        t1_i0s.reserve(sizeof(int) * 2 * ecap);
+        t1_kw.reserve(sizeof(T) * 2 * ecap * ker.w);
+        t1_ent.reserve(sizeof(int) * ecap);
+        t1_cs.reserve(sizeof(cplx<T>) * ecap * tpol);
+
+        for (int ti = t0; ti < t1; ++ti) {
+            if (nsrc == 0) continue;
+            size_t e0 = ev_begin(TM_PREP);
+            const int *Mp = horizon_step(ti, cap, nblk);
+            ev_end(e0);
+            mhist_log.push_back({ti, 0.0});
+            const size_t hist_slot = mhist_log.size() - 1;
+            for (int fa = f0; fa < f1; fa += nfb) {
+                const int nfg = std::min(nfb, f1 - fa);
+                T1Args a{};
+                a.n2 = g.n2;
+                a.nb1 = nb1;
+                a.w = ker.w;
+                a.nfg = nfg;
+                a.f_first = fa;
+                a.cap = cap;
+                a.ecap = ecap;
+                const int nbn = nfg * nb1 * nb1;
+                int *counts_p = t1_meta.as<int>(), *cursor_p = counts_p + (nbins + 1),
+                    *ovf_p = cursor_p + (nbins + 1);
+                size_t e1 = ev_begin(TM_PREP);
+                FV_HIP(hipMemsetAsync(t1_meta.p, 0, sizeof(int) * (2 * (size_t)(nbins + 1) + 2), stream));
+                const dim3 gb((unsigned)cdiv(cap * nfg, 256));
+                hipLaunchKernelGGL((k_t1_bin<T, true>), gb, dim3(256), 0, stream, a, Mp, d_xyz.as<T>(),
+                                   d_freqs.as<double>(), counts_p, (const int *)nullptr, cursor_p,
+                                   (int *)nullptr, (T *)nullptr, (int *)nullptr, (T)ker.beta, (T)ker.c, ovf_p);
+                t1fft->exclusive_scan(counts_p, t1_binstart.as<int>(), nbn);
+                hipLaunchKernelGGL((k_t1_bin<T, false>), gb, dim3(256), 0, stream, a, Mp, d_xyz.as<T>(),
+                                   d_freqs.as<double>(), counts_p, (const int *)t1_binstart.as<int>(),
+                                   cursor_p, t1_i0s.as<int>(), t1_kw.as<T>(), t1_ent.as<int>(),
+                                   (T)ker.beta, (T)ker.c, ovf_p);
+                ev_end(e1);
+                const int *nent = t1_binstart.as<int>() + nbn;
+                for (const Pair &pr : pairs) {
+                    if (pr.n == 0) continue;
+                    size_t e2 = ev_begin(TM_STRENGTHS);
+                    StrengthArgs sa{};
+                    sa.M = cap;
+                    sa.nfg = nfg;
+                    sa.f_first = fa;
+                    sa.nfreq = nfreq_cat;
+                    sa.polarized = polarized;
+                    sa.pol_sky = pol_sky;
+                    sa.same_beam = pr.bi == pr.bj;
+                    sa.dim = 2;
+                    sa.bi = desc(pr.bi);
+                    sa.bj = desc(pr.bj);
+                    hipLaunchKernelGGL(k_t1_strengths<T>, dim3(cdiv(ecap, 256)), dim3(256), 0, stream,
+                                       sa, nent, (const int *)t1_ent.as<int>(), d_srcidx.as<int>(),
+                                       d_az.as<T>(), d_za.as<T>(), d_flux.p, d_freqs.as<double>(),
+                                       t1_cs.as<cplx<T>>());
+                    ev_end(e2);
+                    const int nplanes = nfg * tpol;
+                    cplx<T> *A = t1fft->fft_input(nplanes);
+                    size_t e3 = ev_begin(TM_SPREAD);
+                    const dim3 gs((unsigned)cdiv(g.n2 >> BINLOG, 4), (unsigned)(g.n2 >> BINLOG), (unsigned)nfg);
+                    if (polarized)
+                        hipLaunchKernelGGL((k_t1_spread<T, 4>), gs, dim3(SPREAD_THREADS), 0, stream, a,
+                                           (const int *)t1_i0s.as<int>(), (const T *)t1_kw.as<T>(),
+                                           (const int *)t1_binstart.as<int>(),
+                                           (const cplx<T> *)t1_cs.as<cplx<T>>(), A);
+                    else
+                        hipLaunchKernelGGL((k_t1_spread<T, 1>), gs, dim3(SPREAD_THREADS), 0, stream, a,
+                                           (const int *)t1_i0s.as<int>(), (const T *)t1_kw.as<T>(),
+                                           (const int *)t1_binstart.as<int>(),
+                                           (const cplx<T> *)t1_cs.as<cplx<T>>(), A);
+                    ev_end(e3);
+                    st[0] += 1;
+                    st[1] += (double)g.n2 * g.n2 * nplanes;
+                    mhist_log[hist_slot].second += nplanes;
+                    size_t e4 = ev_begin(TM_FFT);
+                    t1fft->fft(nplanes);
+                    ev_end(e4);
+                    st[3] += ((double)g.n2 * g.n2 + 2.0 * g.no * g.n2 + (double)g.no * g.no) * nplanes;
+                    size_t e5 = ev_begin(TM_INTERP);
+                    cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
+                    hipLaunchKernelGGL(k_t1_pick<T>, dim3(cdiv(pr.n * nfg, 256)), dim3(256), 0, stream,
+                                       t1fft->fft_output(), g.no, nfg, tpol, (const int *)d_blint.as<int>(),
+                                       (const int *)d_blint.as<int>() + nbls, pr.n,
+                                       pr.trivial ? (const int *)nullptr : (const int *)pr.idx->template as<int>(),
+                                       pr.trivial ? (const signed char *)nullptr
+                                                  : (const signed char *)pr.flip->template as<signed char>(),
+                                       (const T *)t1_dec.as<T>(), obase, (int64_t)nt * per_tf, pol_off[0],
+                                       pol_off[1], pol_off[2], pol_off[3]);
+                    ev_end(e5);
+                    st[4] += (double)pr.n * nplanes;
+                    st[6] = g.n2;
+                    st[7] = g.n2;
+                    st[8] = g.n2 * 65536.0 + g.n2;
+                    st[9] = ker.w;
+                }
+            }
+        }
+        if (!out_on_device) {
+            FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
+            FV_HIP(hipStreamSynchronize(stream));
+            if (timing_level) ev_collect();
+        }
+    }
+
     // Tight box of {2 pi R_plane v : |v| = 1, v_up >= 0} per coordinate.
     void source_box(double *xc, double *X) const {
         for (int d = 0; d < 3; ++d) {
@@ -710,6 +1085,10 @@ class Sim : public SimBase {
         FV_REQUIRE(0 <= f0 && f0 <= f1 && f1 <= (int)freqs.size(), "freq range");
         FV_REQUIRE((int)freqs.size() == nfreq_cat, "flux frequency axis != freqs");
         for (const Beam &b : beams) FV_REQUIRE(b.kind >= 0, "beam not set");
+        if (type1) {
+            run_type1(t0, t1, f0, f1, out, out_on_device);
+            return;
+        }
         const int nt = t1 - t0, nf = f1 - f0;
         const int D = dim();
         const int64_t per_tf = (int64_t)tpol * nbls;   // elements per (freq, time)
@@ -770,32 +1149,8 @@ class Sim : public SimBase {
             // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
             size_t e0 = ev_begin(TM_PREP);
             if (nsrc == 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
-            // either R_t . eq on the fly, or topocentric vectors the caller computed
-            const T *vec = ntimes_topo ? d_topo.as<T>() + (size_t)ti * 3 * nsrc : d_eq.as<T>();
-            hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
-                               rots[ti], d_blockcnt.as<int>());
-            if (nblk <= 4096) {
-                hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
-                                   d_blockcnt.as<int>(), d_blockoff.as<int>(), nblk);
-            } else {
-                const int nb2 = (int)cdiv(nblk, 1024);
-                d_scan_tot.reserve(sizeof(int) * (nb2 + 1));
-                d_scan_off.reserve(sizeof(int) * (nb2 + 1));
-                hipLaunchKernelGGL(k_scan_blocks, dim3(nb2), dim3(1024), 0, stream,
-                                   d_blockcnt.as<int>(), d_blockoff.as<int>(), d_scan_tot.as<int>(), nblk);
-                hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
-                                   d_scan_tot.as<int>(), d_scan_off.as<int>(), nb2);
-                hipLaunchKernelGGL(k_scan_add, dim3(nb2), dim3(1024), 0, stream,
-                                   d_blockoff.as<int>(), d_scan_off.as<int>(), nblk);
-            }
-            hipLaunchKernelGGL(k_horizon_compact<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
-                               rots[ti], rplane, d_blockoff.as<int>(), d_xyz.as<T>(), cap,
-                               d_az.as<T>(), d_za.as<T>(), d_srcidx.as<int>());
-            // The live count M stays on the device (no host round trip): kernels read *Mp.
-            const int *Mp = d_blockoff.as<int>() + nblk;
+            const int *Mp = horizon_step(ti, cap, nblk);
             const int64_t M = cap;  // capacity: array stride and launch bound
-            d_mhist.reserve(sizeof(int) * rots.size());
-            FV_HIP(hipMemcpyAsync(d_mhist.as<int>() + ti, Mp, sizeof(int), hipMemcpyDeviceToDevice, stream));
             ev_end(e0);
             size_t hist_slot = mhist_log.size();
             mhist_log.push_back({ti, 0.0});

@@ -18,6 +18,7 @@ import numpy as np
 
 from .. import _lib
 from ..core import utils
+from ..core.antenna_gridding import check_antpos_griddability
 from ..core.beams import describe_beam
 from ..core.coords import SiderealRotation, eq_unit_vectors, julian_dates
 from ..core.simulate import SimulationEngine, default_accuracy_dict
@@ -78,6 +79,13 @@ class SimHandle:
         self.nbls = b.shape[1]
         _lib.check(self._L.fv_sim_set_array(self._h, _lib.ptr(R), self.nbls, _lib.ptr(b),
                                             int(is_coplanar)))
+
+    def set_array_type1(self, basis_matrix, bls_int, n_modes: int):
+        B = np.ascontiguousarray(basis_matrix, dtype=np.float64)
+        b = np.ascontiguousarray(bls_int[:2], dtype=np.int32)
+        self.nbls = b.shape[1]
+        _lib.check(self._L.fv_sim_set_array_type1(self._h, _lib.ptr(B), self.nbls, _lib.ptr(b),
+                                                  int(n_modes)))
 
     def set_beams(self, beam_list, freqs):
         _lib.check(self._L.fv_sim_set_nbeams(self._h, len(beam_list)))
@@ -195,7 +203,7 @@ class GPUSimulationEngine(SimulationEngine):
         coord_method: str = "SiderealRotation",
         coord_method_params: dict | None = None,
         force_use_ray: bool = False,
-        force_use_type3: bool = True,
+        force_use_type3: bool = False,
         trace_mem: bool = False,
         enable_memory_monitor: bool = False,
         nchunks: int = 1,
@@ -210,8 +218,9 @@ class GPUSimulationEngine(SimulationEngine):
         Same arguments and return value as ``CPUSimulationEngine.simulate``
         (reference cpu_simulate.py:537-854).  Differences, all documented in DESIGN.md:
 
-        * always the type-3 path (``force_use_type3`` is accepted; the type-1 lattice path is
-          not built yet);
+        * like the reference, a flat array whose antennas sit on a lattice takes the type-1 path
+          unless ``force_use_type3`` (cpu_simulate.py:634-637); eigenbeam runs always use type 3
+          here;
         * ``coord_method`` defaults to this package's ``SiderealRotation`` because matvis /
           ERFA are not importable here; a caller holding a matvis coordinate manager can pass
           it as ``coord_mgr`` and its per-time topocentric vectors are used verbatim;
@@ -247,7 +256,19 @@ class GPUSimulationEngine(SimulationEngine):
         if coherency.shape[0] != ra.size or coherency.shape[1] != nfreqs:
             raise ValueError("fluxes must have shape (nsources, nfreqs[, 4])")
 
-        R, bls, is_coplanar = prepare_array(ants, baselines, flat_array_tol, real_dtype)
+        # lattice arrays -> type 1 (reference cpu_simulate.py:634-637, 661-681)
+        antvecs = np.array([ants[a] for a in ants], dtype=real_dtype)
+        is_gridded = False
+        if not force_use_type3 and beam_coefs is None and np.abs(antvecs[:, -1]).max() <= flat_array_tol:
+            is_gridded, gridded_antpos, basis_matrix = check_antpos_griddability(ants)
+        if is_gridded:
+            bls_int = np.round(np.array(
+                [gridded_antpos[bl[1]] - gridded_antpos[bl[0]] for bl in baselines]).T).astype(int)
+            bls_int = bls_int.reshape(3, len(baselines))
+            n_modes = 2 * int(np.round(np.max(np.abs(bls_int)))) + 1 if len(baselines) else 1
+            basis_matrix = (basis_matrix / utils.speed_of_light).astype(real_dtype)
+        else:
+            R, bls, is_coplanar = prepare_array(ants, baselines, flat_array_tol, real_dtype)
         antnums = list(ants.keys())
         use_basis = beam_coefs is not None
         if use_basis:
@@ -280,7 +301,11 @@ class GPUSimulationEngine(SimulationEngine):
             else:
                 raise ValueError(f"unknown coord_method {coord_method!r}")
             h.set_freqs(freqs.astype(float))
-            h.set_array(R.astype(float), bls.astype(float), is_coplanar)
+            if is_gridded:
+                logger.info("Using gridded coordinates for the array. Type 1 transform will be used.")
+                h.set_array_type1(basis_matrix.astype(float), bls_int, n_modes)
+            else:
+                h.set_array(R.astype(float), bls.astype(float), is_coplanar)
             h.set_beams(beam_list, freqs.astype(float))
             if use_basis:
                 h.set_basis(beam_coefs, ant1_idxs, ant2_idxs)

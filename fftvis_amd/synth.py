@@ -125,5 +125,5 @@ def make_config(name: str, seed: int = 0, nsrc=None, nfreq=None, ntimes=None):
     return dict(
         ants=ants, fluxes=flux, ra=ra, dec=dec, freqs=freqs, times=times, beam=beam,
         telescope_loc=(HERA_LAT, HERA_LON), baselines=all_cross_baselines(ants), polarized=pol,
-        precision=2, eps=6e-8,
+        precision=2, eps=6e-8, force_use_type3=True,  # the benchmark path is the type-3 NUFFT
     )

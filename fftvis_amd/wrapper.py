@@ -62,7 +62,7 @@ def simulate_vis(
     nthreads: int | None = None,
     coord_method: str = "SiderealRotation",
     coord_method_params: dict | None = None,
-    force_use_type3: bool = True,
+    force_use_type3: bool = False,
     force_use_ray: bool = False,
     trace_mem: bool = False,
     backend: str = "gpu",

@@ -110,6 +110,15 @@ int fv_sim_set_freqs(fv_sim *h, int nfreq, const double *freqs);
 int fv_sim_set_array(fv_sim *h, const double *rotation_matrix, int64_t nbls, const double *bls,
                      int is_coplanar);
 
+/* Lattice ("gridded") array: the type-1 path the reference takes by default for flat arrays whose
+ * antennas sit on a lattice (cpu_simulate.py:634-637, 661-681; cpu_nufft2d_type1,
+ * cpu/nufft.py:120-175).  basis_matrix (3,3) float64 in SECONDS (= lattice basis / (factor c),
+ * :676) -- topo is rotated by its transpose (:964-965); bls_int (2, nbls) int32 lattice
+ * coordinates of each baseline (:666-670); n_modes = 2 max|bls_int| + 1 (:673).  Alternative to
+ * fv_sim_set_array; results equal the type-3 path's to the NUFFT accuracy.                     */
+int fv_sim_set_array_type1(fv_sim *h, const double *basis_matrix, int64_t nbls, const int *bls_int,
+                           int n_modes);
+
 /* Beams (evaluate_beam, cpu/beams.py:12-89).  kind 0: analytic Airy dish, param[0] = diameter
  * [m]; E-field 2 J1(x)/x in all four Jones slots, power beam = its square.
  * kind 1: tabulated on a regular (za, az) grid, order-1 interpolation; table is

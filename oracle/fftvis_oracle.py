@@ -521,15 +521,52 @@ def get_task_chunks(nprocesses, nfreqs, ntimes):
     return nprocesses, fch, tch, nf, nt
 
 
+def check_antpos_griddability(antpos, tol=1e-9, max_denominator=10**6, max_factor=1000):
+    """Lattice test of core/antenna_gridding.py:139-219 (with find_lattice_basis :74-137,
+    can_scale_to_int :38-72, find_integer_multiplier :6-35)."""
+    from fractions import Fraction
+    from math import lcm
+
+    keys = list(antpos)
+    antvecs = np.array([antpos[a] for a in keys], dtype=float)
+    xy = antvecs[:, :2]
+    blvec = np.reshape(xy[:, None, :] - xy[None, :, :], (-1, 2))
+    norms = np.linalg.norm(blvec, axis=1)
+    mask = norms > tol
+    if not np.any(mask):
+        return False, antpos, np.eye(3)
+    blvec = blvec[mask][np.argsort(norms[mask])]
+    b1 = blvec[0]
+    b2 = None
+    for v in blvec[1:]:
+        if abs(b1[0] * v[1] - b1[1] * v[0]) > tol:
+            b2 = v
+            break
+    basis2 = np.vstack([b1, np.array([0, 1])]) if b2 is None else np.column_stack([b1, b2])
+    basis = np.zeros((3, 3))
+    basis[:2, :2] = basis2
+    basis[2, 2] = 1.0
+    mod = np.linalg.solve(basis, (antvecs - antvecs[0]).T).T
+    dens = [Fraction(v).limit_denominator(max_denominator).denominator for v in np.ravel(mod) if v != 0]
+    f = lcm(*dens) if dens else 1
+    if f > max_factor:
+        return False, antpos, np.eye(3)
+    scaled = f * mod
+    if not np.allclose(scaled, np.round(scaled), atol=tol):
+        return False, antpos, np.eye(3)
+    return True, {a: np.round(scaled[i]).astype(int) for i, a in enumerate(keys)}, basis / f
+
+
 # ---------------------------------------------------------------------------
 # The hot loop and its caller                              cpu/cpu_simulate.py
 # ---------------------------------------------------------------------------
 def evaluate_vis_chunk(
     time_idx, freq_idx, beam_list, coord_mgr, rotation_matrix, antnums, baselines, bls,
     freqs, nfeeds, beam_idx=None, polarized=False, polarized_sky_model=False,
-    is_coplanar=False, nchunks=1, beam_coefs=None,
+    is_coplanar=False, nchunks=1, beam_coefs=None, use_type1=False, basis_matrix=None,
+    type1_n_modes=None,
 ):
-    """_evaluate_vis_chunk (cpu_simulate.py:856-1071), type-3 branch only.
+    """_evaluate_vis_chunk (cpu_simulate.py:856-1071), type-3 and type-1 branches.
 
     Returns the reference's scratch layout (nt_here, nbls, nfeeds, nfeeds, nf_here).
     """
@@ -557,18 +594,22 @@ def evaluate_vis_chunk(
             az, za = enu_to_az_za(topo[0], topo[1], orientation="uvbeam")  # :957-959
             if not rot_is_identity:
                 inplace_rot(rotation_matrix, topo)  # :961-962
+            if basis_matrix is not None:
+                inplace_rot(basis_matrix.T, topo)  # :964-965
             topo *= 2 * np.pi  # :967
             for floc, fi in enumerate(f_range):
                 freq = freqs[fi]
-                uvw = bls * freq  # :973
+                uvw = None if use_type1 else bls * freq  # :972-973
+                tx = topo[0] * freq if use_type1 else None  # :990-992
+                ty = topo[1] * freq if use_type1 else None
                 bev = [
                     evaluate_beam(b, az, za, polarized, freq).astype(complex)
                     for b in beam_list
                 ]  # :975-984
                 if use_basis:
                     vis[tloc, :, :, :, floc] += compute_basis_visibilities(
-                        bev, flux, a1, a2, beam_coefs, fi, topo, uvw, bls, None, None,
-                        nbls, nfeeds, False, is_coplanar, None, polarized,
+                        bev, flux, a1, a2, beam_coefs, fi, topo, uvw, bls, tx, ty,
+                        nbls, nfeeds, use_type1, is_coplanar, type1_n_modes, polarized,
                         polarized_sky_model,
                     )  # :998-1024
                 else:
@@ -580,8 +621,8 @@ def evaluate_vis_chunk(
                             bev, bi, bj, flux, fi, polarized, polarized_sky_model, nfeeds
                         )
                         v = run_nufft(
-                            c, topo, uvw, bls, pair_flip[(bi, bj)], idxs, False,
-                            is_coplanar, None, None, None, nfeeds,
+                            c, topo, uvw, bls, pair_flip[(bi, bj)], idxs, use_type1,
+                            is_coplanar, tx, ty, type1_n_modes, nfeeds,
                         )
                         vis[tloc, idxs, :, :, floc] += v  # :1069
     return vis
@@ -590,10 +631,11 @@ def evaluate_vis_chunk(
 def simulate(
     ants, freqs, fluxes, beam_list, ra, dec, times, telescope_loc, baselines=None,
     beam_idx=None, polarized=False, flat_array_tol=1e-6, nchunks=1, beam_coefs=None,
-    coord_mgr=None,
+    coord_mgr=None, force_use_type3=True,
 ):
-    """CPUSimulationEngine.simulate (cpu_simulate.py:537-854), force_use_type3=True,
-    nprocesses=1, precision=2.  Returns (nf, nt, nbls) or (nf, nt, 2, 2, nbls)."""
+    """CPUSimulationEngine.simulate (cpu_simulate.py:537-854), nprocesses=1, precision=2;
+    ``force_use_type3=False`` takes the reference's type-1 branch for griddable flat arrays
+    (:634-637, :661-681).  Returns (nf, nt, nbls) or (nf, nt, 2, 2, nbls)."""
     freqs = np.asarray(freqs, dtype=float)
     nfeeds = 2 if polarized else 1
     if baselines is None:
@@ -602,13 +644,27 @@ def simulate(
     antnums = list(ants.keys())
     key2idx = {a: i for i, a in enumerate(antnums)}
     antvecs = np.array([ants[a] for a in ants], dtype=float)
-    R = np.ascontiguousarray(get_plane_to_xy_rotation_matrix(antvecs).T)  # :642-643
-    rot = R @ antvecs.T
-    bls = np.array(
-        [rot[:, key2idx[b[1]]] - rot[:, key2idx[b[0]]] for b in baselines]
-    ).T.reshape(3, len(baselines))  # :650-652
-    is_coplanar = bool(np.all(np.abs(bls[2]) <= flat_array_tol))  # :655
-    bls = bls / speed_of_light  # :658
+    if np.abs(antvecs[:, -1]).max() > flat_array_tol or force_use_type3:  # :634-637
+        is_gridded = False
+    else:
+        is_gridded, gridded_antpos, basis_matrix = check_antpos_griddability(ants)
+    n_modes = None
+    if not is_gridded:
+        basis_matrix = None
+        R = np.ascontiguousarray(get_plane_to_xy_rotation_matrix(antvecs).T)  # :642-643
+        rot = R @ antvecs.T
+        bls = np.array(
+            [rot[:, key2idx[b[1]]] - rot[:, key2idx[b[0]]] for b in baselines]
+        ).T.reshape(3, len(baselines))  # :650-652
+        is_coplanar = bool(np.all(np.abs(bls[2]) <= flat_array_tol))  # :655
+        bls = bls / speed_of_light  # :658
+    else:
+        bls = np.array([gridded_antpos[b[1]] - gridded_antpos[b[0]] for b in baselines]).T  # :666-669
+        bls = np.round(bls).astype(int).reshape(3, len(baselines))
+        n_modes = 2 * int(np.round(np.max(np.abs(bls)))) + 1  # :673
+        basis_matrix = basis_matrix / speed_of_light  # :676
+        is_coplanar = True
+        R = np.eye(3)  # :681
     if coord_mgr is None:
         chunk_size = int(np.ceil(np.size(dec) / nchunks))  # :691
         coord_mgr = SimpleCoordinateRotation(
@@ -618,6 +674,7 @@ def simulate(
         slice(None), slice(None), beam_list, coord_mgr, R, antnums, baselines, bls, freqs,
         nfeeds, beam_idx=beam_idx, polarized=polarized, polarized_sky_model=pol_sky,
         is_coplanar=is_coplanar, nchunks=nchunks, beam_coefs=beam_coefs,
+        use_type1=is_gridded, basis_matrix=basis_matrix, type1_n_modes=n_modes,
     )
     if polarized:
         return np.transpose(vis, (4, 0, 2, 3, 1))  # :851

@@ -26,4 +26,5 @@ def oracle_simulate(cfg):
         cfg["ants"], cfg["freqs"], cfg["fluxes"], ob, cfg["ra"], cfg["dec"], cfg["times"],
         cfg["telescope_loc"], baselines=cfg.get("baselines"), beam_idx=cfg.get("beam_idx"),
         polarized=cfg["polarized"], beam_coefs=cfg.get("beam_coefs"),
+        force_use_type3=cfg.get("force_use_type3", True),
     )

@@ -387,3 +387,39 @@ def test_sim_empty_sky_and_errors(gpu):
         fftvis_amd.simulate_vis(**dict(cfg, fluxes=np.ones((20, 8, 4))))
     with pytest.raises(NotImplementedError):
         fftvis_amd.simulate_vis(**dict(cfg, beam_spline_opts={"order": 3}))
+
+
+def test_sim_type1_lattice_path(gpu):
+    """Lattice arrays take the type-1 path by default (reference cpu_simulate.py:634-637,661-681);
+    it must agree with the type-3 path and with the oracle (reference tests/test_cpu_simulate.py
+    :199-271: hex-7 and 3x3 square grids, sheared, antennas removed)."""
+    c1 = dict(synth.make_config("C1"))
+    c1.pop("force_use_type3")
+    freqs = c1["freqs"]
+    t3 = fftvis_amd.simulate_vis(**c1, force_use_type3=True)
+    t1 = fftvis_amd.simulate_vis(**c1)  # griddable hex -> type 1
+    exp = oracle_simulate(dict(c1, force_use_type3=False))
+    assert rel_l2(t1, exp) < TOL and rel_l2(t1, t3) < 2 * TOL
+    # polarized table beam + polarized sky + two beams with a flipped baseline and an auto
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs), freqs)
+    tab2 = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, diameter=12.0), freqs)
+    _, _, fl4 = synth.catalog(100, freqs, 0, polarized_sky=True)
+    bidx = np.array([0, 1, 0, 1, 1, 0, 1])
+    cfg = dict(c1, polarized=True, beam=[tab, tab2], beam_idx=bidx, fluxes=fl4,
+               baselines=c1["baselines"] + [(3, 0), (6, 1), (2, 2)])
+    got = fftvis_amd.simulate_vis(**cfg)
+    assert rel_l2(got, oracle_simulate(dict(cfg, force_use_type3=False))) < TOL
+    # 3x3 square grid, sheared, one antenna removed
+    shear = np.array([[1.0, 0.3, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    sq = {i * 3 + j: shear @ np.array([14.6 * i, 14.6 * j, 0.0]) for i in range(3) for j in range(3)}
+    sq.pop(4)
+    cfgs = dict(c1, ants=sq, baselines=[(a, b) for a in sq for b in sq if a <= b])
+    got = fftvis_amd.simulate_vis(**cfgs)
+    assert rel_l2(got, oracle_simulate(dict(cfgs, force_use_type3=False))) < TOL
+    assert rel_l2(got, fftvis_amd.simulate_vis(**cfgs, force_use_type3=True)) < 2 * TOL
+    # fp32 and the larger HERA-37 lattice on a reduced catalog
+    c2 = dict(synth.make_config("C2", nsrc=2000, nfreq=6, ntimes=2))
+    c2.pop("force_use_type3")
+    assert rel_l2(fftvis_amd.simulate_vis(**c2), oracle_simulate(dict(c2, force_use_type3=False))) < TOL
+    g32 = fftvis_amd.simulate_vis(**dict(c1, precision=1, eps=1e-4))
+    assert g32.dtype == np.complex64 and rel_l2(g32, exp) < 5e-3
