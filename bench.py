@@ -229,7 +229,7 @@ def main():
         fft_bytes = st_all["fft_cells"] * 2 * R8
         kern = {
             "note": "per-family times from one extra step with event records around every launch",
-            "spread_ms_per_launch": tm["spread"] / launches,
+            "spread_ms_per_launch": (tm["spread"] / launches) if a.path == "type3" else tm_all["spread"] / l2,
             "fft_ms_per_launch": tm_all["fft"] / l2,
             "interp_ms_per_launch": tm_all["interp"] / l2,
             "strengths_ms_per_launch": tm_all["strengths"] / l2,
