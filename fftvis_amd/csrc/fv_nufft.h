@@ -608,115 +608,6 @@ __global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restric
     }
 }
 
-// --- pruned row FFT, whole row resident in LDS ---------------------------------------------------
-// Same transform as k_rowfft, for rows whose n2 = P * Q elements fit the CU's LDS (n2 <~ 9000
-// in fp64).  The radix-P stage is done as decimation in FREQUENCY while loading:
-//     sub_p[q] = sum_k in[q + k Q] tw[(q + k Q) p]      (inputs beyond n_in are zero, so k < ~P/2)
-// after which X[P k' + p] = FFT_Q(sub_p)[k'].  All P sub-arrays then go through the radix-16/8
-// DIF passes together (n2 / R butterfly groups per pass over up to 1024 threads), and every kept
-// output is read straight from LDS: no accumulators, one contiguous store per output.
-struct RowFftFullArgs {
-    int n_in, n_out, n2, P, Q, logQ, tpr, rpw;
-    int npass, radix_log[4];
-    int sa;              // LDS elements between the P sub-arrays of a row
-    int lds_row;         // LDS elements between rows of a workgroup
-    int colmode;
-    int64_t nrows, rpp, in_plane, in_row, in_elem, out_pitch;
-};
-
-template <typename T>
-__global__ __launch_bounds__(1024) void k_rowfft_full(const cplx<T> *__restrict__ in,
-                                                       cplx<T> *__restrict__ out,
-                                                       const cplx<T> *__restrict__ tw,
-                                                       RowFftFullArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
-    cplx<T> *smem = reinterpret_cast<cplx<T> *>(fft_smem);
-    const int tid = threadIdx.x;
-    const int Q = a.Q, n2 = a.n2;
-    const int64_t row0 = (int64_t)blockIdx.x * a.rpw;
-
-    // ---- load + radix-P decimation in frequency -------------------------------------------------
-    {
-        // colmode: lanes run over the rpw adjacent columns first (rpw * 16 contiguous bytes)
-        const int rr = a.colmode ? (tid & (a.rpw - 1)) : tid / a.tpr;
-        const int e0 = a.colmode ? tid / a.rpw : tid % a.tpr;
-        const int64_t rw = row0 + rr;
-        const bool ok = rw < a.nrows;
-        const cplx<T> *rin = in + (ok ? (rw / a.rpp) * a.in_plane + (rw % a.rpp) * a.in_row : 0);
-        cplx<T> *rb = smem + (int64_t)rr * a.lds_row;
-        for (int e = e0; e < n2; e += a.tpr) {
-            const int p = e >> a.logQ, q = e & (Q - 1);
-            T sr = T(0), si = T(0);
-            if (ok) {
-                int r = 0;  // (k p) mod P
-                for (int ia = q; ia < a.n_in; ia += Q) {
-                    const cplx<T> x = rin[(int64_t)ia * a.in_elem];
-                    if (p) {
-                        int ti = q * p + Q * r;  // ((q + k Q) p) mod n2
-                        if (ti >= n2) ti -= n2;
-                        const cplx<T> t = tw[ti];
-                        sr += x.re * t.re - x.im * t.im;
-                        si += x.re * t.im + x.im * t.re;
-                        r += p;
-                        if (r >= a.P) r -= a.P;
-                    } else {
-                        sr += x.re;
-                        si += x.im;
-                    }
-                }
-            }
-            rb[p * a.sa + fft_pidx(q)] = {sr, si};
-        }
-    }
-    __syncthreads();
-
-    // ---- power-of-two passes over all P sub-arrays ----------------------------------------------
-    const int r = tid / a.tpr, lane = tid % a.tpr;
-    cplx<T> *rb = smem + (int64_t)r * a.lds_row;
-    int logL = a.logQ;
-    for (int s = 0; s < a.npass; ++s) {
-        const int rl = a.radix_log[s];
-        const int logLR = logL - rl;
-        const int ipp = a.logQ - rl;          // log2(items per sub-array)
-        const int items = n2 >> rl;
-        const int twmul = a.P << (a.logQ - logL);  // n2 / L
-        for (int u = lane; u < items; u += a.tpr) {
-            cplx<T> *sb = rb + (u >> ipp) * a.sa;
-            const int ul = u & ((1 << ipp) - 1);
-            if (rl == 4) fft_pass_item<T, 4>(sb, ul, logLR, tw, twmul);
-            else if (rl == 3) fft_pass_item<T, 3>(sb, ul, logLR, tw, twmul);
-            else if (rl == 2) fft_pass_item<T, 2>(sb, ul, logLR, tw, twmul);
-            else fft_pass_item<T, 1>(sb, ul, logLR, tw, twmul);
-        }
-        __syncthreads();
-        logL = logLR;
-    }
-
-    // ---- kept outputs: X[l], l = j - n_out/2, times exp(-2 pi i (n_in/2) l / n2) ------------------
-    const int64_t row = row0 + r;
-    if (row >= a.nrows || lane >= a.n_out) return;
-    const int half_n = a.n_out / 2;
-    cplx<T> *rout = out + row * a.out_pitch;
-    int ti = (int)((-(int64_t)(a.n_in / 2) * (lane - half_n)) % n2);
-    if (ti < 0) ti += n2;
-    cplx<T> t = tw[ti];
-    int si2 = (int)((-(int64_t)(a.n_in / 2) * a.tpr) % n2);
-    if (si2 < 0) si2 += n2;
-    const cplx<T> step = tw[si2];
-    RowFftArgs da{};  // digit-position helper reuses the DIT kernel's descriptor fields
-    da.logQ = a.logQ;
-    da.npass = a.npass;
-    for (int k = 0; k < 4; ++k) da.radix_log[k] = a.radix_log[k];
-    for (int j = lane; j < a.n_out; j += a.tpr) {
-        int lm = j - half_n;
-        if (lm < 0) lm += n2;
-        const int kq = lm / a.P, p = lm - kq * a.P;
-        const cplx<T> v = rb[p * a.sa + fft_pidx(fft_digit_pos(kq, da))];
-        rout[j] = cmul(v, t);
-        t = cmul(t, step);
-    }
-}
-
 // [batch][R][C] -> [batch][C][R], 32x32 tiles through LDS (both sides coalesced).
 template <typename T>
 __global__ void k_transpose(const cplx<T> *__restrict__ in, cplx<T> *__restrict__ out, int R, int C) {
@@ -1163,23 +1054,6 @@ inline void rowfft_shape(const DimGeom &g, int &tpr, int &rpw) {
     rpw = FFT_THREADS / tpr;
 }
 
-#ifndef FV_FFT_ITEMS
-#define FV_FFT_ITEMS 8  // whole-row kernel: threads per row ~ n2 / this
-#endif
-
-// Whole-row kernel geometry; returns false when a row does not fit the LDS.
-inline bool rowfft_full_shape(const DimGeom &g, size_t elem, int &tpr, int &rpw, int &sa, int &lds_row) {
-    sa = fft_pidx(g.Q) | 1;
-    lds_row = g.P * sa;
-    if ((size_t)lds_row * elem > 150 * 1024) return false;
-    tpr = 64;
-    while (tpr < 1024 && tpr * FV_FFT_ITEMS < g.n2) tpr *= 2;
-    const int wgt = std::max(256, tpr);
-    rpw = wgt / tpr;
-    while (rpw > 1 && (size_t)rpw * lds_row * elem > 64 * 1024) rpw /= 2;
-    return true;
-}
-
 // rows = nplanes * rpp; element ia of row (plane, k) sits at plane*in_plane + k*in_row + ia*in_elem.
 template <typename T>
 void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
@@ -1188,43 +1062,6 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     static const int plans[9][4] = {{4, 0, 0, 0}, {3, 2, 0, 0}, {3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0},
                                     {3, 3, 3, 0}, {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 4 .. 12
     FV_REQUIRE(g.logQ >= 4 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
-    int ftpr, frpw, fsa, flds;
-    static const bool use_full = std::getenv("FFTVIS_HIP_FFT_FULL") && std::atoi(std::getenv("FFTVIS_HIP_FFT_FULL"));
-    if (use_full && rowfft_full_shape(g, sizeof(cplx<T>), ftpr, frpw, fsa, flds)) {
-        RowFftFullArgs a{};
-        a.n_in = g.na;
-        a.n_out = g.no;
-        a.n2 = g.n2;
-        a.P = g.P;
-        a.Q = g.Q;
-        a.logQ = g.logQ;
-        a.npass = 0;
-        for (int s = 0; s < 4; ++s) {
-            a.radix_log[s] = plans[g.logQ - 4][s];
-            if (a.radix_log[s]) ++a.npass;
-        }
-        a.tpr = ftpr;
-        a.rpw = frpw;
-        a.sa = fsa;
-        a.lds_row = flds;
-        a.colmode = in_elem != 1;
-        a.nrows = nplanes * rpp;
-        a.rpp = rpp;
-        a.in_plane = in_plane;
-        a.in_row = in_row;
-        a.in_elem = in_elem;
-        a.out_pitch = g.no;
-        const size_t smem = sizeof(cplx<T>) * (size_t)flds * frpw;
-        static bool attr_set_full = false;
-        if (!attr_set_full) {
-            FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft_full<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set_full = true;
-        }
-        hipLaunchKernelGGL(k_rowfft_full<T>, dim3((unsigned)cdiv(a.nrows, frpw)), dim3(ftpr * frpw),
-                           smem, stream, in, out, twd, a);
-        return;
-    }
     RowFftArgs a{};
     a.n_in = g.na;
     a.n_out = g.no;
@@ -1276,9 +1113,8 @@ void Nufft3<T>::fft(int ntrans) {
     // x-pass: A [p][na_y][na_x] -> B [p][na_y][no_x]
     rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1);
     std::swap(cur, oth);
-    int tpr, rpw, sa_, lds_;
-    static const bool use_full = std::getenv("FFTVIS_HIP_FFT_FULL") && std::atoi(std::getenv("FFTVIS_HIP_FFT_FULL"));
-    if (!(use_full && rowfft_full_shape(y, sizeof(cplx<T>), tpr, rpw, sa_, lds_))) rowfft_shape(y, tpr, rpw);
+    int tpr, rpw;
+    rowfft_shape(y, tpr, rpw);
     if (rpw >= 4) {
         // short columns: the y-pass reads rpw adjacent columns of B at once (64-256 B segments),
         // which fuses the transpose:  B -> C [p][no_x][no_y]

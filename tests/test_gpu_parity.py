@@ -423,3 +423,22 @@ def test_sim_type1_lattice_path(gpu):
     assert rel_l2(fftvis_amd.simulate_vis(**c2), oracle_simulate(dict(c2, force_use_type3=False))) < TOL
     g32 = fftvis_amd.simulate_vis(**dict(c1, precision=1, eps=1e-4))
     assert g32.dtype == np.complex64 and rel_l2(g32, exp) < 5e-3
+
+
+def test_sim_c3_geometry_subset_and_paths(gpu):
+    """configs[2] geometry (HERA-350, 61 075 baselines, polarized table beam, 8192^2-class grid)
+    with a reduced catalog and 2 channels x 1 time: a random subset of baselines against the
+    oracle's exact sums, linearity in the flux, and type-1 == type-3 on the full baseline set."""
+    cfg = synth.make_config("C3", nsrc=20_000, nfreq=2, ntimes=1)
+    v3 = fftvis_amd.simulate_vis(**cfg)
+    assert v3.shape == (2, 1, 2, 2, 61075) and np.isfinite(v3).all()
+    rng = np.random.default_rng(1)
+    sub = sorted(rng.choice(61075, 48, replace=False))
+    sub_cfg = dict(cfg, baselines=[cfg["baselines"][i] for i in sub])
+    assert rel_l2(v3[..., sub], oracle_simulate(sub_cfg)) < TOL
+    v1 = fftvis_amd.simulate_vis(**dict(cfg, force_use_type3=False))
+    assert rel_l2(v1, v3) < 2 * TOL
+    _, _, fl2 = synth.catalog(20_000, cfg["freqs"], 9)
+    v12 = fftvis_amd.simulate_vis(**dict(cfg, fluxes=cfg["fluxes"] - 2.0 * fl2))
+    v2 = fftvis_amd.simulate_vis(**dict(cfg, fluxes=fl2))
+    assert rel_l2(v12, v3 - 2.0 * v2) < 1e-10
