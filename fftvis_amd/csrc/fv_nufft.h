@@ -40,14 +40,10 @@ constexpr int FFT_THREADS = 256;
 #ifndef FV_FFT_QMAX_LOG
 #define FV_FFT_QMAX_LOG 12
 #endif
-#ifndef FV_FFT_TPR_DIV
-#define FV_FFT_TPR_DIV 16  // threads per row >= Q / this (P > 1)
-#endif
 #ifndef FV_FFT_TPR_DIV1
-#define FV_FFT_TPR_DIV1 8  // ... and for single-residue rows (P == 1)
+#define FV_FFT_TPR_DIV1 8  // threads per row = Q / this
 #endif
 constexpr int FFT_QMAX_LOG = FV_FFT_QMAX_LOG;  // LDS row buffer: Q <= 2^this complex (70 KiB fp64 at 4096)
-constexpr int FFT_NACC = 18;  // outputs a thread of a row-FFT accumulates in registers
 
 struct DimGeom {
     double xc = 0, X = 0;    // source-coordinate centre / half-width
@@ -391,27 +387,8 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
 
 // --- pruned row FFT -----------------------------------------------------------------------------
 // out[row][j] = sum_{ia < n_in} in[row][ia] exp(+2 pi i (ia - n_in/2)(j - n_out/2) / n2),
-// n2 = P * Q, Q = 2^logQ.  Decimation in time over the P residues of ia: for each p the
-// subsequence a' -> in[P a' + p] (zero-padded to Q) is transformed in LDS by in-place DIF passes of
-// radix 16/8 held in registers (result left digit-reversed), and every kept output accumulates
-// tw[p l] * F_p[l mod Q] in registers.  tpr threads cooperate on a row,
-// rpw = 256 / tpr rows share a workgroup.  LDS rows are padded by one element per 16 so that the
-// unit-stride last pass does not pile 16 lanes onto one bank.
-struct RowFftArgs {
-    int n_in, n_out, n2, P, Q, logQ, tpr, rpw;
-    int npass, radix_log[4];
-    int qp;              // padded LDS row length (elements)
-    int jchunk;          // outputs handled per blockIdx.y (<= tpr * FFT_NACC)
-    int lds_row;         // LDS elements between the rows of a workgroup (odd: bank spread)
-    int colmode;         // 1: rows are COLUMNS of the input planes (fused transpose)
-    int64_t nrows;       // rows over all transforms
-    int64_t rpp;         // rows per input plane
-    int64_t in_plane;    // elements between input planes
-    int64_t in_row;      // elements between consecutive rows of a plane
-    int64_t in_elem;     // elements between consecutive inputs of a row
-    int64_t out_pitch;   // elements between consecutive output rows
-};
-
+// n2 = P * Q, Q = 2^logQ: sub-FFTs of length Q live in LDS (rows padded against bank conflicts)
+// and are computed by in-place DIF passes of radix 16/8 held in registers (result digit-reversed).
 // LDS padding: one element per 16 and one more per 256, so that the unit-stride last pass, the
 // stride-16 middle pass and the stride-256 digit-reversed read-out all spread over the banks.
 __host__ __device__ inline int fft_pidx(int i) { return i + (i >> 4) + (i >> 8); }
@@ -482,7 +459,8 @@ __device__ inline void fft_pass_item(cplx<T> *rb, int u, int logLR, const cplx<T
 }
 
 // position of frequency k after the in-place DIF passes (mixed-radix digit reversal)
-__device__ inline int fft_digit_pos(int k, const RowFftArgs &a) {
+template <typename Args>
+__device__ inline int fft_digit_pos(int k, const Args &a) {
     int pos = 0, span = a.logQ;
     for (int s = 0; s < a.npass; ++s) {
         const int rl = a.radix_log[s];
@@ -493,118 +471,104 @@ __device__ inline int fft_digit_pos(int k, const RowFftArgs &a) {
     return pos;
 }
 
-template <typename T, bool DIRECT>
-__global__ __launch_bounds__(FFT_THREADS) void k_rowfft(const cplx<T> *__restrict__ in,
-                                                         cplx<T> *__restrict__ out,
-                                                         const cplx<T> *__restrict__ tw,
-                                                         RowFftArgs a) {
+// --- pruned row FFT, decimation in frequency over the P residues -------------------------------
+// Output l = P k' + p needs only  Y_p = FFT_Q(fold_Q(x[ia] w^{ia p})):
+//     X[l] = w^{-(n_in/2) l} Y_p[k' mod Q],      w = exp(2 pi i / n2),
+// so every (row group, residue p) is an independent, accumulator-free job: load (twiddle + fold;
+// a plain copy for p = 0 and n_in <= Q), DIF passes, strided write of its own outputs.  108 VGPRs,
+// Q/8 threads per row (up to 512): 8 elements of LDS per thread keeps 4 waves per SIMD.  The P jobs of
+// a row group get block ids that differ by 8, i.e. the same XCD: their interleaved 16-B stores
+// meet in that XCD's L2 before they are written back.
+struct RowDifArgs {
+    int n_in, n_out, n2, P, Q, logQ, tpr, rpw;
+    int npass, radix_log[4];
+    int lds_row, colmode;
+    int64_t nrows, rpp, in_plane, in_row, in_elem, out_pitch;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void k_rowfft_dif(const cplx<T> *__restrict__ in,
+                                                     cplx<T> *__restrict__ out,
+                                                     const cplx<T> *__restrict__ tw, RowDifArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
     cplx<T> *smem = reinterpret_cast<cplx<T> *>(fft_smem);
     const int tid = threadIdx.x;
+    const int vb = blockIdx.x;
+    const int tt = vb >> 3;
+    const int p = tt % a.P;
+    const int64_t grp = (int64_t)(tt / a.P) * 8 + (vb & 7);
+    const int64_t row0 = grp * a.rpw;
+    if (row0 >= a.nrows) return;  // workgroup-uniform
+    const int Q = a.Q, n2 = a.n2;
     const int r = tid / a.tpr, lane = tid % a.tpr;
-    const int64_t row0 = (int64_t)blockIdx.x * a.rpw;
-    const int64_t row = row0 + r;
-    const bool valid = row < a.nrows;
-    cplx<T> *rb = smem + (int64_t)r * a.lds_row;
-    const int Q = a.Q, half_n = a.n_out / 2;
-    const int jbeg = blockIdx.y * a.jchunk;
-    const int jend = min(a.n_out, jbeg + a.jchunk);
-    const int jfirst = jbeg + lane;
 
-    // this thread's outputs j = jfirst + i * tpr (P > 1 only; P == 1 reads them straight from LDS)
-    cplx<T> acc[DIRECT ? 1 : FFT_NACC];
-#pragma unroll
-    for (int i = 0; i < (DIRECT ? 1 : FFT_NACC); ++i) acc[i] = {T(0), T(0)};
-
-    for (int p = 0; p < a.P; ++p) {
-        if (a.colmode) {
-            // rows of this workgroup are adjacent columns: lanes run over the rows first so that
-            // each input index reads rpw * 16 contiguous bytes (rpw is a power of two <= 16)
-            const int rr = tid & (a.rpw - 1), qstep = FFT_THREADS / a.rpw;
-            const int64_t rw = row0 + rr;
-            const bool ok = rw < a.nrows;
-            const cplx<T> *cin = in + (ok ? (rw / a.rpp) * a.in_plane + (rw % a.rpp) * a.in_row : 0);
-            cplx<T> *crb = smem + (int64_t)rr * a.lds_row;
-            for (int q = tid / a.rpw; q < Q; q += qstep) {
-                const int ia = a.P * q + p;
-                crb[fft_pidx(q)] = (ok && ia < a.n_in) ? cin[(int64_t)ia * a.in_elem] : cplx<T>{T(0), T(0)};
-            }
-        } else {
-            const cplx<T> *rin = in + (valid ? (row / a.rpp) * a.in_plane + (row % a.rpp) * a.in_row : 0);
-            for (int q = lane; q < Q; q += a.tpr) {
-                const int ia = a.P * q + p;
-                rb[fft_pidx(q)] = (valid && ia < a.n_in) ? rin[(int64_t)ia * a.in_elem] : cplx<T>{T(0), T(0)};
-            }
-        }
-        __syncthreads();
-        int logL = a.logQ;
-        for (int s = 0; s < a.npass; ++s) {
-            const int rl = a.radix_log[s];
-            const int items = Q >> rl, logLR = logL - rl;
-            const int twmul = a.P << (a.logQ - logL);  // n2 / L
-            if (rl == 4) {
-                for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 4>(rb, u, logLR, tw, twmul);
-            } else if (rl == 3) {
-                for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 3>(rb, u, logLR, tw, twmul);
-            } else if (rl == 2) {
-                for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 2>(rb, u, logLR, tw, twmul);
-            } else {
-                for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 1>(rb, u, logLR, tw, twmul);
-            }
-            __syncthreads();
-            logL = logLR;
-        }
-        if constexpr (DIRECT) break;  // single residue: the write-out below reads rb directly
-        // acc[j] += tw[p l] F_p[l mod Q]; the twiddle advances by a fixed factor per step
-        cplx<T> t = {T(1), T(0)}, step = {T(1), T(0)};
-        if (p && jfirst < jend) {
-            int ti = (int)(((int64_t)p * (jfirst - half_n)) % a.n2);
-            if (ti < 0) ti += a.n2;
-            t = tw[ti];
-            step = tw[(int)(((int64_t)p * a.tpr) % a.n2)];
-        }
-        if constexpr (!DIRECT) {
-#pragma unroll
-            for (int i = 0; i < FFT_NACC; ++i) {
-                const int j = jfirst + i * a.tpr;
-                if (j < jend) {
-                    const int lq = (j - half_n) & (Q - 1);
-                    cplx<T> v = rb[fft_pidx(fft_digit_pos(lq, a))];
-                    if (p) {
-                        v = cmul(v, t);
-                        t = cmul(t, step);
-                    }
-                    acc[i].re += v.re;
-                    acc[i].im += v.im;
+    // ---- load: rb[q] = sum_k x[q + k Q] w^{(q + k Q) p} -------------------------------------------
+    {
+        const int rr = a.colmode ? (tid & (a.rpw - 1)) : r;  // colmode: lanes over adjacent columns
+        const int q0 = a.colmode ? tid / a.rpw : lane;
+        const int64_t rw = row0 + rr;
+        const bool ok = rw < a.nrows;
+        const cplx<T> *rin = in + (ok ? (rw / a.rpp) * a.in_plane + (rw % a.rpp) * a.in_row : 0);
+        cplx<T> *crb = smem + (int64_t)rr * a.lds_row;
+        for (int q = q0; q < Q; q += a.tpr) {
+            cplx<T> v = {T(0), T(0)};
+            if (ok && q < a.n_in) {
+                v = rin[(int64_t)q * a.in_elem];
+                if (p) v = cmul(v, tw[q * p]);  // q p < Q P = n2
+                int rk = p;  // (k p) mod P
+                for (int ia = q + Q; ia < a.n_in; ia += Q) {
+                    int ti = q * p + Q * rk;
+                    if (ti >= n2) ti -= n2;
+                    const cplx<T> x = cmul(rin[(int64_t)ia * a.in_elem], tw[ti]);
+                    v = {v.re + x.re, v.im + x.im};
+                    rk += p;
+                    if (rk >= a.P) rk -= a.P;
                 }
             }
+            crb[fft_pidx(q)] = v;
         }
-        if (p + 1 < a.P) __syncthreads();  // rb is reloaded for the next residue
     }
-    if (!valid || jfirst >= jend) return;
-    // final phase exp(-2 pi i (n_in/2) l / n2), again by recurrence along this thread's outputs
-    cplx<T> *rout = out + row * a.out_pitch;
-    int ti = (int)((-(int64_t)(a.n_in / 2) * (jfirst - half_n)) % a.n2);
-    if (ti < 0) ti += a.n2;
+    __syncthreads();
+
+    cplx<T> *rb = smem + (int64_t)r * a.lds_row;
+    int logL = a.logQ;
+    for (int s = 0; s < a.npass; ++s) {
+        const int rl = a.radix_log[s];
+        const int items = Q >> rl, logLR = logL - rl;
+        const int twmul = a.P << (a.logQ - logL);  // n2 / L
+        if (rl == 4) {
+            for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 4>(rb, u, logLR, tw, twmul);
+        } else if (rl == 3) {
+            for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 3>(rb, u, logLR, tw, twmul);
+        } else if (rl == 2) {
+            for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 2>(rb, u, logLR, tw, twmul);
+        } else {
+            for (int u = lane; u < items; u += a.tpr) fft_pass_item<T, 1>(rb, u, logLR, tw, twmul);
+        }
+        __syncthreads();
+        logL = logLR;
+    }
+
+    // ---- this residue's outputs: l = l0 + P i, l in [-n_out/2, n_out/2) -----------------------------
+    const int64_t row = row0 + r;
+    if (row >= a.nrows) return;
+    const int half_n = a.n_out / 2;
+    int d0 = (p + half_n) % a.P;  // (p - (-half_n)) mod P
+    const int lfirst = -half_n + d0 + a.P * lane;
+    if (lfirst >= a.n_out - half_n) return;
+    const int hshift = a.n_in / 2;
+    int ti = (int)((-(int64_t)hshift * lfirst) % n2);
+    if (ti < 0) ti += n2;
     cplx<T> t = tw[ti];
-    int si = (int)((-(int64_t)(a.n_in / 2) * a.tpr) % a.n2);
-    if (si < 0) si += a.n2;
+    int si = (int)((-(int64_t)hshift * a.P * a.tpr) % n2);
+    if (si < 0) si += n2;
     const cplx<T> step = tw[si];
-    if constexpr (DIRECT) {
-        for (int j = jfirst; j < jend; j += a.tpr) {
-            const int lq = (j - half_n) & (Q - 1);
-            rout[j] = cmul(rb[fft_pidx(fft_digit_pos(lq, a))], t);
-            t = cmul(t, step);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < FFT_NACC; ++i) {
-            const int j = jfirst + i * a.tpr;
-            if (j < jend) {
-                rout[j] = cmul(acc[i], t);
-                t = cmul(t, step);
-            }
-        }
+    cplx<T> *rout = out + row * a.out_pitch + half_n;
+    // k' = (l - p) / P advances by tpr per step: no division inside the loop
+    int kq = (lfirst - p) / a.P;
+    for (int l = lfirst; l < a.n_out - half_n; l += a.P * a.tpr, kq += a.tpr) {
+        rout[l] = cmul(rb[fft_pidx(fft_digit_pos(kq & (Q - 1), a))], t);
+        t = cmul(t, step);
     }
 }
 
@@ -1043,15 +1007,12 @@ void Nufft3<T>::spread(int ntrans, hipEvent_t e0, hipEvent_t e1) {
     launch_spread<1>(ntrans, t, e0, e1);
 }
 
-// Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision).
+// Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision):
+// Q/8 threads per row (16..512), 256..512 threads per workgroup.
 inline void rowfft_shape(const DimGeom &g, int &tpr, int &rpw) {
-    // P == 1 (lean kernel, 108 VGPRs): Q/8 threads per row halves the LDS per wave, which is what
-    // limits occupancy there (measured 1.3x on the C2 FFT).  P > 1 is register-bound either way.
-    const int div = g.P == 1 ? FV_FFT_TPR_DIV1 : FV_FFT_TPR_DIV;
     tpr = 16;
-    while (tpr < FFT_THREADS && (tpr < g.Q / div || (g.P > 1 && (int64_t)tpr * FFT_NACC < g.no)))
-        tpr *= 2;
-    rpw = FFT_THREADS / tpr;
+    while (tpr < 512 && tpr < g.Q / FV_FFT_TPR_DIV1) tpr *= 2;
+    rpw = std::max(1, FFT_THREADS / tpr);
 }
 
 // rows = nplanes * rpp; element ia of row (plane, k) sits at plane*in_plane + k*in_row + ia*in_elem.
@@ -1062,7 +1023,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     static const int plans[9][4] = {{4, 0, 0, 0}, {3, 2, 0, 0}, {3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0},
                                     {3, 3, 3, 0}, {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 4 .. 12
     FV_REQUIRE(g.logQ >= 4 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
-    RowFftArgs a{};
+    RowDifArgs a{};
     a.n_in = g.na;
     a.n_out = g.no;
     a.n2 = g.n2;
@@ -1074,10 +1035,8 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         a.radix_log[s] = plans[g.logQ - 4][s];
         if (a.radix_log[s]) ++a.npass;
     }
-    a.qp = fft_pidx(g.Q);
-    a.lds_row = a.qp | 1;
+    a.lds_row = fft_pidx(g.Q) | 1;
     rowfft_shape(g, a.tpr, a.rpw);
-    a.jchunk = g.P == 1 ? g.no : std::min(g.no, a.tpr * FFT_NACC);  // beyond: extra chunks (grid.y)
     a.colmode = in_elem != 1;
     a.nrows = nplanes * rpp;
     a.rpp = rpp;
@@ -1086,19 +1045,15 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.in_elem = in_elem;
     a.out_pitch = g.no;
     const size_t smem = sizeof(cplx<T>) * (size_t)a.lds_row * a.rpw;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft<T, false>),
+    static bool attr_set_dif = false;
+    if (!attr_set_dif) {
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft_dif<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft<T, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set_dif = true;
     }
-    dim3 grid((unsigned)cdiv(a.nrows, a.rpw), (unsigned)cdiv(g.no, a.jchunk));
-    if (g.P == 1)
-        hipLaunchKernelGGL((k_rowfft<T, true>), grid, dim3(FFT_THREADS), smem, stream, in, out, twd, a);
-    else
-        hipLaunchKernelGGL((k_rowfft<T, false>), grid, dim3(FFT_THREADS), smem, stream, in, out, twd, a);
+    const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
+    hipLaunchKernelGGL(k_rowfft_dif<T>, dim3((unsigned)(ngroups8 * 8 * g.P)), dim3(a.tpr * a.rpw),
+                       smem, stream, in, out, twd, a);
 }
 
 template <typename T>
