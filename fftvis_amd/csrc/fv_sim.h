@@ -611,11 +611,21 @@ class Sim : public SimBase {
     std::unique_ptr<Nufft3<T>> t1fft;
     DevBuf d_coefs, d_ant1, d_ant2;
 
-    // per-time scratch
-    DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scale, d_out, d_mhist,
-        d_scan_tot, d_scan_off;
+    // Per-time scratch lives in a lane.  Small problems run consecutive time steps on two lanes
+    // (two streams) so that one step's launch ramps and tails overlap the other's kernels.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        bool own_stream = false;
+        hipEvent_t done = nullptr;
+        std::unique_ptr<Nufft3<T>> nufft;
+        DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scan_tot, d_scan_off;
+        int binned_ti = -1;
+        int64_t binned_serial = -1;
+    };
+    Lane lanes[2];
+    hipEvent_t ev_start = nullptr;
+    DevBuf d_out, d_mhist;
     std::vector<std::pair<int, double>> mhist_log;  // (time index, transforms spread) per processed time
-    std::unique_ptr<Nufft3<T>> nufft;
 
     // stats / timing
     double st[10] = {0};
@@ -641,7 +651,7 @@ class Sim : public SimBase {
         ev_pool[ev_used].kind = kind;
         return ev_used++;
     }
-    size_t ev_begin(int kind) {
+    size_t ev_begin(int kind, hipStream_t st_) {
         if (timing_level < 2) return (size_t)-1;
         if (ev_used == ev_pool.size()) {
             Ev e;
@@ -651,12 +661,12 @@ class Sim : public SimBase {
             ev_pool.push_back(e);
         }
         ev_pool[ev_used].kind = kind;
-        FV_HIP(hipEventRecord(ev_pool[ev_used].a, stream));
+        FV_HIP(hipEventRecord(ev_pool[ev_used].a, st_));
         return ev_used++;
     }
-    void ev_end(size_t i) {
+    void ev_end(size_t i, hipStream_t st_) {
         if (i == (size_t)-1) return;
-        FV_HIP(hipEventRecord(ev_pool[i].b, stream));
+        FV_HIP(hipEventRecord(ev_pool[i].b, st_));
     }
     void ev_collect() {
         for (size_t i = 0; i < ev_used; ++i) {
@@ -673,11 +683,21 @@ class Sim : public SimBase {
           tpol(polarized_ ? 4 : 1) {
         FV_HIP(hipSetDevice(device));
         FV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        lanes[0].stream = stream;
+        FV_HIP(hipStreamCreateWithFlags(&lanes[1].stream, hipStreamNonBlocking));
+        lanes[1].own_stream = true;
+        FV_HIP(hipEventCreateWithFlags(&lanes[1].done, hipEventDisableTiming));
+        FV_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         for (int i = 0; i < 9; ++i) rplane.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
     }
     ~Sim() override {
         (void)hipSetDevice(device);
-        nufft.reset();
+        for (Lane &L : lanes) {
+            L.nufft.reset();
+            if (L.done) (void)hipEventDestroy(L.done);
+            if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);
+        }
+        if (ev_start) (void)hipEventDestroy(ev_start);
         for (auto &e : ev_pool) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
@@ -851,7 +871,11 @@ class Sim : public SimBase {
 
     // rotate -> horizon cut -> az/za -> 2 pi R topo for time ti; returns the device address of the
     // live above-horizon count (it never visits the host inside the loop).
-    const int *horizon_step(int ti, int64_t cap, int nblk) {
+    const int *horizon_step(Lane &L, int ti, int64_t cap, int nblk) {
+        hipStream_t stream = L.stream;
+        DevBuf &d_blockcnt = L.d_blockcnt, &d_blockoff = L.d_blockoff, &d_scan_tot = L.d_scan_tot,
+               &d_scan_off = L.d_scan_off, &d_xyz = L.d_xyz, &d_az = L.d_az, &d_za = L.d_za,
+               &d_srcidx = L.d_srcidx;
         // either R_t . eq on the fly, or topocentric vectors the caller computed
         const T *vec = ntimes_topo ? d_topo.as<T>() + (size_t)ti * 3 * nsrc : d_eq.as<T>();
         hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
@@ -874,7 +898,6 @@ class Sim : public SimBase {
                            rots[ti], rplane, d_blockoff.as<int>(), d_xyz.as<T>(), cap,
                            d_az.as<T>(), d_za.as<T>(), d_srcidx.as<int>());
         const int *Mp = d_blockoff.as<int>() + nblk;
-        d_mhist.reserve(sizeof(int) * rots.size());
         FV_HIP(hipMemcpyAsync(d_mhist.as<int>() + ti, Mp, sizeof(int), hipMemcpyDeviceToDevice, stream));
         return Mp;
     }
@@ -911,13 +934,16 @@ class Sim : public SimBase {
             for (int r = 0; r < 4; ++r) pol_off[r] = (int64_t)((r % 2) * 2 + r / 2) * nbls;
 
         const int64_t cap = std::max<int64_t>(nsrc, 1);
+        Lane &L = lanes[0];
+        DevBuf &d_xyz = L.d_xyz, &d_az = L.d_az, &d_za = L.d_za, &d_srcidx = L.d_srcidx;
         d_xyz.reserve(sizeof(T) * 3 * cap);
         d_az.reserve(sizeof(T) * cap);
         d_za.reserve(sizeof(T) * cap);
         d_srcidx.reserve(sizeof(int) * cap);
         const int nblk = (int)cdiv(cap, 256);
-        d_blockcnt.reserve(sizeof(int) * (nblk + 1));
-        d_blockoff.reserve(sizeof(int) * (nblk + 1));
+        L.d_blockcnt.reserve(sizeof(int) * (nblk + 1));
+        L.d_blockoff.reserve(sizeof(int) * (nblk + 1));
+        d_mhist.reserve(sizeof(int) * rots.size());
         // frequencies per batch: bounded by entries (~1.3 per (source, freq)) and by grid bytes
         const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
         const double budget = eb ? std::atof(eb) : 8.0 * 1024 * 1024 * 1024;
@@ -934,9 +960,9 @@ class Sim : public SimBase {
 
         for (int ti = t0; ti < t1; ++ti) {
             if (nsrc == 0) continue;
-            size_t e0 = ev_begin(TM_PREP);
-            const int *Mp = horizon_step(ti, cap, nblk);
-            ev_end(e0);
+            size_t e0 = ev_begin(TM_PREP, stream);
+            const int *Mp = horizon_step(L, ti, cap, nblk);
+            ev_end(e0, stream);
             mhist_log.push_back({ti, 0.0});
             const size_t hist_slot = mhist_log.size() - 1;
             for (int fa = f0; fa < f1; fa += nfb) {
@@ -952,7 +978,7 @@ class Sim : public SimBase {
                 const int nbn = nfg * nb1 * nb1;
                 int *counts_p = t1_meta.as<int>(), *cursor_p = counts_p + (nbins + 1),
                     *ovf_p = cursor_p + (nbins + 1);
-                size_t e1 = ev_begin(TM_PREP);
+                size_t e1 = ev_begin(TM_PREP, stream);
                 FV_HIP(hipMemsetAsync(t1_meta.p, 0, sizeof(int) * (2 * (size_t)(nbins + 1) + 2), stream));
                 const dim3 gb((unsigned)cdiv(cap * nfg, 256));
                 hipLaunchKernelGGL((k_t1_bin<T, true>), gb, dim3(256), 0, stream, a, Mp, d_xyz.as<T>(),
@@ -963,11 +989,11 @@ class Sim : public SimBase {
                                    d_freqs.as<double>(), counts_p, (const int *)t1_binstart.as<int>(),
                                    cursor_p, t1_i0s.as<int>(), t1_kw.as<T>(), t1_ent.as<int>(),
                                    (T)ker.beta, (T)ker.c, ovf_p);
-                ev_end(e1);
+                ev_end(e1, stream);
                 const int *nent = t1_binstart.as<int>() + nbn;
                 for (const Pair &pr : pairs) {
                     if (pr.n == 0) continue;
-                    size_t e2 = ev_begin(TM_STRENGTHS);
+                    size_t e2 = ev_begin(TM_STRENGTHS, stream);
                     StrengthArgs sa{};
                     sa.M = cap;
                     sa.nfg = nfg;
@@ -983,10 +1009,10 @@ class Sim : public SimBase {
                                        sa, nent, (const int *)t1_ent.as<int>(), d_srcidx.as<int>(),
                                        d_az.as<T>(), d_za.as<T>(), d_flux.p, d_freqs.as<double>(),
                                        t1_cs.as<cplx<T>>());
-                    ev_end(e2);
+                    ev_end(e2, stream);
                     const int nplanes = nfg * tpol;
                     cplx<T> *A = t1fft->fft_input(nplanes);
-                    size_t e3 = ev_begin(TM_SPREAD);
+                    size_t e3 = ev_begin(TM_SPREAD, stream);
                     const dim3 gs((unsigned)cdiv(g.n2 >> BINLOG, 4), (unsigned)(g.n2 >> BINLOG), (unsigned)nfg);
                     if (polarized)
                         hipLaunchKernelGGL((k_t1_spread<T, 4>), gs, dim3(SPREAD_THREADS), 0, stream, a,
@@ -998,15 +1024,15 @@ class Sim : public SimBase {
                                            (const int *)t1_i0s.as<int>(), (const T *)t1_kw.as<T>(),
                                            (const int *)t1_binstart.as<int>(),
                                            (const cplx<T> *)t1_cs.as<cplx<T>>(), A);
-                    ev_end(e3);
+                    ev_end(e3, stream);
                     st[0] += 1;
                     st[1] += (double)g.n2 * g.n2 * nplanes;
                     mhist_log[hist_slot].second += nplanes;
-                    size_t e4 = ev_begin(TM_FFT);
+                    size_t e4 = ev_begin(TM_FFT, stream);
                     t1fft->fft(nplanes);
-                    ev_end(e4);
+                    ev_end(e4, stream);
                     st[3] += ((double)g.n2 * g.n2 + 2.0 * g.no * g.n2 + (double)g.no * g.no) * nplanes;
-                    size_t e5 = ev_begin(TM_INTERP);
+                    size_t e5 = ev_begin(TM_INTERP, stream);
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
                     hipLaunchKernelGGL(k_t1_pick<T>, dim3(cdiv(pr.n * nfg, 256)), dim3(256), 0, stream,
                                        t1fft->fft_output(), g.no, nfg, tpol, (const int *)d_blint.as<int>(),
@@ -1016,7 +1042,7 @@ class Sim : public SimBase {
                                                   : (const signed char *)pr.flip->template as<signed char>(),
                                        (const T *)t1_dec.as<T>(), obase, (int64_t)nt * per_tf, pol_off[0],
                                        pol_off[1], pol_off[2], pol_off[3]);
-                    ev_end(e5);
+                    ev_end(e5, stream);
                     st[4] += (double)pr.n * nplanes;
                     st[6] = g.n2;
                     st[7] = g.n2;
@@ -1102,8 +1128,7 @@ class Sim : public SimBase {
         }
         // Baselines not covered by any pair stay zero (reference zero-initialises, :909-911).
         FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
-        if (!nufft) nufft.reset(new Nufft3<T>(D, eps, sigma, stream));
-        if (nufft->dim != D) nufft.reset(new Nufft3<T>(D, eps, sigma, stream));
+        d_mhist.reserve(sizeof(int) * rots.size());
 
         double xc[3], X[3];
         source_box(xc, X);
@@ -1112,14 +1137,7 @@ class Sim : public SimBase {
             for (int r = 0; r < 4; ++r) pol_off[r] = (int64_t)((r % 2) * 2 + r / 2) * nbls;
 
         const int64_t cap = std::max<int64_t>(nsrc, 1);
-        d_xyz.reserve(sizeof(T) * 3 * cap);
-        d_az.reserve(sizeof(T) * cap);
-        d_za.reserve(sizeof(T) * cap);
-        d_srcidx.reserve(sizeof(int) * cap);
         const int nblk = (int)cdiv(cap, 256);
-        d_blockcnt.reserve(sizeof(int) * (nblk + 1));
-        d_blockoff.reserve(sizeof(int) * (nblk + 1));
-        d_scale.reserve(sizeof(double) * std::max(nf, 1));
 
         // grid-buffer cells per transform at the top frequency, for the grouping heuristic
         double cells_top = 1.0;
@@ -1143,15 +1161,39 @@ class Sim : public SimBase {
         }
         const auto groups = freq_groups(f0, f1, cells_top);
 
-        int binned_ti = -1;
-        int64_t binned_serial = -1;
+        // two lanes while a group's grid buffers are small (launch-bound regime), else one
+        int max_ntrans = 1;
+        for (const auto &grp : groups) max_ntrans = std::max(max_ntrans, (grp.second - grp.first) * tpol);
+        const char *el = std::getenv("FFTVIS_HIP_LANES");
+        int nlanes = el ? std::atoi(el)
+                        : (cells_top * sizeof(cplx<T>) * max_ntrans <= 1.5 * 1024 * 1024 * 1024 ? 2 : 1);
+        nlanes = std::max(1, std::min(2, std::min(nlanes, nt)));
+        for (int li = 0; li < nlanes; ++li) {
+            Lane &L = lanes[li];
+            if (!L.nufft || L.nufft->dim != D) L.nufft.reset(new Nufft3<T>(D, eps, sigma, L.stream));
+            L.d_xyz.reserve(sizeof(T) * 3 * cap);
+            L.d_az.reserve(sizeof(T) * cap);
+            L.d_za.reserve(sizeof(T) * cap);
+            L.d_srcidx.reserve(sizeof(int) * cap);
+            L.d_blockcnt.reserve(sizeof(int) * (nblk + 1));
+            L.d_blockoff.reserve(sizeof(int) * (nblk + 1));
+            L.binned_ti = -1;
+        }
+        if (nlanes > 1) {  // lane 1 starts after the output memset queued on the main stream
+            FV_HIP(hipEventRecord(ev_start, stream));
+            FV_HIP(hipStreamWaitEvent(lanes[1].stream, ev_start, 0));
+        }
+
         for (int ti = t0; ti < t1; ++ti) {
-            // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
-            size_t e0 = ev_begin(TM_PREP);
             if (nsrc == 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
-            const int *Mp = horizon_step(ti, cap, nblk);
+            Lane &L = lanes[(ti - t0) % nlanes];
+            hipStream_t ls = L.stream;
+            Nufft3<T> *nufft = L.nufft.get();
+            // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
+            size_t e0 = ev_begin(TM_PREP, ls);
+            const int *Mp = horizon_step(L, ti, cap, nblk);
             const int64_t M = cap;  // capacity: array stride and launch bound
-            ev_end(e0);
+            ev_end(e0, ls);
             size_t hist_slot = mhist_log.size();
             mhist_log.push_back({ti, 0.0});
 
@@ -1163,17 +1205,17 @@ class Sim : public SimBase {
                 for (const Pair &pr : pairs) {
                     if (pr.n == 0) continue;
                     // ---- geometry + bin sort (skipped when unchanged since last set) -------
-                    size_t e1 = ev_begin(TM_PREP);
+                    size_t e1 = ev_begin(TM_PREP, ls);
                     nufft->set_geometry(xc, X, pr.btc, pr.B, smax);
-                    if (binned_ti != ti || binned_serial != nufft->geom_serial || nufft->M != M) {
-                        nufft->set_sources(M, d_xyz.as<T>(), d_xyz.as<T>() + cap,
-                                           D > 2 ? d_xyz.as<T>() + 2 * cap : nullptr, Mp);
-                        binned_ti = ti;
-                        binned_serial = nufft->geom_serial;
+                    if (L.binned_ti != ti || L.binned_serial != nufft->geom_serial || nufft->M != M) {
+                        nufft->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
+                                           D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mp);
+                        L.binned_ti = ti;
+                        L.binned_serial = nufft->geom_serial;
                     }
-                    ev_end(e1);
+                    ev_end(e1, ls);
                     // ---- strengths ------------------------------------------------------
-                    size_t e2 = ev_begin(TM_STRENGTHS);
+                    size_t e2 = ev_begin(TM_STRENGTHS, ls);
                     StrengthArgs sa{};
                     sa.M = M;
                     sa.nfg = nfg;
@@ -1193,11 +1235,11 @@ class Sim : public SimBase {
                     sa.bj = desc(pr.bj);
                     cplx<T> *cs = nufft->strengths_buffer(ntrans);
                     hipLaunchKernelGGL(k_strengths<T>, dim3(cdiv((int64_t)M * nfg, 256)), dim3(256),
-                                       0, stream, sa, Mp, nufft->perm.template as<int>(),
-                                       d_srcidx.as<int>(), d_az.as<T>(), d_za.as<T>(), d_flux.p,
-                                       d_freqs.as<double>(), nufft->i0s.template as<int>(),
-                                       nufft->fs.template as<T>(), cs);
-                    ev_end(e2);
+                                       0, ls, sa, Mp, nufft->perm.template as<int>(),
+                                       L.d_srcidx.template as<int>(), L.d_az.template as<T>(),
+                                       L.d_za.template as<T>(), d_flux.p, d_freqs.as<double>(),
+                                       nufft->i0s.template as<int>(), nufft->fs.template as<T>(), cs);
+                    ev_end(e2, ls);
                     // ---- NUFFT ----------------------------------------------------------
                     if (timing_level >= 1) {
                         const size_t e3 = ev_slot(TM_SPREAD);
@@ -1208,15 +1250,15 @@ class Sim : public SimBase {
                     st[0] += 1;
                     st[1] += (double)nufft->geo.cells_a() * ntrans;
                     mhist_log[hist_slot].second += ntrans;
-                    size_t e4 = ev_begin(TM_FFT);
+                    size_t e4 = ev_begin(TM_FFT, ls);
                     nufft->fft(ntrans);
-                    ev_end(e4);
+                    ev_end(e4, ls);
                     {   // cells moved by the pruned FFT: read A, write+read B, write+read Bt, write Ct
                         const DimGeom &gx = nufft->geo.d[0], &gy = nufft->geo.d[1];
                         const double zz = D > 2 ? nufft->geo.d[2].na : 1;
                         st[3] += zz * ((double)gx.na * gy.na + 4.0 * gx.no * gy.na + (double)gx.no * gy.no) * ntrans;
                     }
-                    size_t e5 = ev_begin(TM_INTERP);
+                    size_t e5 = ev_begin(TM_INTERP, ls);
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
                     BasisTerm bt{d_coefs.p, d_ant1.as<int>(), d_ant2.as<int>(), pr.bi, pr.bj, nbasis,
                                  (int)freqs.size(), fa};
@@ -1226,7 +1268,7 @@ class Sim : public SimBase {
                                   pr.trivial ? nullptr : pr.flip->template as<signed char>(),
                                   d_freqs.as<double>() + fa, nfg, tpol, obase,
                                   (int64_t)nt * per_tf, 1, pol_off, false, nbasis ? &bt : nullptr);
-                    ev_end(e5);
+                    ev_end(e5, ls);
                     st[4] += (double)pr.n * ntrans;
                     st[6] = nufft->geo.d[0].n2;
                     st[7] = nufft->geo.d[1].n2;
@@ -1234,6 +1276,10 @@ class Sim : public SimBase {
                     st[9] = nufft->ker.w;
                 }
             }
+        }
+        if (nlanes > 1) {  // join: everything queued on the main stream afterwards sees both lanes
+            FV_HIP(hipEventRecord(lanes[1].done, lanes[1].stream));
+            FV_HIP(hipStreamWaitEvent(stream, lanes[1].done, 0));
         }
         if (!out_on_device) {
             FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
