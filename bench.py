@@ -46,6 +46,10 @@ def parse():
     p.add_argument("--path", default="type3", choices=["type3", "type1"],
                    help="type3 = the benchmarked NUFFT path (BASELINE.json); type1 = the lattice path "
                         "the reference takes by default on these arrays (reported for comparison)")
+    p.add_argument("--lanes", type=int, default=1, choices=[1, 2],
+                   help="time steps in flight on separate streams.  The engine's own default is 2 for "
+                        "small grids (+10 %% on C2); the bench pins 1 so that the per-kernel durations "
+                        "behind `roofline` are not inflated by a second lane sharing the GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     return p.parse_args()
@@ -112,6 +116,7 @@ def main():
     from fftvis_amd.core.coords import SiderealRotation, eq_unit_vectors
     from fftvis_amd.gpu.gpu_simulate import SimHandle, prepare_array
 
+    os.environ["FFTVIS_HIP_LANES"] = str(a.lanes)
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -258,6 +263,7 @@ def main():
                             f"{'polarized table beam' if pol else 'unpolarized Airy beam'}, "
                             f"{a.path} NUFFT eps={a.eps:g} upsampfac={a.upsample:g}",
                 "slices_per_step": nfreq * ntimes,
+                "lanes": a.lanes,
                 "finite_output": finite,
             },
             "roofline": {

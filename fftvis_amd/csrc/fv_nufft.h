@@ -286,15 +286,22 @@ __global__ void k_load_strengths(int64_t M, const int *__restrict__ Mp, int ntra
 // One wave owns one 8x8-cell block of A, aligned with the 8x8 source bins; lane = cell.  A source
 // touches cell c iff 0 <= c - i0 < w in both dimensions, so only the bins
 // (8 b - w + 1) >> 3 .. b of each dimension can reach block b (2x2 bins for w <= 9, 3x3 up to 16).
-// The wave walks those sources together: footprint origin and strengths are wave-uniform (scalar
-// loads), each lane looks up its own pair of tabulated kernel weights (0 when the source misses
-// the cell) and accumulates TCH transforms in registers.  grid (ceil(nbx / 4), nby, chunks).
+// The wave walks those sources in chunks of SPREAD_CHUNK: it first stages the chunk's footprint
+// origins, tabulated kernel weights and TCH strengths into its own slice of LDS with bulk coalesced
+// loads (many in flight), then every lane accumulates from LDS -- strengths and origins are
+// broadcast reads, the two weights are per-lane -- TCH transforms in registers.  Every cell is
+// written once (zeros included, deconvolution applied).  grid (ceil(nbx / 4), nby, chunks).
+constexpr int SPREAD_CHUNK = 16;
+
 template <typename T, int TCH>
 __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
     int64_t M, const int *__restrict__ i0s, const T *__restrict__ kw,
     const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans, int tbegin,
     const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid, int nax,
     int nay, int nbx, int w) {
+    __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TCH];
+    __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][MAX_W];
+    __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int bx = blockIdx.x * 4 + wave, by = blockIdx.y;
@@ -311,19 +318,39 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
     for (int yb = byl; yb <= by; ++yb) {
         // bins bxl .. bx of one bin row are contiguous in the sorted order
         const int s0 = bin_start[yb * nbx + bxl], s1 = bin_start[yb * nbx + bx + 1];
-        for (int s = s0; s < s1; ++s) {
-            const int dx = cx - i0x[s], dy = cy - i0y[s];
-            T wt = T(0);
-            if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
-                wt = kwx[(int64_t)s * w + dx] * kwy[(int64_t)s * w + dy];
-            // whole chunks only: the TCH strength loads are one unconditional scalar burst
-            const cplx<T> *c = cs + (int64_t)s * ntrans + tbase;
-#pragma unroll
-            for (int q = 0; q < TCH; ++q) {
-                const cplx<T> cv = c[q];
-                ar[q] += cv.re * wt;
-                ai[q] += cv.im * wt;
+        for (int base = s0; base < s1; base += SPREAD_CHUNK) {
+            const int n = min(SPREAD_CHUNK, s1 - base);
+            // ---- stage the chunk (wave-private LDS slice; same-wave LDS ops stay in order) ----
+            for (int e = lane; e < n * TCH; e += 64) {
+                const int j = e / TCH, q = e % TCH;
+                s_str[wave][j][q] = cs[(int64_t)(base + j) * ntrans + tbase + q];
             }
+            for (int e = lane; e < n * w; e += 64) {
+                const int j = e / w, k = e - j * w;
+                s_kw[wave][j][0][k] = kwx[(int64_t)(base + j) * w + k];
+                s_kw[wave][j][1][k] = kwy[(int64_t)(base + j) * w + k];
+            }
+            if (lane < n) {
+                s_i0[wave][lane][0] = i0x[base + lane];
+                s_i0[wave][lane][1] = i0y[base + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- accumulate from LDS ----------------------------------------------------------
+            for (int j = 0; j < n; ++j) {
+                const int dx = cx - s_i0[wave][j][0], dy = cy - s_i0[wave][j][1];
+                T wt = T(0);
+                if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
+                    wt = s_kw[wave][j][0][dx] * s_kw[wave][j][1][dy];
+#pragma unroll
+                for (int q = 0; q < TCH; ++q) {
+                    const cplx<T> cv = s_str[wave][j][q];
+                    ar[q] += cv.re * wt;
+                    ai[q] += cv.im * wt;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next chunk
         }
     }
     const T f = decx[cx] * decy[cy];
@@ -334,7 +361,8 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
 }
 
 // --- 3-D spread (gather): as k_spread2d, one wave per 8x8 (x, y) block of ONE z-plane of A ------
-// grid (ceil(nbx / 4), nby, na_z * chunks); bin index = (bz * nby + by) * nbx + bx.
+// grid (ceil(nbx / 4), nby, na_z * chunks); bin index = (bz * nby + by) * nbx + bx.  The z weight of
+// a staged source is folded into its strengths while staging (it is wave-uniform: one z-plane).
 template <typename T, int TCH>
 __global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
     int64_t M, const int *__restrict__ i0s, const T *__restrict__ kw,
@@ -342,6 +370,9 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
     int nchunk, const T *__restrict__ decx, const T *__restrict__ decy,
     const T *__restrict__ decz, cplx<T> *__restrict__ grid, int nax, int nay, int naz, int nbx,
     int nby, int w) {
+    __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TCH];
+    __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][MAX_W];
+    __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int bx = blockIdx.x * 4 + wave, by = blockIdx.y;
@@ -361,20 +392,40 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
         for (int yb = byl; yb <= by; ++yb) {
             const int rowb = (zb * nby + yb) * nbx;
             const int s0 = bin_start[rowb + bxl], s1 = bin_start[rowb + bx + 1];
-            for (int s = s0; s < s1; ++s) {
-                const int dz = cz - i0z[s];  // wave-uniform
-                if ((unsigned)dz >= (unsigned)w) continue;
-                const int dx = cx - i0x[s], dy = cy - i0y[s];
-                T wt = T(0);
-                if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
-                    wt = kwx[(int64_t)s * w + dx] * kwy[(int64_t)s * w + dy] * kwz[(int64_t)s * w + dz];
-                const cplx<T> *c = cs + (int64_t)s * ntrans + tbase;
-#pragma unroll
-                for (int q = 0; q < TCH; ++q) {
-                    const cplx<T> cv = c[q];
-                    ar[q] += cv.re * wt;
-                    ai[q] += cv.im * wt;
+            for (int base = s0; base < s1; base += SPREAD_CHUNK) {
+                const int n = min(SPREAD_CHUNK, s1 - base);
+                for (int e = lane; e < n * TCH; e += 64) {
+                    const int j = e / TCH, q = e % TCH;
+                    const int dz = cz - i0z[base + j];
+                    const T kz = (unsigned)dz < (unsigned)w ? kwz[(int64_t)(base + j) * w + dz] : T(0);
+                    const cplx<T> c = cs[(int64_t)(base + j) * ntrans + tbase + q];
+                    s_str[wave][j][q] = {c.re * kz, c.im * kz};
                 }
+                for (int e = lane; e < n * w; e += 64) {
+                    const int j = e / w, k = e - j * w;
+                    s_kw[wave][j][0][k] = kwx[(int64_t)(base + j) * w + k];
+                    s_kw[wave][j][1][k] = kwy[(int64_t)(base + j) * w + k];
+                }
+                if (lane < n) {
+                    s_i0[wave][lane][0] = i0x[base + lane];
+                    s_i0[wave][lane][1] = i0y[base + lane];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < n; ++j) {
+                    const int dx = cx - s_i0[wave][j][0], dy = cy - s_i0[wave][j][1];
+                    T wt = T(0);
+                    if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
+                        wt = s_kw[wave][j][0][dx] * s_kw[wave][j][1][dy];
+#pragma unroll
+                    for (int q = 0; q < TCH; ++q) {
+                        const cplx<T> cv = s_str[wave][j][q];
+                        ar[q] += cv.re * wt;
+                        ai[q] += cv.im * wt;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }

@@ -429,10 +429,14 @@ __global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent,
 }
 
 // One wave per 8x8 cell block of one frequency plane; TP = transforms per plane (1 or 4).
+// Same LDS staging of source chunks as k_spread2d.
 template <typename T, int TP>
 __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
     T1Args a, const int *__restrict__ i0s, const T *__restrict__ kw,
     const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, cplx<T> *__restrict__ grid) {
+    __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TP];
+    __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][MAX_W];
+    __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nbc = a.n2 >> BINLOG;
@@ -450,18 +454,34 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
     for (int yb = byl; yb <= byh; ++yb) {
         const int rowb = (f * a.nb1 + yb) * a.nb1;
         const int s0 = bin_start[rowb + bxl], s1 = bin_start[rowb + bxh + 1];
-        for (int s = s0; s < s1; ++s) {
-            const int dx = cx - i0x[s], dy = cy - i0y[s];
-            T wt = T(0);
-            if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
-                wt = kwx[(int64_t)s * w + dx] * kwy[(int64_t)s * w + dy];
-            const cplx<T> *c = cs + (int64_t)s * TP;
-#pragma unroll
-            for (int q = 0; q < TP; ++q) {
-                const cplx<T> cv = c[q];
-                ar[q] += cv.re * wt;
-                ai[q] += cv.im * wt;
+        for (int base = s0; base < s1; base += SPREAD_CHUNK) {
+            const int n = min(SPREAD_CHUNK, s1 - base);
+            for (int e = lane; e < n * TP; e += 64) s_str[wave][e / TP][e % TP] = cs[(int64_t)base * TP + e];
+            for (int e = lane; e < n * w; e += 64) {
+                const int j = e / w, k = e - j * w;
+                s_kw[wave][j][0][k] = kwx[(int64_t)(base + j) * w + k];
+                s_kw[wave][j][1][k] = kwy[(int64_t)(base + j) * w + k];
             }
+            if (lane < n) {
+                s_i0[wave][lane][0] = i0x[base + lane];
+                s_i0[wave][lane][1] = i0y[base + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < n; ++j) {
+                const int dx = cx - s_i0[wave][j][0], dy = cy - s_i0[wave][j][1];
+                T wt = T(0);
+                if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
+                    wt = s_kw[wave][j][0][dx] * s_kw[wave][j][1][dy];
+#pragma unroll
+                for (int q = 0; q < TP; ++q) {
+                    const cplx<T> cv = s_str[wave][j][q];
+                    ar[q] += cv.re * wt;
+                    ai[q] += cv.im * wt;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     const int64_t plane = (int64_t)a.n2 * a.n2;
