@@ -81,7 +81,7 @@ def cpu_baseline(cfg, seconds: float):
         topo, flux, n = mgr.select_chunk(0, ti)
         az, za = orc.enu_to_az_za(topo[0], topo[1])
         topo = 2 * np.pi * topo
-        for fi in np.linspace(0, len(freqs) - 1, min(len(freqs), 8)).astype(int):
+        for fi in range(len(freqs)):
             bev = [orc.evaluate_beam(beam, az, za, pol, freqs[fi]).astype(complex)]
             c = orc.compute_apparent_coherency(bev, 0, 0, flux, fi, pol, pol_sky, nfeeds)
             uvw = bls * freqs[fi]
