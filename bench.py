@@ -37,11 +37,11 @@ def parse():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", default=os.environ.get("FFTVIS_BENCH_WORKLOAD", "C2"),
-                   choices=["C1", "C2", "C3", "C4"])
+                   choices=["C1", "C2", "C3", "C4", "C5"])
     p.add_argument("--nsrc", type=int, default=None)
     p.add_argument("--nfreq", type=int, default=None)
     p.add_argument("--ntimes", type=int, default=None)
-    p.add_argument("--eps", type=float, default=6e-8)
+    p.add_argument("--eps", type=float, default=None, help="default: the workload's (6e-8; C5: 1e-4)")
     p.add_argument("--upsample", type=float, default=2.0)
     p.add_argument("--path", default="type3", choices=["type3", "type1"],
                    help="type3 = the benchmarked NUFFT path (BASELINE.json); type1 = the lattice path "
@@ -73,7 +73,10 @@ def cpu_baseline(cfg, seconds: float):
     bls = bls / orc.speed_of_light
     coh, pol_sky = orc.prepare_source_catalog(cfg["fluxes"], pol)
     mgr = orc.SimpleCoordinateRotation(coh, times, cfg["telescope_loc"], cfg["ra"], cfg["dec"])
-    beam = oracle_beam(cfg["beam"], pol, freqs)
+    blist = cfg["beam"] if isinstance(cfg["beam"], list) else [cfg["beam"]]
+    beams = [oracle_beam(b, pol, freqs) for b in blist]
+    # eigenbeam workloads: one NUFFT per basis pair k <= l (reference cpu_simulate.py:416-417)
+    bpairs = [(k, l) for k in range(len(beams)) for l in range(k, len(beams))] if "beam_coefs" in cfg else [(0, 0)]
     nslices, t_used = 0, 0.0
     t_start = time.perf_counter()
     for ti in range(len(times)):
@@ -82,10 +85,11 @@ def cpu_baseline(cfg, seconds: float):
         az, za = orc.enu_to_az_za(topo[0], topo[1])
         topo = 2 * np.pi * topo
         for fi in range(len(freqs)):
-            bev = [orc.evaluate_beam(beam, az, za, pol, freqs[fi]).astype(complex)]
-            c = orc.compute_apparent_coherency(bev, 0, 0, flux, fi, pol, pol_sky, nfeeds)
+            bev = [orc.evaluate_beam(b, az, za, pol, freqs[fi]).astype(complex) for b in beams]
             uvw = bls * freqs[fi]
-            cpu_nufft.nufft_type3([topo[0], topo[1]], c, [uvw[0], uvw[1]], eps=cfg["eps"])
+            for (k, l) in bpairs:
+                c = orc.compute_apparent_coherency(bev, k, l, flux, fi, pol, pol_sky, nfeeds)
+                cpu_nufft.nufft_type3([topo[0], topo[1]], c, [uvw[0], uvw[1]], eps=cfg["eps"])
             nslices += 1
             t_used = time.perf_counter() - t_start
             if t_used > seconds:
@@ -127,7 +131,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
 
     cfg = synth.make_config(a.workload, nsrc=a.nsrc, nfreq=a.nfreq, ntimes=a.ntimes)
+    if a.eps is None:
+        a.eps = cfg["eps"]
     cfg["eps"] = a.eps
+    precision = cfg.get("precision", 2)
+    rdt = torch.float32 if precision == 1 else torch.float64
+    cdt = torch.complex64 if precision == 1 else torch.complex128
+    RB = 4.0 if precision == 1 else 8.0  # bytes per real
     freqs, pol = cfg["freqs"], cfg["polarized"]
     ntimes, nfreq = len(cfg["times"]), len(freqs)
     baselines = cfg["baselines"]
@@ -137,12 +147,12 @@ def main():
     nsrc = len(cfg["ra"])
     if rank == 0:
         coh, pol_sky = utils.prepare_source_catalog(cfg["fluxes"], pol)
-        eq = torch.from_numpy(eq_unit_vectors(cfg["ra"], cfg["dec"])).to(dev)
-        flux = torch.from_numpy(np.ascontiguousarray(coh)).to(dev)
+        eq = torch.from_numpy(eq_unit_vectors(cfg["ra"], cfg["dec"])).to(dev, rdt)
+        flux = torch.from_numpy(np.ascontiguousarray(coh)).to(dev, rdt)
     else:
-        pol_sky = False
-        eq = torch.empty((3, nsrc), dtype=torch.float64, device=dev)
-        flux = torch.empty((nsrc, nfreq), dtype=torch.float64, device=dev)
+        pol_sky = False  # the synthetic catalogs are unpolarized: flux is (nsrc, nfreq) real
+        eq = torch.empty((3, nsrc), dtype=rdt, device=dev)
+        flux = torch.empty((nsrc, nfreq), dtype=rdt, device=dev)
     if dist is not None:
         dist.broadcast(eq, 0)
         dist.broadcast(flux, 0)
@@ -154,7 +164,7 @@ def main():
     R, bls, coplanar = prepare_array(cfg["ants"], baselines, 1e-6, np.float64)
     pairs, pidx, pflip = utils.prepare_beam_evaluation(list(cfg["ants"]), baselines, None)
 
-    h = SimHandle(local_rank, 2, a.eps, a.upsample, pol)
+    h = SimHandle(local_rank, precision, a.eps, a.upsample, pol)
     h.set_sources_device(nsrc, nfreq, eq.data_ptr(), flux.data_ptr(), pol_sky)
     h.set_times(SiderealRotation(my_times, cfg["telescope_loc"]).matrices())
     h.set_freqs(freqs)
@@ -167,9 +177,15 @@ def main():
         h.set_array_type1(basis / utils.speed_of_light, bint, 2 * int(np.abs(bint).max()) + 1)
     else:
         h.set_array(R, bls, coplanar)
-    h.set_beams([cfg["beam"]], freqs)
-    h.set_beam_pairs(pairs, pidx, pflip)
-    out = torch.empty(h.out_shape(ntimes, nfreq), dtype=torch.complex128, device=dev)
+    blist = cfg["beam"] if isinstance(cfg["beam"], list) else [cfg["beam"]]
+    h.set_beams(blist, freqs)
+    if "beam_coefs" in cfg:  # eigenbeam workload (C5): K (K + 1) / 2 NUFFTs per slice
+        antnums = list(cfg["ants"])
+        h.set_basis(cfg["beam_coefs"], [antnums.index(b[0]) for b in baselines],
+                    [antnums.index(b[1]) for b in baselines])
+    else:
+        h.set_beam_pairs(pairs, pidx, pflip)
+    out = torch.empty(h.out_shape(ntimes, nfreq), dtype=cdt, device=dev)
 
     def step():
         h.run_device(0, ntimes, 0, nfreq, out.data_ptr())
@@ -213,7 +229,7 @@ def main():
     if rank == 0:
         # ---- roofline of the spread kernel (the kernel BASELINE.json's metric names) ----------
         launches = max(st["spread_launches"], 1.0)
-        R8 = 8.0
+        R8 = RB
         d = 2 if coplanar else 3
         # algorithmic bytes:  M (d R + T 2R)  +  T G1 2R   summed over launches
         spread_bytes = st["source_visits"] * 2 * R8 + (st["sources_above_horizon"] / max(ntimes * a.steps, 1)) \
@@ -245,7 +261,8 @@ def main():
             "kernel_width": int(st["w"]),
         }
         res = {
-            "metric": "simulated visibilities/sec (baselines x freqs x times) at eps=6e-8",
+            "metric": "simulated visibilities/sec (baselines x freqs x times) at eps="
+                      + ("6e-8" if a.eps == 6e-8 else f"{a.eps:g}"),
             "value": value,
             "unit": "visibilities/s",
             "n_gpus": world,
@@ -255,12 +272,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if precision == 1 else "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{a.workload}: {synth.CONFIGS[a.workload][0]}, {nsrc} sources, "
                             f"{nfreq} freqs, {ntimes} times/GPU, {nbls} baselines, "
-                            f"{'polarized table beam' if pol else 'unpolarized Airy beam'}, "
+                            f"{('%d basis beams (eigenbeam path), polarized' % len(blist)) if 'beam_coefs' in cfg else 'polarized table beam' if pol else 'unpolarized Airy beam'}, "
                             f"{a.path} NUFFT eps={a.eps:g} upsampfac={a.upsample:g}",
                 "slices_per_step": nfreq * ntimes,
                 "lanes": a.lanes,

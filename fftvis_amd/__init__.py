@@ -8,5 +8,6 @@ Mirrors the reference package's public surface for the gpu backend
 __version__ = "0.1.0"
 
 from .core.beams import AiryBeam, TabulatedBeam  # noqa: F401
+from .core.beam_basis import compute_beam_basis, compute_beam_basis_per_freq  # noqa: F401
 from .core.simulate import SimulationEngine, default_accuracy_dict  # noqa: F401
 from .wrapper import create_beam_evaluator, create_simulation_engine, simulate_vis  # noqa: F401

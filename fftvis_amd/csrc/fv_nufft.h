@@ -990,6 +990,7 @@ class Nufft3 {
     int launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e1);
     void buffer_cells(int64_t &c0, int64_t &c1) const;
     void fft(int ntrans);
+    double fft_traffic_cells() const;  // cells read + written by all FFT passes, per transform
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
     // index list / flip flags of length N, per-group scale (device, nfg doubles).
     void interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
@@ -1105,6 +1106,21 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
     hipLaunchKernelGGL(k_rowfft_dif<T>, dim3((unsigned)(ngroups8 * 8 * g.P)), dim3(a.tpr * a.rpw),
                        smem, stream, in, out, twd, a);
+}
+
+// Algorithmic traffic of fft(): every pass reads its input once and writes its pruned output once
+// (plus the explicit transpose when the y-pass cannot read columns directly).
+template <typename T>
+double Nufft3<T>::fft_traffic_cells() const {
+    const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
+    const double zin = dim > 2 ? z.na : 1;
+    int tpr, rpw;
+    rowfft_shape(y, tpr, rpw);
+    double c = zin * ((double)x.na * y.na + (double)x.no * y.na);        // x-pass
+    if (rpw < 4) c += zin * 2.0 * x.no * y.na;                            // transpose
+    c += zin * ((double)x.no * y.na + (double)x.no * y.no);              // y-pass
+    if (dim > 2) c += (double)x.no * y.no * (z.na + z.no);               // z-pass
+    return c;
 }
 
 template <typename T>

@@ -1273,11 +1273,7 @@ class Sim : public SimBase {
                     size_t e4 = ev_begin(TM_FFT, ls);
                     nufft->fft(ntrans);
                     ev_end(e4, ls);
-                    {   // cells moved by the pruned FFT: read A, write+read B, write+read Bt, write Ct
-                        const DimGeom &gx = nufft->geo.d[0], &gy = nufft->geo.d[1];
-                        const double zz = D > 2 ? nufft->geo.d[2].na : 1;
-                        st[3] += zz * ((double)gx.na * gy.na + 4.0 * gx.no * gy.na + (double)gx.no * gy.no) * ntrans;
-                    }
+                    st[3] += nufft->fft_traffic_cells() * ntrans;
                     size_t e5 = ev_begin(TM_INTERP, ls);
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
                     BasisTerm bt{d_coefs.p, d_ant1.as<int>(), d_ant2.as<int>(), pr.bi, pr.bj, nbasis,

@@ -106,7 +106,10 @@ CONFIGS = {
     "C2": ("hera37", 10_000, 64, 10, False, "airy"),
     "C3": ("hera350", 100_000, 128, 20, True, "table"),
     "C4": ("hera350", 1_000_000, 256, 60, True, "table"),
+    # per-antenna beams through K = 4 basis beams (eigenbeam path), fp32, eps 1e-4
+    "C5": ("hera350", 100_000, 128, 20, True, "basis"),
 }
+C5_NBASIS = 4
 
 
 def make_config(name: str, seed: int = 0, nsrc=None, nfreq=None, ntimes=None):
@@ -118,12 +121,29 @@ def make_config(name: str, seed: int = 0, nsrc=None, nfreq=None, ntimes=None):
     freqs = np.linspace(100e6, 200e6, nf)
     times = np.linspace(2459845.0, 2459845.05, nt)
     ra, dec, flux = catalog(ns, freqs, seed)
+    extra = {}
     if beamkind == "airy":
         beam = AiryBeam(14.0)
-    else:
+    elif beamkind == "table":
         beam = TabulatedBeam(synthetic_efield_table(freqs), freqs)
-    return dict(
+    else:
+        # K basis tables (dishes of different diameter from the same generator) and per-antenna
+        # coefficients: a dominant first mode plus a few-percent admixture of the others, the
+        # structure the SVD of a +-7 % diameter scatter gives (beam_decomposition.ipynb cell 8)
+        rng = np.random.default_rng(seed + 5)
+        diam = 14.0 * (1 + 0.07 * np.linspace(-1, 1, C5_NBASIS))
+        # real-valued tables: the eigenbeam path's V_lk = V_kl^T shortcut is exact only for those
+        # (reference cpu_simulate.py:464-468)
+        beam = [TabulatedBeam(synthetic_efield_table(freqs, d, nza=91, naz=180).real.astype(complex), freqs)
+                for d in diam]
+        nant = len(ants)
+        coefs = 0.05 * (rng.normal(size=(nant, C5_NBASIS, nf)) + 1j * rng.normal(size=(nant, C5_NBASIS, nf)))
+        coefs[:, 0, :] += 1.0
+        extra = dict(beam_coefs=coefs, precision=1, eps=1e-4)
+    cfg = dict(
         ants=ants, fluxes=flux, ra=ra, dec=dec, freqs=freqs, times=times, beam=beam,
         telescope_loc=(HERA_LAT, HERA_LON), baselines=all_cross_baselines(ants), polarized=pol,
         precision=2, eps=6e-8, force_use_type3=True,  # the benchmark path is the type-3 NUFFT
     )
+    cfg.update(extra)
+    return cfg
