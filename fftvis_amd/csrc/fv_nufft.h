@@ -623,6 +623,212 @@ __global__ __launch_bounds__(512, 4) void k_rowfft_dif(const cplx<T> *__restrict
     }
 }
 
+// --- pruned row FFT, register-resident (Q = 512 .. 4096) ---------------------------------------
+// Same job decomposition as k_rowfft_dif (one workgroup-row per (row, residue p)), but the three
+// radix passes keep their operands in registers and LDS is only the exchange between passes:
+//   pass 1  item u = n' in [0, Q/R1):  x[u + n1 Q/R1] straight from global memory (coalesced over u,
+//           zero beyond n_in, twiddle/fold for p > 0), radix-R1 butterfly, twiddle w_Q^{u k1};
+//   pass 2  item (k1, j3): radix R2 over the sub-sequence of length Q/R1, twiddle;
+//   pass 3  item v = k1 + R1 k2: radix R3, then X[v + k3 Q/R3] goes straight to global memory
+//           (coalesced over v; only the wanted |l| range is written).
+// The exchange moves real and imaginary parts one after the other through one T-typed buffer of
+// R1*A slots per row (8.4 KiB at Q = 1024 fp64 instead of 17.5 KiB for a complex row), so twice as
+// many rows are in flight per CU, and every element crosses LDS 4 times instead of 8.
+// Slot of element (k1, j2, j3) = k1 A + j2 B + j3: A, B chosen (scratch bank model, 8-byte slots,
+// 32 lanes per LDS pass) so that the pass-1 writes and the pass-2 accesses are conflict-free and
+// the pass-3 reads at most 2-way.
+template <int LOGQ>
+struct StPlan;
+template <>
+struct StPlan<9> {
+    static constexpr int R1 = 8, R2 = 8, R3 = 8, TPR = 64, A = 76, B = 9;
+};
+template <>
+struct StPlan<10> {
+    static constexpr int R1 = 16, R2 = 8, R3 = 8, TPR = 64, A = 66, B = 8;
+};
+template <>
+struct StPlan<11> {
+    static constexpr int R1 = 16, R2 = 16, R3 = 8, TPR = 128, A = 130, B = 8;
+};
+template <>
+struct StPlan<12> {
+    static constexpr int R1 = 16, R2 = 16, R3 = 16, TPR = 256, A = 258, B = 16;
+};
+constexpr int ST_THREADS = 256;
+constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v / 2); }
+
+template <bool WAVE>
+__device__ inline void st_sync() {
+    if constexpr (WAVE) {  // the row lives in one wavefront: LDS is in order, only the compiler must not reorder
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// v holds X[k] at v[bitrev(k)]: multiply X[k] by w^k, k = 1 .. R-1
+template <typename T, int R>
+__device__ inline void st_twiddle(cplx<T> *v, cplx<T> w) {
+    constexpr int LR = ilog2_c(R);
+    cplx<T> wk = w;
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+        v[bitrev_small(k, LR)] = cmul(v[bitrev_small(k, LR)], wk);
+        if (k + 1 < R) wk = cmul(wk, w);
+    }
+}
+
+template <typename T, int LOGQ, bool COL>
+__global__ __launch_bounds__(ST_THREADS, 4) void k_rowfft_st(const cplx<T> *__restrict__ in,
+                                                             cplx<T> *__restrict__ out,
+                                                             const cplx<T> *__restrict__ tw, RowDifArgs a) {
+    using PL = StPlan<LOGQ>;
+    constexpr int R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, TPR = PL::TPR, A = PL::A, B = PL::B;
+    constexpr int Q = 1 << LOGQ, S1 = R2 * R3, RPW = ST_THREADS / TPR, ROW = R1 * A;
+    constexpr int NI2 = R1 * R3 / TPR, NI3 = R1 * R2 / TPR;
+    constexpr int L1 = ilog2_c(R1), L2 = ilog2_c(R2), L3 = ilog2_c(R3);
+    constexpr bool WAVE = TPR == 64 && !COL;
+    static_assert(S1 == TPR, "one pass-1 item per thread");
+    __shared__ T smem[RPW * ROW];
+
+    const int tid = threadIdx.x;
+    const int vb = blockIdx.x;
+    const int tt = vb >> 3;
+    const int p = tt % a.P;
+    const int64_t grp = (int64_t)(tt / a.P) * 8 + (vb & 7);
+    const int64_t row0 = grp * RPW;
+    if (row0 >= a.nrows) return;  // workgroup-uniform
+    const int r = COL ? tid % RPW : tid / TPR;
+    const int u = COL ? tid / RPW : tid % TPR;
+    const int64_t row = row0 + r;
+    const bool ok = row < a.nrows;
+    const int n2 = a.n2;
+    T *rb = smem + r * ROW;
+
+    // ---- pass 1: load (+ twiddle / fold for the residue), radix R1, twiddle ---------------------
+    cplx<T> va[R1];
+    {
+        const cplx<T> *rin = in + (ok ? (row / a.rpp) * a.in_plane + (row % a.rpp) * a.in_row : 0);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int q = u + n1 * S1;
+            va[n1] = {T(0), T(0)};
+            if (ok && q < a.n_in) va[n1] = rin[COL ? (int64_t)q * a.in_elem : (int64_t)q];
+        }
+        if (p) {
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const int q = u + n1 * S1;
+                if (ok && q < a.n_in) va[n1] = cmul(va[n1], tw[q * p]);  // q p < Q P = n2
+            }
+        }
+        if (a.n_in > Q && ok) {  // fold: x[q + k Q] w^{(q + k Q) p}
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const int q = u + n1 * S1;
+                int rk = p;  // (k p) mod P
+                for (int ia = q + Q; ia < a.n_in; ia += Q) {
+                    int ti = q * p + Q * rk;
+                    if (ti >= n2) ti -= n2;
+                    const cplx<T> x = cmul(rin[COL ? (int64_t)ia * a.in_elem : (int64_t)ia], tw[ti]);
+                    va[n1] = {va[n1].re + x.re, va[n1].im + x.im};
+                    rk += p;
+                    if (rk >= a.P) rk -= a.P;
+                }
+            }
+        }
+    }
+    dif_regs<T, R1>(va);
+    st_twiddle<T, R1>(va, tw[u * a.P]);  // w_Q^{u k1} = w_{n2}^{P u k1}
+    const int s1 = (u / R3) * B + (u % R3);
+
+    int base2[NI2], base3[NI3];
+#pragma unroll
+    for (int i = 0; i < NI2; ++i) {
+        const int v = u + i * TPR;
+        base2[i] = (v % R1) * A + (v / R1);
+    }
+#pragma unroll
+    for (int i = 0; i < NI3; ++i) {
+        const int v = u + i * TPR;
+        base3[i] = (v % R1) * A + (v / R1) * B;
+    }
+
+    // ---- exchange 1 -> pass 2 -------------------------------------------------------------------
+    cplx<T> vb2[NI2][R2];
+#pragma unroll
+    for (int k = 0; k < R1; ++k) rb[s1 + k * A] = va[bitrev_small(k, L1)].re;
+    st_sync<WAVE>();
+#pragma unroll
+    for (int i = 0; i < NI2; ++i)
+#pragma unroll
+        for (int n = 0; n < R2; ++n) vb2[i][n].re = rb[base2[i] + n * B];
+    st_sync<WAVE>();
+#pragma unroll
+    for (int k = 0; k < R1; ++k) rb[s1 + k * A] = va[bitrev_small(k, L1)].im;
+    st_sync<WAVE>();
+#pragma unroll
+    for (int i = 0; i < NI2; ++i)
+#pragma unroll
+        for (int n = 0; n < R2; ++n) vb2[i][n].im = rb[base2[i] + n * B];
+
+#pragma unroll
+    for (int i = 0; i < NI2; ++i) {
+        const int j3 = (u + i * TPR) / R1;
+        dif_regs<T, R2>(vb2[i]);
+        st_twiddle<T, R2>(vb2[i], tw[j3 * a.P * R1]);  // w_{Q/R1}^{j3 k2}
+    }
+
+    // ---- exchange 2 -> pass 3 (pass-2 items write back to the slots they read: no sync before) --
+    cplx<T> vc[NI3][R3];
+#pragma unroll
+    for (int i = 0; i < NI2; ++i)
+#pragma unroll
+        for (int k = 0; k < R2; ++k) rb[base2[i] + k * B] = vb2[i][bitrev_small(k, L2)].re;
+    st_sync<WAVE>();
+#pragma unroll
+    for (int i = 0; i < NI3; ++i)
+#pragma unroll
+        for (int n = 0; n < R3; ++n) vc[i][n].re = rb[base3[i] + n];
+    st_sync<WAVE>();
+#pragma unroll
+    for (int i = 0; i < NI2; ++i)
+#pragma unroll
+        for (int k = 0; k < R2; ++k) rb[base2[i] + k * B] = vb2[i][bitrev_small(k, L2)].im;
+    st_sync<WAVE>();
+#pragma unroll
+    for (int i = 0; i < NI3; ++i)
+#pragma unroll
+        for (int n = 0; n < R3; ++n) vc[i][n].im = rb[base3[i] + n];
+
+    // ---- pass 3 and this residue's outputs: k' = v + k3 Q/R3, l = P k' + p (mod n2, signed) ------
+    if (!ok) return;
+    const int half_n = a.n_out / 2;
+    const int hshift = a.n_in / 2;
+    int si = (int)((-(int64_t)hshift * a.P * (Q / R3)) % n2);
+    if (si < 0) si += n2;
+    const cplx<T> step = tw[si];
+    cplx<T> *rout = out + row * a.out_pitch + half_n;
+#pragma unroll
+    for (int i = 0; i < NI3; ++i) {
+        const int v = u + i * TPR;
+        dif_regs<T, R3>(vc[i]);
+        int ti = (int)((-(int64_t)hshift * ((int64_t)a.P * v + p)) % n2);
+        if (ti < 0) ti += n2;
+        cplx<T> t = tw[ti];
+#pragma unroll
+        for (int k = 0; k < R3; ++k) {
+            const int kk = v + k * (Q / R3);
+            const int l = a.P * (kk < Q / 2 ? kk : kk - Q) + p;
+            if (l >= -half_n && l < a.n_out - half_n) rout[l] = cmul(vc[i][bitrev_small(k, L3)], t);
+            if (k + 1 < R3) t = cmul(t, step);
+        }
+    }
+}
+
 // [batch][R][C] -> [batch][C][R], 32x32 tiles through LDS (both sides coalesced).
 template <typename T>
 __global__ void k_transpose(const cplx<T> *__restrict__ in, cplx<T> *__restrict__ out, int R, int C) {
@@ -1062,6 +1268,11 @@ void Nufft3<T>::spread(int ntrans, hipEvent_t e0, hipEvent_t e1) {
 // Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision):
 // Q/8 threads per row (16..512), 256..512 threads per workgroup.
 inline void rowfft_shape(const DimGeom &g, int &tpr, int &rpw) {
+    if (g.logQ >= 9 && g.logQ <= 12) {  // register-resident kernel: Q/16 threads per row (64 for 512)
+        tpr = g.logQ == 9 ? 64 : g.Q / 16;
+        rpw = ST_THREADS / tpr;
+        return;
+    }
     tpr = 16;
     while (tpr < 512 && tpr < g.Q / FV_FFT_TPR_DIV1) tpr *= 2;
     rpw = std::max(1, FFT_THREADS / tpr);
@@ -1096,6 +1307,24 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.in_row = in_row;
     a.in_elem = in_elem;
     a.out_pitch = g.no;
+    const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
+    const dim3 jobs((unsigned)(ngroups8 * 8 * g.P));
+    if (g.logQ >= 9 && g.logQ <= 12 && !std::getenv("FFTVIS_HIP_OLD_FFT")) {
+        const bool col = a.colmode != 0;
+#define FV_ST_LAUNCH(LQ)                                                                               \
+    if (col)                                                                                           \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, true>), jobs, dim3(ST_THREADS), 0, stream, in, out, twd, a); \
+    else                                                                                               \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, false>), jobs, dim3(ST_THREADS), 0, stream, in, out, twd, a);
+        switch (g.logQ) {
+            case 9: FV_ST_LAUNCH(9) break;
+            case 10: FV_ST_LAUNCH(10) break;
+            case 11: FV_ST_LAUNCH(11) break;
+            default: FV_ST_LAUNCH(12) break;
+        }
+#undef FV_ST_LAUNCH
+        return;
+    }
     const size_t smem = sizeof(cplx<T>) * (size_t)a.lds_row * a.rpw;
     static bool attr_set_dif = false;
     if (!attr_set_dif) {
@@ -1103,9 +1332,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set_dif = true;
     }
-    const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
-    hipLaunchKernelGGL(k_rowfft_dif<T>, dim3((unsigned)(ngroups8 * 8 * g.P)), dim3(a.tpr * a.rpw),
-                       smem, stream, in, out, twd, a);
+    hipLaunchKernelGGL(k_rowfft_dif<T>, jobs, dim3(a.tpr * a.rpw), smem, stream, in, out, twd, a);
 }
 
 // Algorithmic traffic of fft(): every pass reads its input once and writes its pruned output once
