@@ -534,7 +534,7 @@ struct RowDifArgs {
     int n_in, n_out, n2, P, Q, logQ, tpr, rpw;
     int npass, radix_log[4];
     int lds_row, colmode;
-    int64_t nrows, rpp, in_plane, in_row, in_elem, out_pitch;
+    int64_t nrows, rpp, rpp_valid, in_plane, in_row, in_elem, out_pitch;  // rows k >= rpp_valid of a plane are padding
 };
 
 template <typename T>
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(512, 4) void k_rowfft_dif(const cplx<T> *__restrict
         const int rr = a.colmode ? (tid & (a.rpw - 1)) : r;  // colmode: lanes over adjacent columns
         const int q0 = a.colmode ? tid / a.rpw : lane;
         const int64_t rw = row0 + rr;
-        const bool ok = rw < a.nrows;
+        const bool ok = rw < a.nrows && rw % a.rpp < a.rpp_valid;
         const cplx<T> *rin = in + (ok ? (rw / a.rpp) * a.in_plane + (rw % a.rpp) * a.in_row : 0);
         cplx<T> *crb = smem + (int64_t)rr * a.lds_row;
         for (int q = q0; q < Q; q += a.tpr) {
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(512, 4) void k_rowfft_dif(const cplx<T> *__restrict
 
     // ---- this residue's outputs: l = l0 + P i, l in [-n_out/2, n_out/2) -----------------------------
     const int64_t row = row0 + r;
-    if (row >= a.nrows) return;
+    if (row >= a.nrows || row % a.rpp >= a.rpp_valid) return;
     const int half_n = a.n_out / 2;
     int d0 = (p + half_n) % a.P;  // (p - (-half_n)) mod P
     const int lfirst = -half_n + d0 + a.P * lane;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(512, 4) void k_rowfft_dif(const cplx<T> *__restrict
     int si = (int)((-(int64_t)hshift * a.P * a.tpr) % n2);
     if (si < 0) si += n2;
     const cplx<T> step = tw[si];
-    cplx<T> *rout = out + row * a.out_pitch + half_n;
+    cplx<T> *rout = out + ((row / a.rpp) * a.rpp_valid + row % a.rpp) * a.out_pitch + half_n;
     // k' = (l - p) / P advances by tpr per step: no division inside the loop
     int kq = (lfirst - p) / a.P;
     for (int l = lfirst; l < a.n_out - half_n; l += a.P * a.tpr, kq += a.tpr) {
@@ -634,28 +634,35 @@ __global__ __launch_bounds__(512, 4) void k_rowfft_dif(const cplx<T> *__restrict
 // The exchange moves real and imaginary parts one after the other through one T-typed buffer of
 // R1*A slots per row (8.4 KiB at Q = 1024 fp64 instead of 17.5 KiB for a complex row), so twice as
 // many rows are in flight per CU, and every element crosses LDS 4 times instead of 8.
-// Slot of element (k1, j2, j3) = k1 A + j2 B + j3: A, B chosen (scratch bank model, 8-byte slots,
-// 32 lanes per LDS pass) so that the pass-1 writes and the pass-2 accesses are conflict-free and
-// the pass-3 reads at most 2-way.
-template <int LOGQ>
+// Slot of element (k1, j2, j3) of row r = r ROW + k1 A + j2 B + j3: A, B, ROW searched with a bank
+// model of ds_read_b64 (2 x 32 lanes, 32 slot classes) and ds_write_b64 (4 x 16 lanes, 16 classes)
+// so that the pass-1 writes and the pass-2 accesses are conflict-free and the pass-3 reads at
+// most 2-way, in row mode and in column mode (512 threads, lanes interleave 8 rows, so that a
+// workgroup reads whole 128-B lines of 8 adjacent columns).
+template <int LOGQ, bool COL>
 struct StPlan;
-template <>
-struct StPlan<9> {
-    static constexpr int R1 = 8, R2 = 8, R3 = 8, TPR = 64, A = 76, B = 9;
+template <bool COL>
+struct StPlan<9, COL> {  // column mode interleaves 8 rows over the lanes: its own padding
+    static constexpr int R1 = 8, R2 = 8, R3 = 8, TPR = 64, A = COL ? 72 : 76, B = COL ? 8 : 9,
+                         ROW = COL ? 577 : 608;
 };
-template <>
-struct StPlan<10> {
-    static constexpr int R1 = 16, R2 = 8, R3 = 8, TPR = 64, A = 66, B = 8;
+template <bool COL>
+struct StPlan<10, COL> {
+    static constexpr int R1 = 16, R2 = 8, R3 = 8, TPR = 64, A = COL ? 72 : 66, B = 8, ROW = COL ? 1153 : 1056;
 };
-template <>
-struct StPlan<11> {
-    static constexpr int R1 = 16, R2 = 16, R3 = 8, TPR = 128, A = 130, B = 8;
+template <bool COL>
+struct StPlan<11, COL> {
+    static constexpr int R1 = 16, R2 = 16, R3 = 8, TPR = 128, A = 130, B = 8, ROW = 2080;
 };
-template <>
-struct StPlan<12> {
-    static constexpr int R1 = 16, R2 = 16, R3 = 16, TPR = 256, A = 258, B = 16;
+template <bool COL>
+struct StPlan<12, COL> {
+    static constexpr int R1 = 16, R2 = 16, R3 = 16, TPR = 256, A = 258, B = 16, ROW = 4128;
 };
-constexpr int ST_THREADS = 256;
+#ifndef FV_ST_MINW12
+#define FV_ST_MINW12 3  // waves per SIMD targeted by the register allocation of the Q = 4096 kernels
+#endif
+constexpr int ST_THREADS = 256;      // row mode
+constexpr int ST_THREADS_COL = 512;  // column mode
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v / 2); }
 
 template <bool WAVE>
@@ -681,13 +688,18 @@ __device__ inline void st_twiddle(cplx<T> *v, cplx<T> w) {
     }
 }
 
-template <typename T, int LOGQ, bool COL>
-__global__ __launch_bounds__(ST_THREADS, 4) void k_rowfft_st(const cplx<T> *__restrict__ in,
-                                                             cplx<T> *__restrict__ out,
-                                                             const cplx<T> *__restrict__ tw, RowDifArgs a) {
-    using PL = StPlan<LOGQ>;
+// NLD = number of leading pass-1 operands that can be non-zero (n_in <= NLD Q/R1): the rest are
+// compile-time zeros, which prunes the first butterfly stages.
+// (Running the P residue jobs of a row group as one lock-stepped workgroup, with or without
+// staging the merged row in LDS, was measured slower than separate workgroups on Q = 4096, P = 2.)
+template <typename T, int LOGQ, bool COL, int NLD>
+__global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_ST_MINW12 : 4) void k_rowfft_st(
+    const cplx<T> *__restrict__ in, cplx<T> *__restrict__ out, const cplx<T> *__restrict__ tw, RowDifArgs a) {
+    using PL = StPlan<LOGQ, COL>;
     constexpr int R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, TPR = PL::TPR, A = PL::A, B = PL::B;
-    constexpr int Q = 1 << LOGQ, S1 = R2 * R3, RPW = ST_THREADS / TPR, ROW = R1 * A;
+    constexpr int THREADS = COL ? ST_THREADS_COL : ST_THREADS;
+    constexpr int Q = 1 << LOGQ, S1 = R2 * R3, RPW = THREADS / TPR, ROW = PL::ROW;
+    static_assert(ROW >= R1 * A && A >= R2 * B && B >= R3, "LDS layout");
     constexpr int NI2 = R1 * R3 / TPR, NI3 = R1 * R2 / TPR;
     constexpr int L1 = ilog2_c(R1), L2 = ilog2_c(R2), L3 = ilog2_c(R3);
     constexpr bool WAVE = TPR == 64 && !COL;
@@ -704,40 +716,55 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_rowfft_st(const cplx<T> *__re
     const int r = COL ? tid % RPW : tid / TPR;
     const int u = COL ? tid / RPW : tid % TPR;
     const int64_t row = row0 + r;
-    const bool ok = row < a.nrows;
+    const int64_t rplane = row / a.rpp, rk = row % a.rpp;
+    const bool ok = row < a.nrows && rk < a.rpp_valid;
     const int n2 = a.n2;
     T *rb = smem + r * ROW;
 
     // ---- pass 1: load (+ twiddle / fold for the residue), radix R1, twiddle ---------------------
     cplx<T> va[R1];
     {
-        const cplx<T> *rin = in + (ok ? (row / a.rpp) * a.in_plane + (row % a.rpp) * a.in_row : 0);
+        // branch-free loads (clamped index, masked afterwards) so that a chunk's requests issue
+        // back to back; chunks of 8 bound the registers held by data + residue twiddles in flight
+        const cplx<T> *rin = in + (ok ? rplane * a.in_plane + rk * a.in_row : 0);
+        const int qmax = a.n_in - 1;
+        constexpr int CH = NLD < 8 ? NLD : 8;
 #pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) {
-            const int q = u + n1 * S1;
-            va[n1] = {T(0), T(0)};
-            if (ok && q < a.n_in) va[n1] = rin[COL ? (int64_t)q * a.in_elem : (int64_t)q];
-        }
-        if (p) {
+        for (int h = 0; h < NLD; h += CH) {
+            cplx<T> x[CH];
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) {
-                const int q = u + n1 * S1;
-                if (ok && q < a.n_in) va[n1] = cmul(va[n1], tw[q * p]);  // q p < Q P = n2
+            for (int j = 0; j < CH; ++j) {
+                const int qq = min(u + (h + j) * S1, qmax);
+                x[j] = rin[COL ? (int64_t)qq * a.in_elem : (int64_t)qq];
             }
-        }
-        if (a.n_in > Q && ok) {  // fold: x[q + k Q] w^{(q + k Q) p}
+            if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
+                cplx<T> w[CH];
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) {
-                const int q = u + n1 * S1;
-                int rk = p;  // (k p) mod P
-                for (int ia = q + Q; ia < a.n_in; ia += Q) {
-                    int ti = q * p + Q * rk;
-                    if (ti >= n2) ti -= n2;
-                    const cplx<T> x = cmul(rin[COL ? (int64_t)ia * a.in_elem : (int64_t)ia], tw[ti]);
-                    va[n1] = {va[n1].re + x.re, va[n1].im + x.im};
-                    rk += p;
-                    if (rk >= a.P) rk -= a.P;
-                }
+                for (int j = 0; j < CH; ++j) w[j] = tw[min(u + (h + j) * S1, qmax) * p];  // q p < Q P = n2
+#pragma unroll
+                for (int j = 0; j < CH; ++j) x[j] = cmul(x[j], w[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const bool live = ok && u + (h + j) * S1 <= qmax;
+                va[h + j] = {live ? x[j].re : T(0), live ? x[j].im : T(0)};
+            }
+            if (h + CH < NLD) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int n1 = NLD; n1 < R1; ++n1) va[n1] = {T(0), T(0)};
+        if (NLD == R1 && a.n_in > Q && ok) {  // fold: x[q + k Q] w^{(q + k Q) p}
+            for (int ia = u + Q; ia < a.n_in; ia += TPR) {  // the few elements beyond Q: n1 = 0 slots first
+                // element ia folds onto q = ia mod Q, held by thread q mod S1 in register q / S1
+                const int q = ia & (Q - 1);
+                const int kq = ia >> LOGQ;
+                int ti = (int)(((int64_t)q * p + (int64_t)Q * ((kq * p) % a.P)) % n2);
+                const cplx<T> xv = cmul(rin[COL ? (int64_t)ia * a.in_elem : (int64_t)ia], tw[ti]);
+                // q mod S1 == u because ia = u + Q + m TPR and TPR == S1 divides Q
+                const int n1 = q / S1;
+#pragma unroll
+                for (int j = 0; j < R1; ++j)
+                    if (j == n1) va[j] = {va[j].re + xv.re, va[j].im + xv.im};
             }
         }
     }
@@ -811,14 +838,14 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_rowfft_st(const cplx<T> *__re
     int si = (int)((-(int64_t)hshift * a.P * (Q / R3)) % n2);
     if (si < 0) si += n2;
     const cplx<T> step = tw[si];
-    cplx<T> *rout = out + row * a.out_pitch + half_n;
+    cplx<T> *rout = out + (rplane * a.rpp_valid + rk) * a.out_pitch + half_n;
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
         const int v = u + i * TPR;
         dif_regs<T, R3>(vc[i]);
-        int ti = (int)((-(int64_t)hshift * ((int64_t)a.P * v + p)) % n2);
-        if (ti < 0) ti += n2;
-        cplx<T> t = tw[ti];
+        // (-hshift (P v + p)) mod n2 in 32 bits: hshift <= n2 / 2, P v + p < n2 <= 2^16
+        const unsigned tm = ((unsigned)hshift * (unsigned)(a.P * v + p)) % (unsigned)n2;
+        cplx<T> t = tw[tm ? n2 - (int)tm : 0];
 #pragma unroll
         for (int k = 0; k < R3; ++k) {
             const int kk = v + k * (Q / R3);
@@ -1206,7 +1233,9 @@ class Nufft3 {
 
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
-                int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row, int64_t in_elem);
+                int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row, int64_t in_elem,
+                int64_t out_pitch = 0, int64_t rpp_valid = 0);
+    int64_t b_pitch() const;  // row pitch of the x-pass output
     cplx<T> *grid_out = nullptr;  // where the last fft() left Ct
 };
 
@@ -1242,11 +1271,37 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
 }
 
 // Largest buffer (cells per transform) each ping-pong buffer has to hold during spread + fft.
+// Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision):
+// Q/8 threads per row (16..512), 256..512 threads per workgroup.
+inline bool rowfft_uses_st(const DimGeom &g, bool col) {  // register-resident kernel applies
+    return g.logQ >= 9 && g.logQ <= (col ? 10 : 12) && !std::getenv("FFTVIS_HIP_OLD_FFT");
+}
+inline void rowfft_shape(const DimGeom &g, bool col, int &tpr, int &rpw) {
+    if (rowfft_uses_st(g, col)) {  // Q/16 threads per row (64 for 512); 8 columns / 1-4 rows per workgroup
+        tpr = g.logQ == 9 ? 64 : g.Q / 16;
+        rpw = (col ? ST_THREADS_COL : ST_THREADS) / tpr;
+        return;
+    }
+    tpr = 16;
+    while (tpr < 512 && tpr < g.Q / FV_FFT_TPR_DIV1) tpr *= 2;
+    rpw = std::max(1, FFT_THREADS / tpr);
+}
+
+// The y-pass reads 8 adjacent columns of B per workgroup when it can (column mode): B's rows are
+// then padded to a multiple of 8 elements so that those 128-B segments are whole cache lines.
+template <typename T>
+int64_t Nufft3<T>::b_pitch() const {
+    const DimGeom &x = geo.d[0], &y = geo.d[1];
+    int tpr, rpw;
+    rowfft_shape(y, true, tpr, rpw);
+    return rpw >= 8 ? (x.no + 7) / 8 * 8 : x.no;
+}
+
 template <typename T>
 void Nufft3<T>::buffer_cells(int64_t &c0, int64_t &c1) const {
     const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
     const int64_t zin = dim > 2 ? z.na : 1, zout = dim > 2 ? z.no : 1;
-    const int64_t A = zin * y.na * x.na, B = zin * y.na * x.no, C = zin * x.no * y.no,
+    const int64_t A = zin * y.na * x.na, B = zin * y.na * b_pitch(), C = zin * x.no * y.no,
                   D = zout * x.no * y.no;
     c0 = std::max({A, B, C, D});  // either buffer may end up holding any stage (transpose or not)
     c1 = c0;
@@ -1265,24 +1320,11 @@ void Nufft3<T>::spread(int ntrans, hipEvent_t e0, hipEvent_t e1) {
     launch_spread<1>(ntrans, t, e0, e1);
 }
 
-// Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision):
-// Q/8 threads per row (16..512), 256..512 threads per workgroup.
-inline void rowfft_shape(const DimGeom &g, int &tpr, int &rpw) {
-    if (g.logQ >= 9 && g.logQ <= 12) {  // register-resident kernel: Q/16 threads per row (64 for 512)
-        tpr = g.logQ == 9 ? 64 : g.Q / 16;
-        rpw = ST_THREADS / tpr;
-        return;
-    }
-    tpr = 16;
-    while (tpr < 512 && tpr < g.Q / FV_FFT_TPR_DIV1) tpr *= 2;
-    rpw = std::max(1, FFT_THREADS / tpr);
-}
-
 // rows = nplanes * rpp; element ia of row (plane, k) sits at plane*in_plane + k*in_row + ia*in_elem.
 template <typename T>
 void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                        int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row,
-                       int64_t in_elem) {
+                       int64_t in_elem, int64_t out_pitch, int64_t rpp_valid) {
     static const int plans[9][4] = {{4, 0, 0, 0}, {3, 2, 0, 0}, {3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0},
                                     {3, 3, 3, 0}, {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 4 .. 12
     FV_REQUIRE(g.logQ >= 4 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
@@ -1299,30 +1341,43 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         if (a.radix_log[s]) ++a.npass;
     }
     a.lds_row = fft_pidx(g.Q) | 1;
-    rowfft_shape(g, a.tpr, a.rpw);
     a.colmode = in_elem != 1;
+    rowfft_shape(g, a.colmode != 0, a.tpr, a.rpw);
     a.nrows = nplanes * rpp;
     a.rpp = rpp;
+    a.rpp_valid = rpp_valid ? rpp_valid : rpp;
     a.in_plane = in_plane;
     a.in_row = in_row;
     a.in_elem = in_elem;
-    a.out_pitch = g.no;
+    a.out_pitch = out_pitch ? out_pitch : g.no;
     const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
     const dim3 jobs((unsigned)(ngroups8 * 8 * g.P));
-    if (g.logQ >= 9 && g.logQ <= 12 && !std::getenv("FFTVIS_HIP_OLD_FFT")) {
+    if (rowfft_uses_st(g, a.colmode != 0)) {
+        const int s1 = g.Q / (g.logQ == 9 ? 8 : 16);       // stride of the first radix pass
+        const int need = (int)cdiv(std::min(a.n_in, g.Q), s1);
+        const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;  // possibly non-zero inputs per thread
         const bool col = a.colmode != 0;
-#define FV_ST_LAUNCH(LQ)                                                                               \
-    if (col)                                                                                           \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, true>), jobs, dim3(ST_THREADS), 0, stream, in, out, twd, a); \
+#define FV_ST_GO(LQ, COLM, NLD)                                                                        \
+    hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD>), jobs, dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0,   \
+                       stream, in, out, twd, a)
+#define FV_ST_NLD(LQ, COLM)                                                                            \
+    if (nld == 4)                                                                                      \
+        FV_ST_GO(LQ, COLM, 4);                                                                         \
+    else if (nld == 8 || LQ == 9)                                                                      \
+        FV_ST_GO(LQ, COLM, 8);                                                                         \
     else                                                                                               \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, false>), jobs, dim3(ST_THREADS), 0, stream, in, out, twd, a);
-        switch (g.logQ) {
-            case 9: FV_ST_LAUNCH(9) break;
-            case 10: FV_ST_LAUNCH(10) break;
-            case 11: FV_ST_LAUNCH(11) break;
-            default: FV_ST_LAUNCH(12) break;
+        FV_ST_GO(LQ, COLM, (LQ == 9 ? 8 : 16));
+        if (g.logQ == 9) {
+            if (col) { FV_ST_NLD(9, true) } else { FV_ST_NLD(9, false) }
+        } else if (g.logQ == 10) {
+            if (col) { FV_ST_NLD(10, true) } else { FV_ST_NLD(10, false) }
+        } else if (g.logQ == 11) {
+            FV_ST_NLD(11, false)
+        } else {
+            FV_ST_NLD(12, false)
         }
-#undef FV_ST_LAUNCH
+#undef FV_ST_NLD
+#undef FV_ST_GO
         return;
     }
     const size_t smem = sizeof(cplx<T>) * (size_t)a.lds_row * a.rpw;
@@ -1342,7 +1397,7 @@ double Nufft3<T>::fft_traffic_cells() const {
     const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
     const double zin = dim > 2 ? z.na : 1;
     int tpr, rpw;
-    rowfft_shape(y, tpr, rpw);
+    rowfft_shape(y, true, tpr, rpw);
     double c = zin * ((double)x.na * y.na + (double)x.no * y.na);        // x-pass
     if (rpw < 4) c += zin * 2.0 * x.no * y.na;                            // transpose
     c += zin * ((double)x.no * y.na + (double)x.no * y.no);              // y-pass
@@ -1359,15 +1414,17 @@ void Nufft3<T>::fft(int ntrans) {
     cplx<T> *cur = buf0.as<cplx<T>>(), *oth = buf1.as<cplx<T>>();
     const int64_t zin = dim > 2 ? z.na : 1;       // planes per transform before the z-pass
     const int64_t np = (int64_t)ntrans * zin;     // (trans, z) planes
-    // x-pass: A [p][na_y][na_x] -> B [p][na_y][no_x]
-    rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1);
+    // x-pass: A [p][na_y][na_x] -> B [p][na_y][xp]   (xp = no_x, padded to 8 for column mode)
+    const int64_t xp = b_pitch();
+    rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp);
     std::swap(cur, oth);
     int tpr, rpw;
-    rowfft_shape(y, tpr, rpw);
+    rowfft_shape(y, true, tpr, rpw);
     if (rpw >= 4) {
-        // short columns: the y-pass reads rpw adjacent columns of B at once (64-256 B segments),
-        // which fuses the transpose:  B -> C [p][no_x][no_y]
-        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, x.no, (int64_t)y.na * x.no, 1, x.no);
+        // short columns: the y-pass reads rpw adjacent columns of B at once (64-128 B segments),
+        // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
+        // plane are skipped as rows
+        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.no);
         std::swap(cur, oth);
     } else {
         // long columns: explicit tile transpose B -> Bt [p][no_x][na_y], then contiguous rows

@@ -90,6 +90,29 @@ def test_nufft2d_shapes_and_edge_cases(gpu):
     assert rel_l2(gpu_nufft2d(xo, yo, c, so, to, 1e-9), nudft.nudft_type3([xo, yo], c, [so, to])) < 2e-8
 
 
+@pytest.mark.parametrize(
+    "Sx,Sy",
+    [(62, 128), (128, 62), (256, 62), (62, 256), (520, 128), (128, 520), (390, 200), (200, 390),
+     (1040, 62), (62, 1040), (700, 700)],
+)
+def test_nufft2d_every_row_fft_length(gpu, Sx, Sy):
+    """Target extents chosen so that the fine grid (n2 = P * Q per dimension) walks through every
+    row-FFT length the register-resident kernel handles -- Q = 512, 1024, 2048, 4096 with P = 1, 2,
+    3, contiguous rows (x) and column mode / transposed (y) -- at sizes where the exact sum is
+    cheap.  fp64 at eps = 1e-9 and fp32 at 1e-4."""
+    rng = np.random.default_rng(3)
+    M, N = 400, 300
+    x, y = rng.uniform(-3, 3, (2, M))
+    c = rng.normal(size=(3, M)) + 1j * rng.normal(size=(3, M))
+    s = rng.uniform(-Sx, Sx, N)
+    t = rng.uniform(-Sy, Sy, N)
+    ex = nudft.nudft_type3([x, y], c, [s, t])
+    assert rel_l2(gpu_nufft2d(x, y, c, s, t, 1e-9), ex) < 5e-9
+    f32 = gpu_nufft2d(x.astype(np.float32), y.astype(np.float32), c.astype(np.complex64),
+                      s.astype(np.float32), t.astype(np.float32), 1e-4)
+    assert f32.dtype == np.complex64 and rel_l2(f32, ex) < 1e-3
+
+
 @pytest.mark.parametrize("eps", [1e-3, 6e-8, 1e-12])
 def test_nufft3d_meets_eps(gpu, eps):
     """gpu_nufft3d vs the exact sum (reference cpu/nufft.py:62-118 -> finufft.nufft3d3), for a
