@@ -293,20 +293,27 @@ __global__ void k_load_strengths(int64_t M, const int *__restrict__ Mp, int ntra
 // written once (zeros included, deconvolution applied).  grid (ceil(nbx / 4), nby, chunks).
 constexpr int SPREAD_CHUNK = 16;
 
+#ifndef FV_SPREAD_MINW
+#define FV_SPREAD_MINW 3
+#endif
 template <typename T, int TCH>
-__global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
+__global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
     int64_t M, const int *__restrict__ i0s, const T *__restrict__ kw,
     const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans, int tbegin,
     const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid, int nax,
-    int nay, int nbx, int w) {
+    int nay, int nbx, int w, const int *__restrict__ order, int nchunk) {
     __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TCH];
     __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][MAX_W];
     __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int bx = blockIdx.x * 4 + wave, by = blockIdx.y;
+    // workgroup id -> (4 blocks of one bin row, transform chunk): `order` lists the 4-block groups
+    // by decreasing expected load (see Nufft3::build_block_order), chunks fastest, so that the
+    // heavy groups of every chunk start first and the light ones fill the tail
+    const int og = order[blockIdx.x / nchunk];
+    const int bx = (og & 0xffff) * 4 + wave, by = og >> 16;
     if (bx >= nbx) return;  // wave-uniform
-    const int tbase = tbegin + blockIdx.z * TCH;  // the launcher only issues whole chunks
+    const int tbase = tbegin + (blockIdx.x % nchunk) * TCH;  // the launcher only issues whole chunks
     const int cx = (bx << BINLOG) + (lane & 7), cy = (by << BINLOG) + (lane >> 3);
     const int *i0x = i0s, *i0y = i0s + M;
     const T *kwx = kw, *kwy = kw + M * w;
@@ -315,43 +322,108 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread2d(
     for (int q = 0; q < TCH; ++q) ar[q] = ai[q] = T(0);
     const int bxl = max((bx << BINLOG) - w + 1, 0) >> BINLOG;
     const int byl = max((by << BINLOG) - w + 1, 0) >> BINLOG;
-    for (int yb = byl; yb <= by; ++yb) {
-        // bins bxl .. bx of one bin row are contiguous in the sorted order
-        const int s0 = bin_start[yb * nbx + bxl], s1 = bin_start[yb * nbx + bx + 1];
-        for (int base = s0; base < s1; base += SPREAD_CHUNK) {
-            const int n = min(SPREAD_CHUNK, s1 - base);
-            // ---- stage the chunk (wave-private LDS slice; same-wave LDS ops stay in order) ----
-            for (int e = lane; e < n * TCH; e += 64) {
-                const int j = e / TCH, q = e % TCH;
-                s_str[wave][j][q] = cs[(int64_t)(base + j) * ntrans + tbase + q];
-            }
-            for (int e = lane; e < n * w; e += 64) {
-                const int j = e / w, k = e - j * w;
-                s_kw[wave][j][0][k] = kwx[(int64_t)(base + j) * w + k];
-                s_kw[wave][j][1][k] = kwy[(int64_t)(base + j) * w + k];
-            }
-            if (lane < n) {
-                s_i0[wave][lane][0] = i0x[base + lane];
-                s_i0[wave][lane][1] = i0y[base + lane];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- accumulate from LDS ----------------------------------------------------------
-            for (int j = 0; j < n; ++j) {
-                const int dx = cx - s_i0[wave][j][0], dy = cy - s_i0[wave][j][1];
-                T wt = T(0);
-                if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
-                    wt = s_kw[wave][j][0][dx] * s_kw[wave][j][1][dy];
+    // bins bxl .. bx of one bin row are contiguous in the sorted order: up to 3 source ranges
+    // (w <= 16), walked as one sequence of chunks
+    int rs0[3], rnc[3];
 #pragma unroll
-                for (int q = 0; q < TCH; ++q) {
-                    const cplx<T> cv = s_str[wave][j][q];
-                    ar[q] += cv.re * wt;
-                    ai[q] += cv.im * wt;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next chunk
+    for (int r = 0; r < 3; ++r) {
+        const int yb = min(byl + r, by);
+        const int s0 = bin_start[yb * nbx + bxl], s1 = bin_start[yb * nbx + bx + 1];
+        rs0[r] = s0;
+        rnc[r] = byl + r <= by ? s1 - s0 : 0;  // sources in the range
+    }
+    const int nc0 = (rnc[0] + SPREAD_CHUNK - 1) / SPREAD_CHUNK, nc1 = (rnc[1] + SPREAD_CHUNK - 1) / SPREAD_CHUNK,
+              nc2 = (rnc[2] + SPREAD_CHUNK - 1) / SPREAD_CHUNK;
+    const int nct = nc0 + nc1 + nc2;
+    auto chunk_at = [&](int c, int &n) -> int {  // first source and size of chunk c (wave-uniform)
+        int r0 = rs0[0], len = rnc[0], k = c;
+        if (c >= nc0 + nc1) {
+            r0 = rs0[2];
+            len = rnc[2];
+            k = c - nc0 - nc1;
+        } else if (c >= nc0) {
+            r0 = rs0[1];
+            len = rnc[1];
+            k = c - nc0;
         }
+        n = min(SPREAD_CHUNK, len - k * SPREAD_CHUNK);
+        return r0 + k * SPREAD_CHUNK;
+    };
+    // a chunk travels global -> registers (requested one chunk ahead, so the loads fly while the
+    // previous chunk is accumulated) -> the wave's LDS slice -> broadcast reads
+    constexpr int NS = TCH >= 4 ? TCH / 4 : 1;  // strengths per lane: 16 TCH / 64
+    constexpr int NW = (SPREAD_CHUNK * MAX_W) / 64;  // weights per lane and dimension (w <= MAX_W)
+    cplx<T> ps[NS];
+    T pkx[NW], pky[NW];
+    int pix = 0, piy = 0;
+    auto request = [&](int base, int n) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int e = lane + 64 * i;
+            ps[i] = {T(0), T(0)};
+            if (e < n * TCH) ps[i] = cs[(int64_t)(base + e / TCH) * ntrans + tbase + e % TCH];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = lane + 64 * i;
+            pkx[i] = pky[i] = T(0);
+            if (e < n * w) {  // rows of w weights are contiguous: element e of the chunk's block
+                pkx[i] = kwx[(int64_t)base * w + e];
+                pky[i] = kwy[(int64_t)base * w + e];
+            }
+        }
+        if (lane < n) {
+            pix = i0x[base + lane];
+            piy = i0y[base + lane];
+        }
+    };
+    int n = 0, base = 0;
+    if (nct > 0) {
+        base = chunk_at(0, n);
+        request(base, n);
+    }
+    for (int c = 0; c < nct; ++c) {
+        // ---- registers -> LDS (wave-private slice; same-wave LDS ops stay in order) -----------
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int e = lane + 64 * i;
+            if (e < n * TCH) s_str[wave][e / TCH][e % TCH] = ps[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = lane + 64 * i;
+            if (e < n * w) {
+                const int j = e / w, k = e - j * w;
+                s_kw[wave][j][0][k] = pkx[i];
+                s_kw[wave][j][1][k] = pky[i];
+            }
+        }
+        if (lane < n) {
+            s_i0[wave][lane][0] = pix;
+            s_i0[wave][lane][1] = piy;
+        }
+        const int ncur = n;
+        if (c + 1 < nct) {
+            base = chunk_at(c + 1, n);
+            request(base, n);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- accumulate from LDS --------------------------------------------------------------
+        for (int j = 0; j < ncur; ++j) {
+            const int dx = cx - s_i0[wave][j][0], dy = cy - s_i0[wave][j][1];
+            T wt = T(0);
+            if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
+                wt = s_kw[wave][j][0][dx] * s_kw[wave][j][1][dy];
+#pragma unroll
+            for (int q = 0; q < TCH; ++q) {
+                const cplx<T> cv = s_str[wave][j][q];
+                ar[q] += cv.re * wt;
+                ai[q] += cv.im * wt;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next chunk
     }
     const T f = decx[cx] * decy[cy];
     const int64_t plane = (int64_t)nay * nax;
@@ -1067,6 +1139,44 @@ class Nufft3 {
         geo.dim = dim;
     }
 
+    // Launch order of the spread workgroups (groups of 4 blocks of one bin row), heaviest first.
+    // A wave's time grows with the sources that reach its block, and skies are far from uniform on
+    // the grid: directions uniform on the sphere pile up towards the rim of the (l, m) disc like
+    // 1 / sqrt(1 - r^2) (7x the central density in the outermost blocks of C2).  Dispatched in
+    // raster order, the heavy rim rows come last and the kernel ends in a long, nearly empty
+    // tail (measured: 4.8 resident waves per CU on average); heaviest-first lets the light central
+    // blocks fill that tail.  The weight is only a heuristic -- any order is correct.
+    DevBuf order;
+    std::vector<int> order_host;
+    void build_block_order() {
+        const int nbx = geo.nbin[0], nby = geo.nbin[1], ngx = (int)cdiv(nbx, 4);
+        std::vector<std::pair<float, int>> wg((size_t)ngx * nby);
+        for (int by = 0; by < nby; ++by) {
+            const double ry = ((by + 0.5) * (1 << BINLOG) - 0.5 * geo.d[1].na) / (0.5 * geo.d[1].na);
+            for (int gx = 0; gx < ngx; ++gx) {
+                double wsum = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const int bx = gx * 4 + k;
+                    if (bx >= nbx) break;
+                    const double rx = ((bx + 0.5) * (1 << BINLOG) - 0.5 * geo.d[0].na) / (0.5 * geo.d[0].na);
+                    const double r2 = rx * rx + ry * ry;
+                    wsum += r2 < 1.0 ? 1.0 / std::sqrt(std::max(1.0 - r2, 0.02)) : 0.05;
+                }
+                wg[(size_t)by * ngx + gx] = {(float)wsum, (by << 16) | gx};
+            }
+        }
+        // huge grids are HBM-bound and have thousands of groups per CU: raster order keeps their
+        // writes local and the tail is negligible there
+        if (wg.size() <= 16384)
+            std::stable_sort(wg.begin(), wg.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+        order_host.resize(wg.size());
+        for (size_t i = 0; i < wg.size(); ++i) order_host[i] = wg[i].second;
+        order.reserve(sizeof(int) * order_host.size());
+        FV_HIP(hipMemcpyAsync(order.p, order_host.data(), sizeof(int) * order_host.size(),
+                              hipMemcpyHostToDevice, stream));
+        FV_HIP(hipStreamSynchronize(stream));  // geometry changes are rare; keeps order_host reusable
+    }
+
     // Bounds -> grid sizes, deconvolution + twiddle tables.
     void set_geometry(const double *xc, const double *X, const double *btc, const double *B,
                       double scale_max) {
@@ -1081,6 +1191,7 @@ class Nufft3 {
             geo.nbin[d] = geo.d[d].na >> BINLOG;
         for (int d = dim; d < 3; ++d) geo.nbin[d] = 1;
         }
+        if (first || old.nbin[0] != geo.nbin[0] || old.nbin[1] != geo.nbin[1]) build_block_order();
         for (int d = 0; d < dim; ++d) {
             const DimGeom &g = geo.d[d];
             if (old.d[d].na == g.na && old.d[d].n2 == g.n2 && dec[d].p && !first) continue;
@@ -1250,13 +1361,14 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
     hipEvent_t es = tbegin == 0 ? e0 : nullptr;
     hipEvent_t ee = tbegin + nchunk * TCH == ntrans ? e1 : nullptr;
     if (dim == 2) {
-        dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)nchunk);
+        dim3 g((unsigned)(cdiv(geo.nbin[0], 4) * geo.nbin[1] * nchunk));
         hipExtLaunchKernelGGL((k_spread2d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
                               (const int *)i0s.as<int>(), (const T *)kw.as<T>(),
                               (const int *)bin_start.as<int>(),
                               (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin,
                               (const T *)dec[0].as<T>(), (const T *)dec[1].as<T>(),
-                              buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0], ker.w);
+                              buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0], ker.w,
+                              (const int *)order.as<int>(), nchunk);
     } else {
         dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)(z.na * nchunk));
         hipExtLaunchKernelGGL((k_spread3d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
