@@ -295,6 +295,17 @@ def main():
                 "algorithmic_bytes_per_launch": spread_bytes / launches,
                 "avg_launch_ms": tm["spread"] / launches,
             },
+            # the pruned row FFT is the largest share of the step; same accounting: algorithmic
+            # bytes of its passes over its summed pass durations (HIP events)
+            "roofline_fft": {
+                "kernel": "k_rowfft_st (x-pass + y-pass" + (" + k_transpose" if kern["grid"]["n2"][1] > 1024 else "") + ")",
+                "bound": "hbm",
+                "achieved": kern["fft_GBps"],
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": kern["fft_GBps"] / HBM_PEAK_GBS,
+                "share_of_step": tm_all["fft"] / max(sum(tm_all.values()), 1e-12),
+            },
             "kernels": kern,
         }
         if not a.no_cpu_baseline:
