@@ -448,6 +448,55 @@ def test_sim_type1_lattice_path(gpu):
     assert g32.dtype == np.complex64 and rel_l2(g32, exp) < 5e-3
 
 
+def _ref_hex_grid():
+    s3 = np.sqrt(3) / 2
+    pts = [(-0.5, s3), (0.5, s3), (-1.0, 0.0), (0.0, 0.0), (1.0, 0.0), (-0.5, -s3), (0.5, -s3)]
+    return {i: np.array([x, y, 0.0]) for i, (x, y) in enumerate(pts)}
+
+
+def _ref_square_grid(n_side=3, spacing=10.0):
+    return {i * n_side + j: spacing * np.array([i, j, 0.0]) for i in range(n_side) for j in range(n_side)}
+
+
+@pytest.mark.parametrize("polarized", [False, True])
+@pytest.mark.parametrize("precision", [2, 1])
+@pytest.mark.parametrize("shear_array", [True, False])
+@pytest.mark.parametrize("rotate_array", [True, False])
+@pytest.mark.parametrize("remove_antennas", [True, False])
+@pytest.mark.parametrize("grid", ["hex", "square"])
+def test_simulate_gridded_type1_vs_type3(gpu, polarized, precision, shear_array, rotate_array,
+                                         remove_antennas, grid):
+    """The reference's own matrix (tests/test_cpu_simulate.py:199-271): unit hex-7 and 10 m 3x3
+    square lattices, optionally with antennas removed, rotated by 90 degrees, sheared; all
+    (i, j >= i) baselines incl. autos; type 1 against forced type 3 with the reference's
+    tolerances (atol 1e-5 fp64 at eps 1e-10, 1e-4 fp32 at eps 6e-8), plus the oracle for fp64."""
+    rng = np.random.default_rng(42)
+    ants = _ref_hex_grid() if grid == "hex" else _ref_square_grid()
+    if remove_antennas:
+        ants = {k: ants[k] for k in ants if rng.uniform(0, 1) > 0.25}
+        ants = {ki: ants[k] for ki, k in enumerate(ants)}
+    if rotate_array:
+        rot = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+        ants = {a: rot @ ants[a] for a in ants}
+    if shear_array:
+        shear = np.array([[1, 0.5, 0], [0, 1, 0], [0, 0, 1.0]])
+        ants = {a: shear @ ants[a] for a in ants}
+    baselines = [(i, j) for i in ants for j in ants if j >= i]
+    base = dict(synth.make_config("C1", nsrc=40, nfreq=3, ntimes=2))
+    for k in ("ants", "baselines", "force_use_type3", "eps", "precision", "polarized"):
+        base.pop(k)
+    kw = dict(base, ants=ants, baselines=baselines, polarized=polarized, precision=precision,
+              eps=1e-10 if precision == 2 else 6e-8)
+    t1 = fftvis_amd.simulate_vis(force_use_type3=False, **kw)
+    t3 = fftvis_amd.simulate_vis(force_use_type3=True, **kw)
+    atol = 1e-5 if precision == 2 else 1e-4
+    scale = np.abs(t3).max()
+    np.testing.assert_allclose(t1, t3, atol=atol * max(scale, 1.0))
+    if precision == 2:
+        exp = oracle_simulate(dict(kw, force_use_type3=False))
+        assert rel_l2(t1, exp) < 1e-8 and rel_l2(t3, exp) < 1e-8
+
+
 def test_sim_c3_geometry_subset_and_paths(gpu):
     """configs[2] geometry (HERA-350, 61 075 baselines, polarized table beam, 8192^2-class grid)
     with a reduced catalog and 2 channels x 1 time: a random subset of baselines against the
