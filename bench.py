@@ -235,6 +235,19 @@ def main():
         spread_bytes = st["source_visits"] * 2 * R8 + (st["sources_above_horizon"] / max(ntimes * a.steps, 1)) \
             * d * R8 * launches + st["spread_cells"] * 2 * R8
         spread_s = tm["spread"] * 1e-3
+        spread_kernel = "k_spread2d"
+        if a.path == "type1":
+            # lattice path: every (source, channel) pair is an entry with its own origin and 2 w
+            # weights; timed in the extra step (event records around the launch), not in the
+            # timed region
+            spread_kernel = "k_t1_spread"
+            tpol = 4 if pol else 1
+            entries = st_all["source_visits"] / tpol
+            spread_bytes = st_all["source_visits"] * 2 * R8 + entries * (8 + 2 * st_all["w"] * R8) \
+                + st_all["spread_cells"] * 2 * R8
+            launches = max(st_all["spread_launches"], 1.0)
+            spread_s = tm_all["spread"] * 1e-3
+            tm = dict(tm, spread=tm_all["spread"])
         ach = spread_bytes / spread_s / 1e9 if spread_s > 0 else 0.0
         # HBM traffic of the spread kernel from the committed PMC run (rocprofv3 counters cannot be
         # read from inside this process): only for the workload that run was taken on.
@@ -284,7 +297,7 @@ def main():
                 "finite_output": finite,
             },
             "roofline": {
-                "kernel": "k_spread2d",
+                "kernel": spread_kernel,
                 "bound": "hbm",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
