@@ -122,13 +122,21 @@ def main():
 
     os.environ["FFTVIS_HIP_LANES"] = str(a.lanes)
     _lib.require_gpu()
+    # rehearsal switches (a one-GPU box cannot host two RCCL ranks): FFTVIS_BENCH_BACKEND=gloo
+    # with FFTVIS_BENCH_SHARE_GPU=1 runs the N > 1 code path with every rank on device 0
+    backend = os.environ.get("FFTVIS_BENCH_BACKEND", "nccl")
+    if os.environ.get("FFTVIS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     cfg = synth.make_config(a.workload, nsrc=a.nsrc, nfreq=a.nfreq, ntimes=a.ntimes)
     if a.eps is None:
@@ -154,8 +162,14 @@ def main():
         eq = torch.empty((3, nsrc), dtype=rdt, device=dev)
         flux = torch.empty((nsrc, nfreq), dtype=rdt, device=dev)
     if dist is not None:
-        dist.broadcast(eq, 0)
-        dist.broadcast(flux, 0)
+        if backend == "nccl":
+            dist.broadcast(eq, 0)
+            dist.broadcast(flux, 0)
+        else:  # rehearsal: host-side broadcast
+            for tns in (eq, flux):
+                hcopy = tns.cpu()
+                dist.broadcast(hcopy, 0)
+                tns.copy_(hcopy)
     torch.cuda.synchronize()
 
     # ---- this rank's block of the observation: ntimes integrations after rank * span ----------
@@ -211,7 +225,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
