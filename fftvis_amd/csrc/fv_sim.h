@@ -356,7 +356,16 @@ struct T1Args {
     int n2, nb1, w, nfg, f_first;
     int64_t cap;       // stride of xyz
     int64_t ecap;      // entry capacity
+    int rec;           // bytes per entry record (multiple of 64)
 };
+// Entry record (rec bytes, 64-B aligned): {int i0x, i0y, ent, 0} then T wx[w], wy[w], zero padding.
+// One record per (source, frequency[, periodic image]) in bin order: the scatter writes whole
+// 64-B sectors (the earlier split arrays -- 72-B weight rows at arbitrary offsets -- cost 4x their
+// size in WRITE_SIZE) and the spread stages a chunk of entries from one contiguous run.
+constexpr int T1_HDR = 16;
+inline int t1_record_bytes(int w, size_t real_bytes) {
+    return (int)((T1_HDR + 2 * (size_t)w * real_bytes + 63) / 64 * 64);
+}
 
 // Footprint origin (and first kernel argument) of compacted source p at frequency f.
 template <typename T>
@@ -378,8 +387,7 @@ template <typename T, bool COUNT>
 __global__ void k_t1_bin(T1Args a, const int *__restrict__ Mp, const T *__restrict__ xyz,
                          const double *__restrict__ freqs, int *__restrict__ counts,
                          const int *__restrict__ bin_start, int *__restrict__ cursor,
-                         int *__restrict__ i0s, T *__restrict__ kw, int *__restrict__ ent, T beta,
-                         T c4, int *__restrict__ overflow) {
+                         unsigned char *__restrict__ recs, T beta, T c4, int *__restrict__ overflow) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)*Mp * a.nfg) return;
     const int64_t p = idx / a.nfg;
@@ -402,27 +410,26 @@ __global__ void k_t1_bin(T1Args a, const int *__restrict__ Mp, const T *__restri
                     atomicAdd(overflow, 1);
                     continue;
                 }
-                i0s[pos] = jx;
-                i0s[a.ecap + pos] = jy;
-                ent[pos] = (int)idx;  // p * nfg + f
-                T *rx = kw + pos * a.w, *ry = kw + (a.ecap + pos) * a.w;
-                for (int k = 0; k < a.w; ++k) {
-                    rx[k] = es_eval<T>((T)(fx + k), beta, c4);
-                    ry[k] = es_eval<T>((T)(fy + k), beta, c4);
-                }
+                unsigned char *rec = recs + pos * a.rec;
+                *reinterpret_cast<int4 *>(rec) = make_int4(jx, jy, (int)idx, 0);  // ent = p * nfg + f
+                T *wr = reinterpret_cast<T *>(rec + T1_HDR);
+                const int nreal = (a.rec - T1_HDR) / (int)sizeof(T);
+                for (int k = 0; k < a.w; ++k) wr[k] = es_eval<T>((T)(fx + k), beta, c4);
+                for (int k = 0; k < a.w; ++k) wr[a.w + k] = es_eval<T>((T)(fy + k), beta, c4);
+                for (int k = 2 * a.w; k < nreal; ++k) wr[k] = T(0);  // whole sectors, no partial writes
             }
         }
 }
 
 template <typename T>
 __global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent,
-                               const int *__restrict__ ent, const int *__restrict__ src_idx,
+                               const unsigned char *__restrict__ recs, int rec, const int *__restrict__ src_idx,
                                const T *__restrict__ az, const T *__restrict__ za,
                                const void *__restrict__ flux, const double *__restrict__ freqs,
                                cplx<T> *__restrict__ cs) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= *nent) return;
-    const int id = ent[e];
+    const int id = reinterpret_cast<const int *>(recs + e * rec)[2];
     const int tp = a.polarized ? 4 : 1;
     strength_eval<T>(a, id / a.nfg, a.f_first + id % a.nfg, cplx<double>{1.0, 0.0}, src_idx, az, za,
                      flux, freqs, cs + e * tp);
@@ -432,8 +439,8 @@ __global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent,
 // Same LDS staging of source chunks as k_spread2d.
 template <typename T, int TP>
 __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
-    T1Args a, const int *__restrict__ i0s, const T *__restrict__ kw,
-    const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, cplx<T> *__restrict__ grid) {
+    T1Args a, const unsigned char *__restrict__ recs, const int *__restrict__ bin_start,
+    const cplx<T> *__restrict__ cs, cplx<T> *__restrict__ grid) {
     __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TP];
     __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][MAX_W];
     __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
@@ -443,8 +450,6 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
     const int bx = blockIdx.x * 4 + wave, by = blockIdx.y, f = blockIdx.z;
     if (bx >= nbc) return;
     const int cx = (bx << BINLOG) + (lane & 7), cy = (by << BINLOG) + (lane >> 3);
-    const int *i0x = i0s, *i0y = i0s + a.ecap;
-    const T *kwx = kw, *kwy = kw + a.ecap * a.w;
     T ar[TP], ai[TP];
 #pragma unroll
     for (int q = 0; q < TP; ++q) ar[q] = ai[q] = T(0);
@@ -457,14 +462,16 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
         for (int base = s0; base < s1; base += SPREAD_CHUNK) {
             const int n = min(SPREAD_CHUNK, s1 - base);
             for (int e = lane; e < n * TP; e += 64) s_str[wave][e / TP][e % TP] = cs[(int64_t)base * TP + e];
-            for (int e = lane; e < n * w; e += 64) {
-                const int j = e / w, k = e - j * w;
-                s_kw[wave][j][0][k] = kwx[(int64_t)(base + j) * w + k];
-                s_kw[wave][j][1][k] = kwy[(int64_t)(base + j) * w + k];
+            const unsigned char *rb = recs + (int64_t)base * a.rec;
+            for (int e = lane; e < n * 2 * w; e += 64) {
+                const int j = e / (2 * w), k = e - j * 2 * w;
+                const T v = reinterpret_cast<const T *>(rb + (int64_t)j * a.rec + T1_HDR)[k];
+                s_kw[wave][j][k >= w][k >= w ? k - w : k] = v;
             }
             if (lane < n) {
-                s_i0[wave][lane][0] = i0x[base + lane];
-                s_i0[wave][lane][1] = i0y[base + lane];
+                const int2 o = *reinterpret_cast<const int2 *>(rb + (int64_t)lane * a.rec);
+                s_i0[wave][lane][0] = o.x;
+                s_i0[wave][lane][1] = o.y;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -627,7 +634,7 @@ class Sim : public SimBase {
     bool type1 = false;
     int t1_nmodes = 0;
     DevBuf d_blint;  // (2, nbls) int
-    DevBuf t1_meta, t1_binstart, t1_i0s, t1_kw, t1_ent, t1_cs, t1_dec;
+    DevBuf t1_meta, t1_binstart, t1_rec, t1_cs, t1_dec;
     std::unique_ptr<Nufft3<T>> t1fft;
     DevBuf d_coefs, d_ant1, d_ant2;
 
@@ -973,9 +980,8 @@ class Sim : public SimBase {
         const int nbins = nfb * nb1 * nb1;
         t1_meta.reserve(sizeof(int) * (2 * (size_t)(nbins + 1) + 2));
         t1_binstart.reserve(sizeof(int) * (nbins + 1));
-        t1_i0s.reserve(sizeof(int) * 2 * ecap);
-        t1_kw.reserve(sizeof(T) * 2 * ecap * ker.w);
-        t1_ent.reserve(sizeof(int) * ecap);
+        const int rec = t1_record_bytes(ker.w, sizeof(T));
+        t1_rec.reserve((size_t)rec * ecap);
         t1_cs.reserve(sizeof(cplx<T>) * ecap * tpol);
 
         for (int ti = t0; ti < t1; ++ti) {
@@ -995,6 +1001,7 @@ class Sim : public SimBase {
                 a.f_first = fa;
                 a.cap = cap;
                 a.ecap = ecap;
+                a.rec = rec;
                 const int nbn = nfg * nb1 * nb1;
                 int *counts_p = t1_meta.as<int>(), *cursor_p = counts_p + (nbins + 1),
                     *ovf_p = cursor_p + (nbins + 1);
@@ -1003,12 +1010,11 @@ class Sim : public SimBase {
                 const dim3 gb((unsigned)cdiv(cap * nfg, 256));
                 hipLaunchKernelGGL((k_t1_bin<T, true>), gb, dim3(256), 0, stream, a, Mp, d_xyz.as<T>(),
                                    d_freqs.as<double>(), counts_p, (const int *)nullptr, cursor_p,
-                                   (int *)nullptr, (T *)nullptr, (int *)nullptr, (T)ker.beta, (T)ker.c, ovf_p);
+                                   (unsigned char *)nullptr, (T)ker.beta, (T)ker.c, ovf_p);
                 t1fft->exclusive_scan(counts_p, t1_binstart.as<int>(), nbn);
                 hipLaunchKernelGGL((k_t1_bin<T, false>), gb, dim3(256), 0, stream, a, Mp, d_xyz.as<T>(),
                                    d_freqs.as<double>(), counts_p, (const int *)t1_binstart.as<int>(),
-                                   cursor_p, t1_i0s.as<int>(), t1_kw.as<T>(), t1_ent.as<int>(),
-                                   (T)ker.beta, (T)ker.c, ovf_p);
+                                   cursor_p, t1_rec.as<unsigned char>(), (T)ker.beta, (T)ker.c, ovf_p);
                 ev_end(e1, stream);
                 const int *nent = t1_binstart.as<int>() + nbn;
                 for (const Pair &pr : pairs) {
@@ -1026,7 +1032,8 @@ class Sim : public SimBase {
                     sa.bi = desc(pr.bi);
                     sa.bj = desc(pr.bj);
                     hipLaunchKernelGGL(k_t1_strengths<T>, dim3(cdiv(ecap, 256)), dim3(256), 0, stream,
-                                       sa, nent, (const int *)t1_ent.as<int>(), d_srcidx.as<int>(),
+                                       sa, nent, (const unsigned char *)t1_rec.as<unsigned char>(), rec,
+                                       d_srcidx.as<int>(),
                                        d_az.as<T>(), d_za.as<T>(), d_flux.p, d_freqs.as<double>(),
                                        t1_cs.as<cplx<T>>());
                     ev_end(e2, stream);
@@ -1036,12 +1043,12 @@ class Sim : public SimBase {
                     const dim3 gs((unsigned)cdiv(g.n2 >> BINLOG, 4), (unsigned)(g.n2 >> BINLOG), (unsigned)nfg);
                     if (polarized)
                         hipLaunchKernelGGL((k_t1_spread<T, 4>), gs, dim3(SPREAD_THREADS), 0, stream, a,
-                                           (const int *)t1_i0s.as<int>(), (const T *)t1_kw.as<T>(),
+                                           (const unsigned char *)t1_rec.as<unsigned char>(),
                                            (const int *)t1_binstart.as<int>(),
                                            (const cplx<T> *)t1_cs.as<cplx<T>>(), A);
                     else
                         hipLaunchKernelGGL((k_t1_spread<T, 1>), gs, dim3(SPREAD_THREADS), 0, stream, a,
-                                           (const int *)t1_i0s.as<int>(), (const T *)t1_kw.as<T>(),
+                                           (const unsigned char *)t1_rec.as<unsigned char>(),
                                            (const int *)t1_binstart.as<int>(),
                                            (const cplx<T> *)t1_cs.as<cplx<T>>(), A);
                     ev_end(e3, stream);
