@@ -46,10 +46,13 @@ def parse():
     p.add_argument("--path", default="type3", choices=["type3", "type1"],
                    help="type3 = the benchmarked NUFFT path (BASELINE.json); type1 = the lattice path "
                         "the reference takes by default on these arrays (reported for comparison)")
-    p.add_argument("--lanes", type=int, default=1, choices=[1, 2],
-                   help="time steps in flight on separate streams.  The engine's own default is 2 for "
-                        "small grids (+10 %% on C2); the bench pins 1 so that the per-kernel durations "
-                        "behind `roofline` are not inflated by a second lane sharing the GPU")
+    p.add_argument("--lanes", type=int, default=None, choices=[1, 2],
+                   help="FFTVIS_HIP_LANES (default: the engine's own choice -- 2 pipelined lanes for small "
+                        "grids: the per-time preparation of the next step runs on a low-priority stream "
+                        "beside the current step, all big kernels stay on one stream, so the per-kernel "
+                        "durations behind `roofline` are uncontended)")
+    p.add_argument("--pipe", type=int, default=None, choices=[0, 1],
+                   help="FFTVIS_HIP_PIPE=0: two lanes run freely on two streams (kernel durations inflate)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     return p.parse_args()
@@ -120,7 +123,10 @@ def main():
     from fftvis_amd.core.coords import SiderealRotation, eq_unit_vectors
     from fftvis_amd.gpu.gpu_simulate import SimHandle, prepare_array
 
-    os.environ["FFTVIS_HIP_LANES"] = str(a.lanes)
+    if a.lanes is not None:
+        os.environ["FFTVIS_HIP_LANES"] = str(a.lanes)
+    if a.pipe is not None:
+        os.environ["FFTVIS_HIP_PIPE"] = str(a.pipe)
     _lib.require_gpu()
     # rehearsal switches (a one-GPU box cannot host two RCCL ranks): FFTVIS_BENCH_BACKEND=gloo
     # with FFTVIS_BENCH_SHARE_GPU=1 runs the N > 1 code path with every rank on device 0
@@ -243,12 +249,13 @@ def main():
     if rank == 0:
         # ---- roofline of the spread kernel (the kernel BASELINE.json's metric names) ----------
         launches = max(st["spread_launches"], 1.0)
+        timed = max(tm.get("spread_launches_timed", 0.0), 1.0)  # level 1 times the launches of every 4th time step
         R8 = RB
         d = 2 if coplanar else 3
         # algorithmic bytes:  M (d R + T 2R)  +  T G1 2R   summed over launches
         spread_bytes = st["source_visits"] * 2 * R8 + (st["sources_above_horizon"] / max(ntimes * a.steps, 1)) \
             * d * R8 * launches + st["spread_cells"] * 2 * R8
-        spread_s = tm["spread"] * 1e-3
+        spread_s = tm["spread"] * 1e-3 * launches / timed  # all launches, from the sampled average
         spread_kernel = "k_spread2d"
         if a.path == "type1":
             # lattice path: every (source, channel) pair is an entry with its own origin and 2 w
@@ -262,6 +269,7 @@ def main():
             launches = max(st_all["spread_launches"], 1.0)
             spread_s = tm_all["spread"] * 1e-3
             tm = dict(tm, spread=tm_all["spread"])
+            timed = launches
         ach = spread_bytes / spread_s / 1e9 if spread_s > 0 else 0.0
         # HBM traffic of the spread kernel from the committed PMC run (rocprofv3 counters cannot be
         # read from inside this process): only for the workload that run was taken on.
@@ -277,7 +285,7 @@ def main():
         fft_bytes = st_all["fft_cells"] * 2 * R8
         kern = {
             "note": "per-family times from one extra step with event records around every launch",
-            "spread_ms_per_launch": (tm["spread"] / launches) if a.path == "type3" else tm_all["spread"] / l2,
+            "spread_ms_per_launch": (tm["spread"] / timed) if a.path == "type3" else tm_all["spread"] / l2,
             "fft_ms_per_launch": tm_all["fft"] / l2,
             "interp_ms_per_launch": tm_all["interp"] / l2,
             "strengths_ms_per_launch": tm_all["strengths"] / l2,
@@ -307,7 +315,8 @@ def main():
                             f"{('%d basis beams (eigenbeam path), polarized' % len(blist)) if 'beam_coefs' in cfg else 'polarized table beam' if pol else 'unpolarized Airy beam'}, "
                             f"{a.path} NUFFT eps={a.eps:g} upsampfac={a.upsample:g}",
                 "slices_per_step": nfreq * ntimes,
-                "lanes": a.lanes,
+                "lanes": a.lanes if a.lanes is not None else "engine default (2 pipelined lanes for small grids)",
+                "pipe": a.pipe if a.pipe is not None else 1,
                 "finite_output": finite,
             },
             "roofline": {
@@ -320,7 +329,8 @@ def main():
                 "traffic": traffic,
                 "traffic_source": "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)" if traffic else None,
                 "algorithmic_bytes_per_launch": spread_bytes / launches,
-                "avg_launch_ms": tm["spread"] / launches,
+                "avg_launch_ms": tm["spread"] / timed,
+                "launches_timed": timed,
             },
             # the pruned row FFT is the largest share of the step; same accounting: algorithmic
             # bytes of its passes over its summed pass durations (HIP events)
@@ -331,7 +341,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": kern["fft_GBps"] / HBM_PEAK_GBS,
-                "share_of_step": tm_all["fft"] / max(sum(tm_all.values()), 1e-12),
+                "share_of_step": tm_all["fft"] / max(sum(tm_all[k] for k in ("spread", "fft", "interp", "strengths", "prep")), 1e-12),
             },
             "kernels": kern,
         }

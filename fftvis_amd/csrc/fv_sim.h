@@ -644,12 +644,15 @@ class Sim : public SimBase {
         hipStream_t stream = nullptr;
         bool own_stream = false;
         hipEvent_t done = nullptr;
+        hipEvent_t prep_done = nullptr, heavy_done = nullptr;  // pipelined mode (see run())
+        bool heavy_pending = false;
         std::unique_ptr<Nufft3<T>> nufft;
         DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scan_tot, d_scan_off;
         int binned_ti = -1;
         int64_t binned_serial = -1;
     };
     Lane lanes[2];
+    hipStream_t prep_stream = nullptr;  // low priority: per-time preparation of the next step
     hipEvent_t ev_start = nullptr;
     DevBuf d_out, d_mhist;
     std::vector<std::pair<int, double>> mhist_log;  // (time index, transforms spread) per processed time
@@ -664,6 +667,11 @@ class Sim : public SimBase {
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
     double tm[TM_COUNT] = {0};
+    // level 1 attaches events to the spread launches of every TIMING_STRIDE-th time step only (all
+    // frequency groups of that step, so the sample is representative): even dispatch-attached
+    // events leave ~5-8 us of idle queue on either side of a launch
+    static constexpr int TIMING_STRIDE = 4;
+    double spread_timed = 0;
 
     int dim() const { return coplanar ? 2 : 3; }
 
@@ -709,11 +717,18 @@ class Sim : public SimBase {
         : device(device_), eps(eps_), sigma(sigma_), polarized(polarized_ != 0),
           tpol(polarized_ ? 4 : 1) {
         FV_HIP(hipSetDevice(device));
-        FV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        int prio_least = 0, prio_greatest = 0;
+        FV_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        FV_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_greatest));
         lanes[0].stream = stream;
         FV_HIP(hipStreamCreateWithFlags(&lanes[1].stream, hipStreamNonBlocking));
         lanes[1].own_stream = true;
+        FV_HIP(hipStreamCreateWithPriority(&prep_stream, hipStreamNonBlocking, prio_least));
         FV_HIP(hipEventCreateWithFlags(&lanes[1].done, hipEventDisableTiming));
+        for (Lane &L : lanes) {
+            FV_HIP(hipEventCreateWithFlags(&L.prep_done, hipEventDisableTiming));
+            FV_HIP(hipEventCreateWithFlags(&L.heavy_done, hipEventDisableTiming));
+        }
         FV_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         for (int i = 0; i < 9; ++i) rplane.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
     }
@@ -722,8 +737,11 @@ class Sim : public SimBase {
         for (Lane &L : lanes) {
             L.nufft.reset();
             if (L.done) (void)hipEventDestroy(L.done);
+            if (L.prep_done) (void)hipEventDestroy(L.prep_done);
+            if (L.heavy_done) (void)hipEventDestroy(L.heavy_done);
             if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);
         }
+        if (prep_stream) (void)hipStreamDestroy(prep_stream);
         if (ev_start) (void)hipEventDestroy(ev_start);
         for (auto &e : ev_pool) {
             (void)hipEventDestroy(e.a);
@@ -898,8 +916,8 @@ class Sim : public SimBase {
 
     // rotate -> horizon cut -> az/za -> 2 pi R topo for time ti; returns the device address of the
     // live above-horizon count (it never visits the host inside the loop).
-    const int *horizon_step(Lane &L, int ti, int64_t cap, int nblk) {
-        hipStream_t stream = L.stream;
+    const int *horizon_step(Lane &L, int ti, int64_t cap, int nblk, hipStream_t on = nullptr) {
+        hipStream_t stream = on ? on : L.stream;
         DevBuf &d_blockcnt = L.d_blockcnt, &d_blockoff = L.d_blockoff, &d_scan_tot = L.d_scan_tot,
                &d_scan_off = L.d_scan_off, &d_xyz = L.d_xyz, &d_az = L.d_az, &d_za = L.d_za,
                &d_srcidx = L.d_srcidx;
@@ -1195,8 +1213,16 @@ class Sim : public SimBase {
         int nlanes = el ? std::atoi(el)
                         : (cells_top * sizeof(cplx<T>) * max_ntrans <= 1.5 * 1024 * 1024 * 1024 ? 2 : 1);
         nlanes = std::max(1, std::min(2, std::min(nlanes, nt)));
+        // Two lanes, pipelined (default): every big kernel runs on the main (high-priority) stream,
+        // one time step after the other, so kernel durations stay uncontended; the dozen tiny
+        // latency-bound preparation kernels of step t+1 (rotation, horizon cut, bin sort, weight
+        // tables) run on a low-priority stream beside step t's big kernels and fill their ramps
+        // and tails.  FFTVIS_HIP_PIPE=0: the two lanes run freely on two streams instead.
+        const char *ep = std::getenv("FFTVIS_HIP_PIPE");
+        const bool pipe = nlanes > 1 && !(ep && std::atoi(ep) == 0);
         for (int li = 0; li < nlanes; ++li) {
             Lane &L = lanes[li];
+            L.heavy_pending = false;
             if (!L.nufft || L.nufft->dim != D) L.nufft.reset(new Nufft3<T>(D, eps, sigma, L.stream));
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
             L.d_az.reserve(sizeof(T) * cap);
@@ -1206,7 +1232,7 @@ class Sim : public SimBase {
             L.d_blockoff.reserve(sizeof(int) * (nblk + 1));
             L.binned_ti = -1;
         }
-        if (nlanes > 1) {  // lane 1 starts after the output memset queued on the main stream
+        if (nlanes > 1 && !pipe) {  // lane 1 starts after the output memset queued on the main stream
             FV_HIP(hipEventRecord(ev_start, stream));
             FV_HIP(hipStreamWaitEvent(lanes[1].stream, ev_start, 0));
         }
@@ -1214,13 +1240,35 @@ class Sim : public SimBase {
         for (int ti = t0; ti < t1; ++ti) {
             if (nsrc == 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
             Lane &L = lanes[(ti - t0) % nlanes];
-            hipStream_t ls = L.stream;
+            const hipStream_t ls = pipe ? stream : L.stream;        // big kernels
+            const hipStream_t ps = pipe ? prep_stream : L.stream;   // per-time preparation
             Nufft3<T> *nufft = L.nufft.get();
             // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
-            size_t e0 = ev_begin(TM_PREP, ls);
-            const int *Mp = horizon_step(L, ti, cap, nblk);
+            if (pipe && L.heavy_pending) FV_HIP(hipStreamWaitEvent(ps, L.heavy_done, 0));  // lane scratch is free
+            nufft->stream = ps;
+            size_t e0 = ev_begin(TM_PREP, ps);
+            const int *Mp = horizon_step(L, ti, cap, nblk, ps);
             const int64_t M = cap;  // capacity: array stride and launch bound
-            ev_end(e0, ls);
+            if (pipe) {  // the first (group, pair)'s bin sort belongs to the preparation as well
+                for (const Pair &pr : pairs) {
+                    if (pr.n == 0 || groups.empty()) continue;
+                    double smax0 = 0;
+                    for (int f = groups[0].first; f < groups[0].second; ++f)
+                        smax0 = std::max(smax0, std::fabs(freqs[f]));
+                    nufft->set_geometry(xc, X, pr.btc, pr.B, smax0);
+                    nufft->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
+                                       D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mp);
+                    L.binned_ti = ti;
+                    L.binned_serial = nufft->geom_serial;
+                    break;
+                }
+            }
+            ev_end(e0, ps);
+            if (pipe) {
+                FV_HIP(hipEventRecord(L.prep_done, ps));
+                FV_HIP(hipStreamWaitEvent(ls, L.prep_done, 0));
+            }
+            nufft->stream = ls;
             size_t hist_slot = mhist_log.size();
             mhist_log.push_back({ti, 0.0});
 
@@ -1268,9 +1316,10 @@ class Sim : public SimBase {
                                        nufft->i0s.template as<int>(), nufft->fs.template as<T>(), cs);
                     ev_end(e2, ls);
                     // ---- NUFFT ----------------------------------------------------------
-                    if (timing_level >= 1) {
+                    if (timing_level >= 2 || (timing_level == 1 && (ti - t0) % TIMING_STRIDE == 0)) {
                         const size_t e3 = ev_slot(TM_SPREAD);
                         nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b);
+                        spread_timed += 1;
                     } else {
                         nufft->spread(ntrans);
                     }
@@ -1299,8 +1348,12 @@ class Sim : public SimBase {
                     st[9] = nufft->ker.w;
                 }
             }
+            if (pipe) {
+                FV_HIP(hipEventRecord(L.heavy_done, ls));
+                L.heavy_pending = true;
+            }
         }
-        if (nlanes > 1) {  // join: everything queued on the main stream afterwards sees both lanes
+        if (nlanes > 1 && !pipe) {  // join: everything queued on the main stream afterwards sees both lanes
             FV_HIP(hipEventRecord(lanes[1].done, lanes[1].stream));
             FV_HIP(hipStreamWaitEvent(stream, lanes[1].done, 0));
         }
@@ -1348,12 +1401,14 @@ class Sim : public SimBase {
     void reset_stats() override {
         for (double &x : st) x = 0;
         for (double &x : tm) x = 0;
+        spread_timed = 0;
         mhist_log.clear();
         ev_used = 0;
     }
     void enable_timing(int level) override { timing_level = level; }
     void timing(double *ms, int n) override {
         for (int i = 0; i < n && i < TM_COUNT; ++i) ms[i] = tm[i];
+        if (n > TM_COUNT) ms[TM_COUNT] = spread_timed;
     }
 };
 

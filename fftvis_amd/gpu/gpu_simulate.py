@@ -153,9 +153,9 @@ class SimHandle:
         _lib.check(self._L.fv_sim_enable_timing(self._h, int(on)))
 
     def timing(self):
-        v = np.zeros(5)
-        _lib.check(self._L.fv_sim_timing(self._h, _lib.ptr(v), 5))
-        return dict(zip(["spread", "fft", "interp", "strengths", "prep"], v))
+        v = np.zeros(6)
+        _lib.check(self._L.fv_sim_timing(self._h, _lib.ptr(v), 6))
+        return dict(zip(["spread", "fft", "interp", "strengths", "prep", "spread_launches_timed"], v))
 
 
 def prepare_array(ants: dict, baselines, flat_array_tol: float, real_dtype):
