@@ -54,7 +54,21 @@ struct DimGeom {
     int na = 8;              // n1 rounded up to whole 8-cell bins: extent of buffer A
     int n2 = 64, P = 1, Q = 64, logQ = 6;  // FFT length n2 = P * Q
     int no = 2;              // transform outputs kept (centred on mode 0)
+    // Outputs are stored residue-major: output index idx = l + no/2 sits at
+    // (idx mod P) * cnt + idx / P of a row of nos = P * cnt slots.  A residue job of the pruned FFT
+    // (l = P k' + p) then writes one contiguous run instead of every P-th 16-B element -- the
+    // interleaved stores of separate workgroups cost 2.6x the algorithmic write traffic at P = 2.
+    // Every consumer (next pass, transpose, gather, mode pick) addresses columns through out_pos().
+    // The last dimension (contiguous for the gather, whose lanes read w consecutive outputs) keeps
+    // the natural order: rm = false.
+    bool rm = true;
+    int sP() const { return rm ? P : 1; }
+    int cnt() const { return (no + sP() - 1) / sP(); }
+    int nos() const { return cnt() * sP(); }
 };
+__host__ __device__ inline int out_pos(int idx, int P, int cnt) {
+    return P == 1 ? idx : (idx % P) * cnt + idx / P;
+}
 
 struct Geom {
     int dim = 2;
@@ -606,6 +620,8 @@ struct RowDifArgs {
     int n_in, n_out, n2, P, Q, logQ, tpr, rpw;
     int npass, radix_log[4];
     int lds_row, colmode;
+    int cnt;  // outputs per residue: row position of l is ((l + n_out/2) mod P) cnt + (l + n_out/2) / P;
+              // 0 = natural order (position l + n_out/2)
     int64_t nrows, rpp, rpp_valid, in_plane, in_row, in_elem, out_pitch;  // rows k >= rpp_valid of a plane are padding
 };
 
@@ -686,11 +702,14 @@ __global__ __launch_bounds__(512, 4) void k_rowfft_dif(const cplx<T> *__restrict
     int si = (int)((-(int64_t)hshift * a.P * a.tpr) % n2);
     if (si < 0) si += n2;
     const cplx<T> step = tw[si];
-    cplx<T> *rout = out + ((row / a.rpp) * a.rpp_valid + row % a.rpp) * a.out_pitch + half_n;
+    // residue-major storage: l = P kq + p sits at ((p + half_n) mod P) cnt + (p + half_n) / P + kq
+    cplx<T> *rout = out + ((row / a.rpp) * a.rpp_valid + row % a.rpp) * a.out_pitch;
+    rout += a.cnt ? ((p + half_n) % a.P) * a.cnt + (p + half_n) / a.P : p + half_n;
+    const int ostep = a.cnt ? 1 : a.P;  // position of l = P kq + p: base + kq (residue-major) or + P kq
     // k' = (l - p) / P advances by tpr per step: no division inside the loop
     int kq = (lfirst - p) / a.P;
     for (int l = lfirst; l < a.n_out - half_n; l += a.P * a.tpr, kq += a.tpr) {
-        rout[l] = cmul(rb[fft_pidx(fft_digit_pos(kq & (Q - 1), a))], t);
+        rout[kq * ostep] = cmul(rb[fft_pidx(fft_digit_pos(kq & (Q - 1), a))], t);
         t = cmul(t, step);
     }
 }
@@ -910,7 +929,11 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     int si = (int)((-(int64_t)hshift * a.P * (Q / R3)) % n2);
     if (si < 0) si += n2;
     const cplx<T> step = tw[si];
-    cplx<T> *rout = out + (rplane * a.rpp_valid + rk) * a.out_pitch + half_n;
+    // residue-major storage: l = P ks + p sits at ((p + half_n) mod P) cnt + (p + half_n) / P + ks
+    // (natural order when cnt == 0: position l + half_n = base + P ks)
+    cplx<T> *rout = out + (rplane * a.rpp_valid + rk) * a.out_pitch;
+    rout += a.cnt ? ((p + half_n) % a.P) * a.cnt + (p + half_n) / a.P : p + half_n;
+    const int ostep = a.cnt ? 1 : a.P;
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
         const int v = u + i * TPR;
@@ -921,8 +944,9 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
 #pragma unroll
         for (int k = 0; k < R3; ++k) {
             const int kk = v + k * (Q / R3);
-            const int l = a.P * (kk < Q / 2 ? kk : kk - Q) + p;
-            if (l >= -half_n && l < a.n_out - half_n) rout[l] = cmul(vc[i][bitrev_small(k, L3)], t);
+            const int ks = kk < Q / 2 ? kk : kk - Q;
+            const int l = a.P * ks + p;
+            if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = cmul(vc[i][bitrev_small(k, L3)], t);
             if (k + 1 < R3) t = cmul(t, step);
         }
     }
@@ -953,6 +977,7 @@ __global__ void k_transpose(const cplx<T> *__restrict__ in, cplx<T> *__restrict_
 struct InterpArgs {
     int w, tpol, nfg;             // tpol transforms per frequency group, nfg groups
     int n2[3], no[3];
+    int P[3], cnt[3];             // residue-major column storage (DimGeom::out_pos), row length P cnt
     double h[3];                  // theta = h * s'
     double btc[3], xc[3];
     int64_t out_fg_stride;        // output element strides
@@ -1029,10 +1054,10 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
         pr = pr * cs;
     }
 
-    const int64_t row_sz = a.no[0];
-    const int64_t slab_sz = row_sz * a.no[1];
-    const int64_t plane_sz = DIM == 3 ? slab_sz * a.no[2] : slab_sz;
-    const int gcol = min(j0[0] + g, a.no[0] - 1);
+    const int64_t row_sz = (int64_t)a.P[0] * a.cnt[0];
+    const int64_t slab_sz = row_sz * a.P[1] * a.cnt[1];
+    const int64_t plane_sz = DIM == 3 ? slab_sz * a.P[2] * a.cnt[2] : slab_sz;
+    const int gcol = out_pos(min(j0[0] + g, a.no[0] - 1), a.P[0], a.cnt[0]);
     const int nouter = DIM == 3 ? w : 1;
     for (int r = 0; r < a.tpol; ++r) {
         const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * plane_sz + gcol;
@@ -1042,13 +1067,13 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
             const cplx<T> *slab = plane;
             if (DIM == 3) {
                 k2 = __shfl(kv[DIM - 1], lane_base + ro, 64);
-                slab += (int64_t)(j0[DIM - 1] + ro) * slab_sz;
+                slab += (int64_t)out_pos(j0[DIM - 1] + ro, a.P[DIM - 1], a.cnt[DIM - 1]) * slab_sz;
             }
             T tr = T(0), ti = T(0);
 #pragma unroll
             for (int rr = 0; rr < MAX_W; ++rr) {
                 if (rr < w) {
-                    const cplx<T> v = slab[(int64_t)(j0[1] + rr) * row_sz];
+                    const cplx<T> v = slab[(int64_t)out_pos(j0[1] + rr, a.P[1], a.cnt[1]) * row_sz];
                     tr += v.re * k1[rr];
                     ti += v.im * k1[rr];
                 }
@@ -1188,6 +1213,7 @@ class Nufft3 {
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
             set_dim_geom(geo.d[d], sigma, ker.w, scale_max);
+            geo.d[d].rm = d != dim - 1 && !std::getenv("FFTVIS_HIP_NATURAL_ORDER");
             geo.nbin[d] = geo.d[d].na >> BINLOG;
         for (int d = dim; d < 3; ++d) geo.nbin[d] = 1;
         }
@@ -1287,7 +1313,9 @@ class Nufft3 {
 
     // Use this plan only as a pruned 2-D FFT engine (type-1 path): geometry given directly.
     void set_fft_geometry(const DimGeom &gx, const DimGeom &gy) {
-        const DimGeom g[2] = {gx, gy};
+        DimGeom g[2] = {gx, gy};
+        g[0].rm = true;
+        g[1].rm = false;
         for (int d = 0; d < 2; ++d) {
             const bool same = geo.d[d].n2 == g[d].n2 && tw[d].p;
             geo.d[d] = g[d];
@@ -1406,15 +1434,15 @@ int64_t Nufft3<T>::b_pitch() const {
     const DimGeom &x = geo.d[0], &y = geo.d[1];
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
-    return rpw >= 8 ? (x.no + 7) / 8 * 8 : x.no;
+    return rpw >= 8 ? (x.nos() + 7) / 8 * 8 : x.nos();
 }
 
 template <typename T>
 void Nufft3<T>::buffer_cells(int64_t &c0, int64_t &c1) const {
     const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
-    const int64_t zin = dim > 2 ? z.na : 1, zout = dim > 2 ? z.no : 1;
-    const int64_t A = zin * y.na * x.na, B = zin * y.na * b_pitch(), C = zin * x.no * y.no,
-                  D = zout * x.no * y.no;
+    const int64_t zin = dim > 2 ? z.na : 1, zout = dim > 2 ? z.nos() : 1;
+    const int64_t A = zin * y.na * x.na, B = zin * y.na * b_pitch(), C = zin * x.nos() * y.nos(),
+                  D = zout * x.nos() * y.nos();
     c0 = std::max({A, B, C, D});  // either buffer may end up holding any stage (transpose or not)
     c1 = c0;
 }
@@ -1461,7 +1489,8 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.in_plane = in_plane;
     a.in_row = in_row;
     a.in_elem = in_elem;
-    a.out_pitch = out_pitch ? out_pitch : g.no;
+    a.out_pitch = out_pitch ? out_pitch : g.nos();
+    a.cnt = g.sP() > 1 ? g.cnt() : 0;
     const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
     const dim3 jobs((unsigned)(ngroups8 * 8 * g.P));
     if (rowfft_uses_st(g, a.colmode != 0)) {
@@ -1536,18 +1565,18 @@ void Nufft3<T>::fft(int ntrans) {
         // short columns: the y-pass reads rpw adjacent columns of B at once (64-128 B segments),
         // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
         // plane are skipped as rows
-        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.no);
+        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.nos());
         std::swap(cur, oth);
     } else {
         // long columns: explicit tile transpose B -> Bt [p][no_x][na_y], then contiguous rows
-        dim3 tg((unsigned)cdiv(x.no, 32), (unsigned)cdiv(y.na, 32), (unsigned)np);
-        hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, cur, oth, y.na, x.no);
-        rowfft(oth, cur, y, tw[1].as<cplx<T>>(), np, x.no, (int64_t)x.no * y.na, y.na, 1);
+        dim3 tg((unsigned)cdiv(x.nos(), 32), (unsigned)cdiv(y.na, 32), (unsigned)np);
+        hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, cur, oth, y.na, x.nos());
+        rowfft(oth, cur, y, tw[1].as<cplx<T>>(), np, x.nos(), (int64_t)x.nos() * y.na, y.na, 1);
     }
     if (dim > 2) {
         // z-pass: C [t][na_z][nc] (nc = no_x no_y) -> D [t][nc][no_z]; adjacent (lx, ly) columns
         // are adjacent in memory, so the column-mode load is coalesced whenever rpw >= 4.
-        const int64_t nc = (int64_t)x.no * y.no;
+        const int64_t nc = (int64_t)x.nos() * y.nos();
         rowfft(cur, oth, z, tw[2].as<cplx<T>>(), ntrans, nc, (int64_t)z.na * nc, 1, nc);
         std::swap(cur, oth);
     }
@@ -1577,6 +1606,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.w = ker.w;
     a.tpol = tpol;
     a.nfg = nfg;
+    for (int i = 0; i < 3; ++i) a.P[i] = a.cnt[i] = 1;
     // grid dimensions from fastest to slowest: 2-D (y, x), 3-D (z, y, x)
     const int map2[3] = {1, 0, 0}, map3[3] = {2, 1, 0};
     const int *map = dim == 2 ? map2 : map3;
@@ -1586,6 +1616,8 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
         const DimGeom &g = geo.d[map[i]];
         a.n2[i] = g.n2;
         a.no[i] = g.no;
+        a.P[i] = g.sP();
+        a.cnt[i] = g.cnt();
         a.h[i] = g.h;
         a.btc[i] = g.btc;
         a.xc[i] = g.xc;

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
 // vis[f][pol][k] = X_{f,pol}[bx_k][by_k] / (psi_hat(bx) psi_hat(by)); flipped baselines take the
 // negated mode and are conjugated (cpu_simulate.py:259,298).  X is stored [plane][lx][ly].
 template <typename T>
-__global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int nfg, int tp,
+__global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int P, int cnt, int nfg, int tp,
                           const int *__restrict__ blx, const int *__restrict__ bly, int64_t N,
                           const int *__restrict__ bl_idx, const signed char *__restrict__ flip,
                           const T *__restrict__ dec, cplx<T> *__restrict__ out,
@@ -516,7 +516,8 @@ __global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int nfg, int tp
     const T d = dec[lx] * dec[ly];
     const int64_t pol[4] = {p0, p1, p2, p3};
     for (int r = 0; r < tp; ++r) {
-        cplx<T> v = X[(((int64_t)f * tp + r) * no + lx) * no + ly];
+        // rows (lx) are stored residue-major (DimGeom::out_pos), the contiguous ly in natural order
+        cplx<T> v = X[(((int64_t)f * tp + r) * ((int64_t)P * cnt) + out_pos(lx, P, cnt)) * no + ly];
         v = {v.re * d, fl ? -v.im * d : v.im * d};
         out[(int64_t)f * out_fg_stride + pol[r] + k] = v;
     }
@@ -1080,7 +1081,8 @@ class Sim : public SimBase {
                     size_t e5 = ev_begin(TM_INTERP, stream);
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
                     hipLaunchKernelGGL(k_t1_pick<T>, dim3(cdiv(pr.n * nfg, 256)), dim3(256), 0, stream,
-                                       t1fft->fft_output(), g.no, nfg, tpol, (const int *)d_blint.as<int>(),
+                                       t1fft->fft_output(), g.no, g.P, g.cnt(), nfg, tpol,
+                                       (const int *)d_blint.as<int>(),
                                        (const int *)d_blint.as<int>() + nbls, pr.n,
                                        pr.trivial ? (const int *)nullptr : (const int *)pr.idx->template as<int>(),
                                        pr.trivial ? (const signed char *)nullptr
