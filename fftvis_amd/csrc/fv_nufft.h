@@ -29,6 +29,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <memory>
 
 namespace fv {
 
@@ -1171,10 +1173,18 @@ class Nufft3 {
     // raster order, the heavy rim rows come last and the kernel ends in a long, nearly empty
     // tail (measured: 4.8 resident waves per CU on average); heaviest-first lets the light central
     // blocks fill that tail.  The weight is only a heuristic -- any order is correct.
-    DevBuf order;
+    // One table per (nbx, nby), kept for the life of the plan: frequency groups cycle through a
+    // handful of grid sizes every time step.
+    std::map<std::pair<int, int>, std::unique_ptr<DevBuf>> order_cache;
+    const int *order_ptr = nullptr;
     std::vector<int> order_host;
     void build_block_order() {
         const int nbx = geo.nbin[0], nby = geo.nbin[1], ngx = (int)cdiv(nbx, 4);
+        auto hit = order_cache.find({nbx, nby});
+        if (hit != order_cache.end()) {
+            order_ptr = hit->second->template as<int>();
+            return;
+        }
         std::vector<std::pair<float, int>> wg((size_t)ngx * nby);
         for (int by = 0; by < nby; ++by) {
             const double ry = ((by + 0.5) * (1 << BINLOG) - 0.5 * geo.d[1].na) / (0.5 * geo.d[1].na);
@@ -1196,10 +1206,13 @@ class Nufft3 {
             std::stable_sort(wg.begin(), wg.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
         order_host.resize(wg.size());
         for (size_t i = 0; i < wg.size(); ++i) order_host[i] = wg[i].second;
-        order.reserve(sizeof(int) * order_host.size());
-        FV_HIP(hipMemcpyAsync(order.p, order_host.data(), sizeof(int) * order_host.size(),
+        std::unique_ptr<DevBuf> buf(new DevBuf);
+        buf->reserve(sizeof(int) * order_host.size());
+        FV_HIP(hipMemcpyAsync(buf->p, order_host.data(), sizeof(int) * order_host.size(),
                               hipMemcpyHostToDevice, stream));
-        FV_HIP(hipStreamSynchronize(stream));  // geometry changes are rare; keeps order_host reusable
+        FV_HIP(hipStreamSynchronize(stream));  // once per grid size; keeps order_host reusable
+        order_ptr = buf->template as<int>();
+        order_cache[{nbx, nby}] = std::move(buf);
     }
 
     // Bounds -> grid sizes, deconvolution + twiddle tables.
@@ -1396,7 +1409,7 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
                               (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin,
                               (const T *)dec[0].as<T>(), (const T *)dec[1].as<T>(),
                               buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0], ker.w,
-                              (const int *)order.as<int>(), nchunk);
+                              order_ptr, nchunk);
     } else {
         dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)(z.na * nchunk));
         hipExtLaunchKernelGGL((k_spread3d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
