@@ -30,6 +30,15 @@ class BeamEvaluator(ABC):
         """Beam response at (az, za, freq): (2, 2, nsrc) if polarized else (nsrc,)."""
 
 
+def spline_order(spline_opts) -> int:
+    """Interpolation order asked for by the reference's ``spline_opts``: ``{"order": n}`` for
+    ``az_za_map_coordinates``, ``{"kx": n, "ky": n}`` for ``az_za_simple`` (RectBivariateSpline);
+    linear (1) when absent -- the only values the reference's own tests pass
+    (tests/test_cpu_beams.py:72,82,411,428)."""
+    o = spline_opts or {}
+    return int(max(o.get("order", 1), o.get("kx", 1), o.get("ky", 1)))
+
+
 class AiryBeam:
     """Analytic Airy dish: E-field 2 J1(x)/x, x = pi D nu sin(za)/c, in all four Jones slots;
     the power beam is its square (the pyuvdata ``AiryBeam`` used by the reference's tests,

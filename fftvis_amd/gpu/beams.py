@@ -8,7 +8,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import _lib
-from ..core.beams import BeamEvaluator, describe_beam
+from ..core.beams import BeamEvaluator, describe_beam, spline_order
 from ..core.utils import prepare_beam_evaluation as _prepare_beam_evaluation
 
 
@@ -45,7 +45,7 @@ class GPUBeamEvaluator(BeamEvaluator):
         self.polarized = polarized
         self.freq = freq
         self.spline_opts = spline_opts or {}
-        if self.spline_opts.get("order", 1) != 1:
+        if spline_order(self.spline_opts) != 1:
             raise NotImplementedError("GPU beam interpolation supports spline order 1 only")
         az = np.asarray(az)
         prec = 1 if az.dtype == np.float32 else 2

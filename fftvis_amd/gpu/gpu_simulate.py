@@ -19,7 +19,7 @@ import numpy as np
 from .. import _lib
 from ..core import utils
 from ..core.antenna_gridding import check_antpos_griddability
-from ..core.beams import describe_beam
+from ..core.beams import describe_beam, spline_order
 from ..core.coords import SiderealRotation, eq_unit_vectors, julian_dates
 from ..core.simulate import SimulationEngine, default_accuracy_dict
 
@@ -234,8 +234,7 @@ class GPUSimulationEngine(SimulationEngine):
         * ``time_idx`` / ``freq_idx`` (extra) restrict the run to a block, which is how ranks
           shard a simulation across GPUs.
         """
-        order = (beam_spline_opts or {}).get("order", 1)
-        if order != 1:
+        if spline_order(beam_spline_opts) != 1:
             raise NotImplementedError("GPU beam interpolation supports spline order 1 only")
         freqs = np.asarray(freqs)
         nfreqs, ntimes, nbeam, nant = np.size(freqs), len(julian_dates(times)), len(beam_list), len(ants)
