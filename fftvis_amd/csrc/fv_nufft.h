@@ -34,6 +34,17 @@
 
 namespace fv {
 
+// A/B switches for measurements (read once): FFTVIS_HIP_OLD_FFT routes every row FFT through the
+// LDS-resident kernel, FFTVIS_HIP_NATURAL_ORDER stores all FFT outputs in natural (interleaved) order.
+inline bool debug_switch_old_fft() {
+    static const bool v = std::getenv("FFTVIS_HIP_OLD_FFT") != nullptr;
+    return v;
+}
+inline bool debug_switch_natural_order() {
+    static const bool v = std::getenv("FFTVIS_HIP_NATURAL_ORDER") != nullptr;
+    return v;
+}
+
 constexpr int BINLOG = 3;      // sources are binned by footprint origin in 8x8-cell bins
 constexpr int GROUP = 16;      // lanes cooperating on one source / one target (>= MAX_W)
 constexpr int SPREAD_THREADS = 256;
@@ -1226,7 +1237,7 @@ class Nufft3 {
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
             set_dim_geom(geo.d[d], sigma, ker.w, scale_max);
-            geo.d[d].rm = d != dim - 1 && !std::getenv("FFTVIS_HIP_NATURAL_ORDER");
+            geo.d[d].rm = d != dim - 1 && !debug_switch_natural_order();
             geo.nbin[d] = geo.d[d].na >> BINLOG;
         for (int d = dim; d < 3; ++d) geo.nbin[d] = 1;
         }
@@ -1427,7 +1438,7 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
 // Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision):
 // Q/8 threads per row (16..512), 256..512 threads per workgroup.
 inline bool rowfft_uses_st(const DimGeom &g, bool col) {  // register-resident kernel applies
-    return g.logQ >= 9 && g.logQ <= (col ? 10 : 12) && !std::getenv("FFTVIS_HIP_OLD_FFT");
+    return g.logQ >= 9 && g.logQ <= (col ? 10 : 12) && !debug_switch_old_fft();
 }
 inline void rowfft_shape(const DimGeom &g, bool col, int &tpr, int &rpw) {
     if (rowfft_uses_st(g, col)) {  // Q/16 threads per row (64 for 512); 8 columns / 1-4 rows per workgroup
