@@ -82,7 +82,7 @@ __host__ __device__ inline cplx<T> cscale(cplx<T> a, T s) {
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Smallest even integer >= n whose only prime factors are 2, 3, 5 (rocFFT's fast sizes).
+// Smallest even integer >= n whose only prime factors are 2, 3, 5 (the usual FFT-friendly sizes).
 inline int next235even(int n) {
     if (n <= 2) return 2;
     if (n % 2) ++n;

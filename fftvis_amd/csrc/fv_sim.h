@@ -1,5 +1,5 @@
 // fv_sim.h -- the fused visibility simulator: per time  rotate -> horizon compaction -> az/za;
-// per frequency group  beam x coherency strengths -> type-3 NUFFT (spread, rocFFT, gather).
+// per frequency group  beam x coherency strengths -> type-3 NUFFT (spread, pruned row FFTs, gather).
 //
 // GPU twin of CPUSimulationEngine._evaluate_vis_chunk (src/fftvis/cpu/cpu_simulate.py:856-1071).
 // Loop order follows the reference (time -> frequency -> beam pair); what differs is that a

@@ -5,7 +5,7 @@
 (src/fftvis/cpu/cpu_simulate.py:537-569, 850-854) because that is what ``simulate_vis`` calls
 (src/fftvis/wrapper.py:308-336); the stub's own narrower signature could not accept that call.
 Host work here is one-time setup in numpy; every per-(time, frequency) computation happens in
-libfftvis_hip (HIP kernels + rocFFT) behind the C ABI of include/fftvis_hip.h.  There is no CPU
+libfftvis_hip (hand-written HIP kernels, no library FFT) behind the C ABI of include/fftvis_hip.h.  There is no CPU
 fallback: without the library or a GPU the calls raise.
 """
 

@@ -4,7 +4,7 @@
 
     out[t, k] = sum_j weights[t, j] * exp(+i (u_k x_j + v_k y_j [+ w_k z_j]))
 
-computed on the MI355X by libfftvis_hip (spread -> rocFFT -> gather) to relative accuracy
+computed on the MI355X by libfftvis_hip (spread -> pruned row FFTs -> gather) to relative accuracy
 ``eps``.  Input dtype selects the precision exactly as finufft does (float32 -> complex64).
 """
 

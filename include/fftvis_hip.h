@@ -67,7 +67,7 @@ int fv_apparent_coherency(int device, int precision, int variant, int64_t n, con
 int fv_inplace_rot(int device, int precision, const double *rot, void *b, int64_t n);
 
 /* ---- fused simulator (the hot loop) ---------------------------------------------------------
- * One handle = one GPU context: stream, rocFFT plan cache, device-resident catalog / baselines /
+ * One handle = one GPU context: streams, FFT twiddle / deconvolution tables, device-resident catalog / baselines /
  * beams / scratch.  A handle is not thread-safe; different handles are independent.
  * Replaces: GPUSimulationEngine._evaluate_vis_chunk stub (src/fftvis/gpu/gpu_simulate.py:62-91),
  * i.e. the GPU twin of CPUSimulationEngine._evaluate_vis_chunk
