@@ -380,6 +380,26 @@ def test_sim_c2_size_properties(gpu):
     assert rel_l2(v12, 2.0 * v + 0.5 * v2) < 1e-11
 
 
+def test_sim_c2_full_size(gpu):
+    """BASELINE.json configs[1] at its full size (HERA-37, 666 baselines, 1e4 sources, 64 channels,
+    10 times -- the benchmark workload, two pipelined lanes): every slice of a random subset of
+    baselines against the oracle's exact sums over the full catalog, plus two size-independent
+    properties: conjugate symmetry under baseline reversal with a real power beam, and invariance
+    under a permutation of the catalog."""
+    cfg = synth.make_config("C2")
+    v = fftvis_amd.simulate_vis(**cfg)
+    assert v.shape == (64, 10, 666) and np.isfinite(v).all()
+    rng = np.random.default_rng(7)
+    sub = sorted(rng.choice(666, 12, replace=False))
+    sub_cfg = dict(cfg, baselines=[cfg["baselines"][i] for i in sub])
+    assert rel_l2(v[..., sub], oracle_simulate(sub_cfg)) < TOL
+    rev = dict(cfg, baselines=[(b, a) for (a, b) in cfg["baselines"]])
+    assert rel_l2(fftvis_amd.simulate_vis(**rev), np.conj(v)) < 1e-9
+    perm = rng.permutation(len(cfg["ra"]))
+    shuf = dict(cfg, ra=cfg["ra"][perm], dec=cfg["dec"][perm], fluxes=cfg["fluxes"][perm])
+    assert rel_l2(fftvis_amd.simulate_vis(**shuf), v) < 1e-11
+
+
 def test_sim_precomputed_topo_equals_rotation(gpu):
     """Handing the engine per-time topocentric vectors (the matvis coord_mgr route) gives the
     same answer as the on-device rotation."""
