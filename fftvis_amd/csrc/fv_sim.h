@@ -1123,7 +1123,9 @@ class Sim : public SimBase {
     std::vector<std::pair<int, int>> freq_groups(int f0, int f1, double cells_top) const {
         const char *er = std::getenv("FFTVIS_HIP_GROUP_RATIO");
         const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
-        const double budget = eb ? std::atof(eb) : 8.0 * 1024 * 1024 * 1024;
+        // 4 GiB of grid per launch measured best on C3 (3-4 GiB: 350 ms per two time steps, 8 GiB:
+        // 362, 2 GiB: 364, 1 GiB: 369)
+        const double budget = eb ? std::atof(eb) : 4.0 * 1024 * 1024 * 1024;
         double fmax = 1.0;
         for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
         const double mb = cells_top * sizeof(cplx<T>) / (1024.0 * 1024.0);
