@@ -249,7 +249,7 @@ def main():
     if rank == 0:
         # ---- roofline of the spread kernel (the kernel BASELINE.json's metric names) ----------
         launches = max(st["spread_launches"], 1.0)
-        timed = max(tm.get("spread_launches_timed", 0.0), 1.0)  # level 1 times the launches of every 4th time step
+        timed = max(tm.get("spread_launches_timed", 0.0), 1.0)  # level 1 times the launches of every 16th time step
         R8 = RB
         d = 2 if coplanar else 3
         # algorithmic bytes:  M (d R + T 2R)  +  T G1 2R   summed over launches

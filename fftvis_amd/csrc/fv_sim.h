@@ -668,10 +668,10 @@ class Sim : public SimBase {
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
     double tm[TM_COUNT] = {0};
-    // level 1 attaches events to the spread launches of every TIMING_STRIDE-th time step only (all
+    // level 1 attaches events to the spread launches of every TIMING_STRIDE-th (16th) time step only (all
     // frequency groups of that step, so the sample is representative): even dispatch-attached
     // events leave ~5-8 us of idle queue on either side of a launch
-    static constexpr int TIMING_STRIDE = 4;
+    static constexpr int TIMING_STRIDE = 16;
     double spread_timed = 0;
 
     int dim() const { return coplanar ? 2 : 3; }
