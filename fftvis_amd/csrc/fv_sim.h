@@ -668,7 +668,8 @@ class Sim : public SimBase {
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
     double tm[TM_COUNT] = {0};
-    // level 1 attaches events to the spread launches of every TIMING_STRIDE-th (16th) time step only (all
+    // level 1 attaches events to the spread launches of one time step in TIMING_STRIDE (16; the 9th of
+    // each 16, a steady-state one rather than the first after the run's set-up) only (all
     // frequency groups of that step, so the sample is representative): even dispatch-attached
     // events leave ~5-8 us of idle queue on either side of a launch
     static constexpr int TIMING_STRIDE = 16;
@@ -1320,7 +1321,7 @@ class Sim : public SimBase {
                                        nufft->i0s.template as<int>(), nufft->fs.template as<T>(), cs);
                     ev_end(e2, ls);
                     // ---- NUFFT ----------------------------------------------------------
-                    if (timing_level >= 2 || (timing_level == 1 && (ti - t0) % TIMING_STRIDE == 0)) {
+                    if (timing_level >= 2 || (timing_level == 1 && (ti - t0) % TIMING_STRIDE == std::min(TIMING_STRIDE / 2, nt - 1))) {
                         const size_t e3 = ev_slot(TM_SPREAD);
                         nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b);
                         spread_timed += 1;

@@ -164,7 +164,7 @@ int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,
  * [2] interp, [3] strengths (beam + coherency), [4] rotate/sort, [5] number of spread launches
  * behind [0].  level 0: off; 1: spread only, events attached to the dispatches themselves (no extra
- * queue packets) for the spread launches of every 16th time step of a run -- sampled because even
+ * queue packets) for the spread launches of one time step in 16 of a run (the 9th: steady state) -- sampled because even
  * attached events idle the queue for a few us around a launch; cheap enough for a timed region; 2: every launch of every
  * family, bracketed by event records (adds ~10 us bubbles each). */
 int fv_sim_enable_timing(fv_sim *h, int level);
