@@ -1251,6 +1251,8 @@ class Sim : public SimBase {
             // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
             if (pipe && L.heavy_pending) FV_HIP(hipStreamWaitEvent(ps, L.heavy_done, 0));  // lane scratch is free
             nufft->stream = ps;
+            const Pair *first_pair = nullptr;
+            bool strengths_ahead = false;
             size_t e0 = ev_begin(TM_PREP, ps);
             const int *Mp = horizon_step(L, ti, cap, nblk, ps);
             const int64_t M = cap;  // capacity: array stride and launch bound
@@ -1265,6 +1267,11 @@ class Sim : public SimBase {
                                        D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mp);
                     L.binned_ti = ti;
                     L.binned_serial = nufft->geom_serial;
+                    // ... and so do its strengths (beam x coherency, pre-phase): they depend on this
+                    // step's sources only, not on the previous step's big kernels
+                    launch_strengths(L, pr, groups[0].first, groups[0].second - groups[0].first, M, Mp, ps);
+                    first_pair = &pr;
+                    strengths_ahead = true;
                     break;
                 }
             }
@@ -1294,32 +1301,9 @@ class Sim : public SimBase {
                         L.binned_serial = nufft->geom_serial;
                     }
                     ev_end(e1, ls);
-                    // ---- strengths ------------------------------------------------------
-                    size_t e2 = ev_begin(TM_STRENGTHS, ls);
-                    StrengthArgs sa{};
-                    sa.M = M;
-                    sa.nfg = nfg;
-                    sa.f_first = fa;
-                    sa.nfreq = nfreq_cat;
-                    sa.polarized = polarized;
-                    sa.pol_sky = pol_sky;
-                    sa.same_beam = pr.bi == pr.bj;
-                    sa.dim = D;
-                    sa.w = nufft->ker.w;
-                    for (int d = 0; d < 3; ++d) {
-                        sa.h[d] = nufft->geo.d[d].h;
-                        sa.btc[d] = d < D ? pr.btc[d] : 0.0;
-                        sa.na[d] = d < D ? nufft->geo.d[d].na : 1;
-                    }
-                    sa.bi = desc(pr.bi);
-                    sa.bj = desc(pr.bj);
-                    cplx<T> *cs = nufft->strengths_buffer(ntrans);
-                    hipLaunchKernelGGL(k_strengths<T>, dim3(cdiv((int64_t)M * nfg, 256)), dim3(256),
-                                       0, ls, sa, Mp, nufft->perm.template as<int>(),
-                                       L.d_srcidx.template as<int>(), L.d_az.template as<T>(),
-                                       L.d_za.template as<T>(), d_flux.p, d_freqs.as<double>(),
-                                       nufft->i0s.template as<int>(), nufft->fs.template as<T>(), cs);
-                    ev_end(e2, ls);
+                    // ---- strengths (already queued with the preparation for the first pair) -------
+                    if (!(strengths_ahead && &grp == &groups.front() && &pr == first_pair))
+                        launch_strengths(L, pr, fa, nfg, M, Mp, ls);
                     // ---- NUFFT ----------------------------------------------------------
                     if (timing_level >= 2 || (timing_level == 1 && (ti - t0) % TIMING_STRIDE == std::min(TIMING_STRIDE / 2, nt - 1))) {
                         const size_t e3 = ev_slot(TM_SPREAD);
@@ -1367,6 +1351,36 @@ class Sim : public SimBase {
             FV_HIP(hipStreamSynchronize(stream));
             if (timing_level) ev_collect();
         }
+    }
+
+    // beam x coherency strengths of one (frequency group, beam pair) for the lane's current sources
+    void launch_strengths(Lane &L, const Pair &pr, int fa, int nfg, int64_t M, const int *Mp, hipStream_t on) {
+        Nufft3<T> *nufft = L.nufft.get();
+        const int D = dim();
+        size_t e2 = ev_begin(TM_STRENGTHS, on);
+        StrengthArgs sa{};
+        sa.M = M;
+        sa.nfg = nfg;
+        sa.f_first = fa;
+        sa.nfreq = nfreq_cat;
+        sa.polarized = polarized;
+        sa.pol_sky = pol_sky;
+        sa.same_beam = pr.bi == pr.bj;
+        sa.dim = D;
+        sa.w = nufft->ker.w;
+        for (int d = 0; d < 3; ++d) {
+            sa.h[d] = nufft->geo.d[d].h;
+            sa.btc[d] = d < D ? pr.btc[d] : 0.0;
+            sa.na[d] = d < D ? nufft->geo.d[d].na : 1;
+        }
+        sa.bi = desc(pr.bi);
+        sa.bj = desc(pr.bj);
+        cplx<T> *cs = nufft->strengths_buffer(nfg * tpol);
+        hipLaunchKernelGGL(k_strengths<T>, dim3(cdiv((int64_t)M * nfg, 256)), dim3(256), 0, on, sa, Mp,
+                           nufft->perm.template as<int>(), L.d_srcidx.template as<int>(),
+                           L.d_az.template as<T>(), L.d_za.template as<T>(), d_flux.p, d_freqs.as<double>(),
+                           nufft->i0s.template as<int>(), nufft->fs.template as<T>(), cs);
+        ev_end(e2, on);
     }
 
     BeamDesc desc(int b) const {
