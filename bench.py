@@ -284,7 +284,7 @@ def main():
         l2 = max(st_all["spread_launches"], 1.0)
         fft_bytes = st_all["fft_cells"] * 2 * R8
         kern = {
-            "note": "per-family times from one extra step with event records around every launch",
+            "note": "per-family times from one extra single-stream step with event records around every launch",
             "spread_ms_per_launch": (tm["spread"] / timed) if a.path == "type3" else tm_all["spread"] / l2,
             "fft_ms_per_launch": tm_all["fft"] / l2,
             "interp_ms_per_launch": tm_all["interp"] / l2,

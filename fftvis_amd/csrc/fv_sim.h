@@ -1218,6 +1218,7 @@ class Sim : public SimBase {
         int nlanes = el ? std::atoi(el)
                         : (cells_top * sizeof(cplx<T>) * max_ntrans <= 1.5 * 1024 * 1024 * 1024 ? 2 : 1);
         nlanes = std::max(1, std::min(2, std::min(nlanes, nt)));
+        if (timing_level >= 2) nlanes = 1;  // per-family event brackets only make sense on one stream
         // Two lanes, pipelined (default): every big kernel runs on the main (high-priority) stream,
         // one time step after the other, so kernel durations stay uncontended; the dozen tiny
         // latency-bound preparation kernels of step t+1 (rotation, horizon cut, bin sort, weight

@@ -166,7 +166,7 @@ int fv_sim_reset_stats(fv_sim *h);
  * behind [0].  level 0: off; 1: spread only, events attached to the dispatches themselves (no extra
  * queue packets) for the spread launches of one time step in 16 of a run (the 9th: steady state) -- sampled because even
  * attached events idle the queue for a few us around a launch; cheap enough for a timed region; 2: every launch of every
- * family, bracketed by event records (adds ~10 us bubbles each). */
+ * family, bracketed by event records (adds ~10 us bubbles each; runs on a single stream). */
 int fv_sim_enable_timing(fv_sim *h, int level);
 int fv_sim_timing(fv_sim *h, double *ms, int n);
 
