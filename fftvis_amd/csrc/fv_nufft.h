@@ -792,13 +792,102 @@ __device__ inline void st_twiddle(cplx<T> *v, cplx<T> w) {
     }
 }
 
+// --- fused gather (small 2-D problems) ---------------------------------------------------------
+// When the last FFT pass runs in column mode (8 adjacent lx per workgroup, all ly of one transform)
+// and both dimensions are stored in natural order (P = 1), the workgroup can serve the targets
+// directly from its LDS tile instead of writing C to memory for a separate gather kernel: every
+// (target, frequency) item whose w footprint columns touch the workgroup's 8 columns receives that
+// partial sum through two fp64 atomic adds (2-3 workgroups per item).  Everything that depends on
+// (target, frequency) only -- footprint origin, the 2 w kernel weights, 1 / (psi_hat_x psi_hat_y),
+// post-phase, flip -- is tabulated once per geometry (FgHdr records + per-(frequency, column group)
+// item lists) and reused by every time step.
+struct FgHdr {           // 48 bytes, followed by T kx[w], ky[w]
+    int j0x, j0y;        // footprint origin (output indices)
+    int64_t out_off;     // fg * out_fg_stride + k * out_k_stride
+    double pr, pi;       // exp(i s . x_c) / (psi_hat_x psi_hat_y)
+    double sgn;          // -1: conjugate (flipped baseline)
+    double pad;
+};
+struct FusedArgs {
+    const int *lstart;            // [nfg * ngx + 1] list offsets per (frequency, column group)
+    const int *list;              // item ids
+    const unsigned char *recs;    // records, rec bytes each
+    int rec, ngx, tpol, w;
+    void *out;                    // cplx<T> *, base of this (time, frequency-group) block
+    int64_t pol_off[4];
+};
+struct FgGeom {
+    int w, nox, noy, n2x, n2y;
+    double hx, hy, btcx, btcy, xcx, xcy;
+    int64_t out_fg_stride, out_k_stride;
+    int rec, ngx;
+};
+
+// One thread per (target, frequency): record (BUILD) and the count / fill of the column-group lists.
+template <typename T, int MODE>  // 0: records + counts, 1: fill lists
+__global__ void k_fg_build(int64_t N, int nfg, const T *__restrict__ btx, const T *__restrict__ bty,
+                           const int *__restrict__ bl_idx, const signed char *__restrict__ flip,
+                           const double *__restrict__ scale, FgGeom gm, KerParams ker,
+                           unsigned char *__restrict__ recs, int *__restrict__ counts,
+                           const int *__restrict__ lstart, int *__restrict__ cursor, int *__restrict__ list) {
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= N * nfg) return;
+    const int fg = (int)(item / N);
+    FgHdr *h = reinterpret_cast<FgHdr *>(recs + item * gm.rec);
+    if (MODE == 0) {
+        const int64_t kl = item % N;
+        const int64_t k = bl_idx ? bl_idx[kl] : kl;
+        const double sg = (flip && flip[kl]) ? -1.0 : 1.0;
+        const double sc = scale[fg];
+        const T beta = (T)ker.beta, c4 = (T)ker.c;
+        // same arithmetic as k_interp's preamble
+        const double svx = sc * sg * (double)btx[k], svy = sc * sg * (double)bty[k];
+        const double thx = gm.hx * (svx - sc * gm.btcx), thy = gm.hy * (svy - sc * gm.btcy);
+        const double ex = thx * gm.n2x * (0.5 / M_PI) + 0.5 * gm.nox;
+        const double ey = thy * gm.n2y * (0.5 / M_PI) + 0.5 * gm.noy;
+        const int jx = max(0, min(gm.nox - gm.w, (int)ceil(ex - 0.5 * gm.w)));
+        const int jy = max(0, min(gm.noy - gm.w, (int)ceil(ey - 0.5 * gm.w)));
+        T *kx = reinterpret_cast<T *>(recs + item * gm.rec + sizeof(FgHdr));
+        T *ky = kx + gm.w;
+        for (int d = 0; d < gm.w; ++d) {
+            kx[d] = es_eval<T>((T)((double)(jx + d) - ex), beta, c4);
+            ky[d] = es_eval<T>((T)((double)(jy + d) - ey), beta, c4);
+        }
+        const double den = es_hat(ker, thx) * es_hat(ker, thy);
+        const double ph = svx * gm.xcx + svy * gm.xcy;  // post-phase exp(i s . x_c)
+        double pr = 1.0 / den, pi_ = 0.0;
+        if (ph != 0.0) {
+            double sn, cs;
+            sincos(ph, &sn, &cs);
+            pi_ = pr * sn;
+            pr = pr * cs;
+        }
+        h->j0x = jx;
+        h->j0y = jy;
+        h->out_off = (int64_t)fg * gm.out_fg_stride + k * gm.out_k_stride;
+        h->pr = pr;
+        h->pi = pi_;
+        h->sgn = sg;
+        h->pad = 0.0;
+        for (int g = jx >> 3; g <= (jx + gm.w - 1) >> 3; ++g) atomicAdd(&counts[fg * gm.ngx + g], 1);
+    } else {
+        const int jx = h->j0x;
+        for (int g = jx >> 3; g <= (jx + gm.w - 1) >> 3; ++g) {
+            const int b = fg * gm.ngx + g;
+            list[lstart[b] + atomicAdd(&cursor[b], 1)] = (int)item;
+        }
+    }
+}
+
 // NLD = number of leading pass-1 operands that can be non-zero (n_in <= NLD Q/R1): the rest are
 // compile-time zeros, which prunes the first butterfly stages.
 // (Running the P residue jobs of a row group as one lock-stepped workgroup, with or without
 // staging the merged row in LDS, was measured slower than separate workgroups on Q = 4096, P = 2.)
-template <typename T, int LOGQ, bool COL, int NLD>
+template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false>
 __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_ST_MINW12 : 4) void k_rowfft_st(
-    const cplx<T> *__restrict__ in, cplx<T> *__restrict__ out, const cplx<T> *__restrict__ tw, RowDifArgs a) {
+    const cplx<T> *__restrict__ in, cplx<T> *__restrict__ out, const cplx<T> *__restrict__ tw, RowDifArgs a,
+    FusedArgs fz) {
+    static_assert(!FUSED || COL, "the fused gather rides on the column-mode last pass");
     using PL = StPlan<LOGQ, COL>;
     constexpr int R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, TPR = PL::TPR, A = PL::A, B = PL::B;
     constexpr int THREADS = COL ? ST_THREADS_COL : ST_THREADS;
@@ -808,7 +897,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     constexpr int L1 = ilog2_c(R1), L2 = ilog2_c(R2), L3 = ilog2_c(R3);
     constexpr bool WAVE = TPR == 64 && !COL;
     static_assert(S1 == TPR, "one pass-1 item per thread");
-    __shared__ T smem[RPW * ROW];
+    __shared__ __attribute__((aligned(16))) T smem[RPW * ROW];
 
     const int tid = threadIdx.x;
     const int vb = blockIdx.x;
@@ -824,6 +913,25 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     const bool ok = row < a.nrows && rk < a.rpp_valid;
     const int n2 = a.n2;
     T *rb = smem + r * ROW;
+
+    // fused gather: this 8-lane slot's first item (id, header, x weight) is requested now, so that
+    // two of the three dependent round trips of the gather are long over when the tile is ready
+    int fz_s1 = 0, fz_e = 0, fz_item = 0, fz_dx = -1;
+    FgHdr fz_h{};
+    T fz_wx = T(0);
+    if constexpr (FUSED) {
+        const int tr = (int)(row0 / a.rpp);
+        const int b = (tr / fz.tpol) * fz.ngx + (int)((row0 % a.rpp) >> 3);
+        fz_e = fz.lstart[b] + (tid >> 3);
+        fz_s1 = fz.lstart[b + 1];
+        if (fz_e < fz_s1) {
+            fz_item = fz.list[fz_e];
+            const unsigned char *rp = fz.recs + (int64_t)fz_item * fz.rec;
+            fz_h = *reinterpret_cast<const FgHdr *>(rp);
+            fz_dx = (int)(row0 % a.rpp) + (tid & 7) - fz_h.j0x;
+            if ((unsigned)fz_dx < (unsigned)fz.w) fz_wx = reinterpret_cast<const T *>(rp + sizeof(FgHdr))[fz_dx];
+        }
+    }
 
     // ---- pass 1: load (+ twiddle / fold for the residue), radix R1, twiddle ---------------------
     cplx<T> va[R1];
@@ -936,7 +1044,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         for (int n = 0; n < R3; ++n) vc[i][n].im = rb[base3[i] + n];
 
     // ---- pass 3 and this residue's outputs: k' = v + k3 Q/R3, l = P k' + p (mod n2, signed) ------
-    if (!ok) return;
+    if (!FUSED && !ok) return;
     const int half_n = a.n_out / 2;
     const int hshift = a.n_in / 2;
     int si = (int)((-(int64_t)hshift * a.P * (Q / R3)) % n2);
@@ -946,7 +1054,12 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     // (natural order when cnt == 0: position l + half_n = base + P ks)
     cplx<T> *rout = out + (rplane * a.rpp_valid + rk) * a.out_pitch;
     rout += a.cnt ? ((p + half_n) % a.P) * a.cnt + (p + half_n) / a.P : p + half_n;
-    const int ostep = a.cnt ? 1 : a.P;
+    int ostep = a.cnt ? 1 : a.P;
+    if constexpr (FUSED) {  // P = 1, natural order: the column's outputs go to the LDS tile [RPW][n_out]
+        __syncthreads();    // every pass-3 operand has left the exchange buffers
+        rout = reinterpret_cast<cplx<T> *>(smem) + (int64_t)r * a.n_out + half_n;
+        ostep = 1;
+    }
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
         const int v = u + i * TPR;
@@ -961,6 +1074,48 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
             const int l = a.P * ks + p;
             if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = cmul(vc[i][bitrev_small(k, L3)], t);
             if (k + 1 < R3) t = cmul(t, step);
+        }
+    }
+    if constexpr (FUSED) {
+        // ---- gather from the tile: 8 lanes (one per column) per item, 64 items in flight -----------
+        __syncthreads();
+        const cplx<T> *tile = reinterpret_cast<const cplx<T> *>(smem);
+        const int64_t rk0 = row0 % a.rpp;                    // first column of the workgroup
+        const int pol = (int)(row0 / a.rpp) % fz.tpol;       // transform = (frequency, polarisation)
+        const int c = tid & 7;
+        cplx<T> *obase = reinterpret_cast<cplx<T> *>(fz.out) + fz.pol_off[pol];
+        for (int e = fz_e; e < fz_s1; e += (COL ? ST_THREADS_COL : ST_THREADS) / 8) {
+            if (e != fz_e) {  // beyond the prefetched first round
+                fz_item = fz.list[e];
+                const unsigned char *rp = fz.recs + (int64_t)fz_item * fz.rec;
+                fz_h = *reinterpret_cast<const FgHdr *>(rp);
+                fz_dx = (int)rk0 + c - fz_h.j0x;
+                fz_wx = (unsigned)fz_dx < (unsigned)fz.w ? reinterpret_cast<const T *>(rp + sizeof(FgHdr))[fz_dx] : T(0);
+            }
+            T sr = T(0), si = T(0);
+            if ((unsigned)fz_dx < (unsigned)fz.w) {
+                const T *ky = reinterpret_cast<const T *>(fz.recs + (int64_t)fz_item * fz.rec + sizeof(FgHdr)) + fz.w;
+                const cplx<T> *col = tile + (int64_t)c * a.n_out + fz_h.j0y;
+                for (int d = 0; d < fz.w; ++d) {
+                    const T wy = ky[d];
+                    sr += col[d].re * wy;
+                    si += col[d].im * wy;
+                }
+                sr *= fz_wx;
+                si *= fz_wx;
+            }
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {
+                sr += __shfl_xor(sr, off, 64);
+                si += __shfl_xor(si, off, 64);
+            }
+            if (c == 0) {
+                const double vr = (double)sr * fz_h.pr - (double)si * fz_h.pi;
+                const double vi = ((double)sr * fz_h.pi + (double)si * fz_h.pr) * fz_h.sgn;
+                cplx<T> *o = obase + fz_h.out_off;
+                atomicAdd(&o->re, (T)vr);
+                atomicAdd(&o->im, (T)vi);
+            }
         }
     }
 }
@@ -1157,6 +1312,29 @@ class Nufft3 {
     KerParams ker;
     Geom geo;
     hipStream_t stream;
+
+    // ---- fused gather plan (see FgHdr): built once per (geometry, target set), reused by every fft()
+    DevBuf fg_recs, fg_meta, fg_start, fg_list;
+    struct FusedKey {
+        int64_t serial = -1, N = 0, ofs = 0, oks = 0;
+        const void *btx = nullptr, *bl_idx = nullptr, *flip = nullptr, *scale = nullptr;
+        int nfg = 0, tpol = 0;
+        double g[10] = {0};  // h, btc, xc, no, n2 of both dimensions
+        bool operator==(const FusedKey &o) const {
+            for (int i = 0; i < 10; ++i)
+                if (g[i] != o.g[i]) return false;
+            return serial == o.serial && N == o.N && ofs == o.ofs && oks == o.oks && btx == o.btx &&
+                   bl_idx == o.bl_idx && flip == o.flip && scale == o.scale && nfg == o.nfg && tpol == o.tpol;
+        }
+    } fused_key;
+    FusedArgs fused_args{};
+    bool fused_active = false;
+    bool fused_possible() const;
+    // Arms the fused gather for the next fft() (which then leaves no grid for interp()); false when the
+    // configuration does not qualify and the caller must use interp().
+    bool prepare_fused_gather(int64_t N, const T *btx, const T *bty, const int *bl_idx, const signed char *flip,
+                              const double *scale_dev, int nfg, int tpol, cplx<T> *out, int64_t out_fg_stride,
+                              int64_t out_k_stride, const int64_t *out_pol_off);
     int64_t M = 0;            // sources currently binned
     int64_t geom_serial = 0;  // bumps whenever the source->cell mapping changes
 
@@ -1397,7 +1575,7 @@ class Nufft3 {
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                 int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row, int64_t in_elem,
-                int64_t out_pitch = 0, int64_t rpp_valid = 0);
+                int64_t out_pitch = 0, int64_t rpp_valid = 0, const FusedArgs *fused = nullptr);
     int64_t b_pitch() const;  // row pitch of the x-pass output
     cplx<T> *grid_out = nullptr;  // where the last fft() left Ct
 };
@@ -1488,7 +1666,7 @@ void Nufft3<T>::spread(int ntrans, hipEvent_t e0, hipEvent_t e1) {
 template <typename T>
 void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                        int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row,
-                       int64_t in_elem, int64_t out_pitch, int64_t rpp_valid) {
+                       int64_t in_elem, int64_t out_pitch, int64_t rpp_valid, const FusedArgs *fused) {
     static const int plans[9][4] = {{4, 0, 0, 0}, {3, 2, 0, 0}, {3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0},
                                     {3, 3, 3, 0}, {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 4 .. 12
     FV_REQUIRE(g.logQ >= 4 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
@@ -1523,8 +1701,12 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;  // possibly non-zero inputs per thread
         const bool col = a.colmode != 0;
 #define FV_ST_GO(LQ, COLM, NLD)                                                                        \
-    hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD>), jobs, dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0,   \
-                       stream, in, out, twd, a)
+    if (COLM && fused)                                                                                 \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, COLM>), jobs,                                \
+                           dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, *fused); \
+    else                                                                                               \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, false>), jobs,                               \
+                           dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, FusedArgs{})
 #define FV_ST_NLD(LQ, COLM)                                                                            \
     if (nld == 4)                                                                                      \
         FV_ST_GO(LQ, COLM, 4);                                                                         \
@@ -1589,7 +1771,8 @@ void Nufft3<T>::fft(int ntrans) {
         // short columns: the y-pass reads rpw adjacent columns of B at once (64-128 B segments),
         // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
         // plane are skipped as rows
-        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.nos());
+        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.nos(),
+               fused_active ? &fused_args : nullptr);
         std::swap(cur, oth);
     } else {
         // long columns: explicit tile transpose B -> Bt [p][no_x][na_y], then contiguous rows
@@ -1605,6 +1788,89 @@ void Nufft3<T>::fft(int ntrans) {
         std::swap(cur, oth);
     }
     grid_out = cur;
+    fused_active = false;
+}
+
+template <typename T>
+bool Nufft3<T>::fused_possible() const {
+    static const bool off = std::getenv("FFTVIS_HIP_NO_FUSED_GATHER") != nullptr;
+    if (off || dim != 2) return false;
+    const DimGeom &x = geo.d[0], &y = geo.d[1];
+    int tpr, rpw;
+    rowfft_shape(y, true, tpr, rpw);
+    if (!rowfft_uses_st(y, true) || rpw != 8) return false;   // column-mode last pass, 8 columns per workgroup
+    if (x.sP() != 1 || y.P != 1) return false;                 // natural order in both dimensions
+    const int row_slots = y.logQ == 9 ? 577 : 1153;            // StPlan<9|10, true>::ROW
+    return 2 * y.no <= row_slots && b_pitch() % 8 == 0;        // the 8 x n_out tile fits the exchange buffers
+}
+
+template <typename T>
+bool Nufft3<T>::prepare_fused_gather(int64_t N, const T *btx, const T *bty, const int *bl_idx,
+                                     const signed char *flip, const double *scale_dev, int nfg, int tpol,
+                                     cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
+                                     const int64_t *out_pol_off) {
+    if (N == 0 || nfg == 0 || tpol > 4 || !fused_possible()) return false;
+    const DimGeom &x = geo.d[0], &y = geo.d[1];
+    FusedKey key;
+    key.serial = geom_serial;
+    key.N = N;
+    key.ofs = out_fg_stride;
+    key.oks = out_k_stride;
+    key.btx = btx;
+    key.bl_idx = bl_idx;
+    key.flip = flip;
+    key.scale = scale_dev;
+    key.nfg = nfg;
+    key.tpol = tpol;
+    const double kg[10] = {x.h, y.h, x.btc, y.btc, x.xc, y.xc, (double)x.no, (double)y.no, (double)x.n2, (double)y.n2};
+    for (int i = 0; i < 10; ++i) key.g[i] = kg[i];
+    FgGeom gm{};
+    gm.w = ker.w;
+    gm.nox = x.no;
+    gm.noy = y.no;
+    gm.n2x = x.n2;
+    gm.n2y = y.n2;
+    gm.hx = x.h;
+    gm.hy = y.h;
+    gm.btcx = x.btc;
+    gm.btcy = y.btc;
+    gm.xcx = x.xc;
+    gm.xcy = y.xc;
+    gm.out_fg_stride = out_fg_stride;
+    gm.out_k_stride = out_k_stride;
+    gm.rec = (int)((sizeof(FgHdr) + 2 * (size_t)ker.w * sizeof(T) + 15) / 16 * 16);
+    gm.ngx = (int)(b_pitch() / 8);
+    const int nb = nfg * gm.ngx;
+    if (!(key == fused_key)) {
+        const int64_t items = N * nfg;
+        fg_recs.reserve((size_t)gm.rec * items);
+        fg_meta.reserve(sizeof(int) * 2 * (size_t)(nb + 1));
+        fg_start.reserve(sizeof(int) * (size_t)(nb + 1));
+        int *counts_p = fg_meta.as<int>(), *cursor_p = counts_p + (nb + 1);
+        FV_HIP(hipMemsetAsync(fg_meta.p, 0, sizeof(int) * 2 * (size_t)(nb + 1), stream));
+        const dim3 gb((unsigned)cdiv(items, 256));
+        hipLaunchKernelGGL((k_fg_build<T, 0>), gb, dim3(256), 0, stream, N, nfg, btx, bty, bl_idx, flip, scale_dev,
+                           gm, ker, fg_recs.as<unsigned char>(), counts_p, (const int *)nullptr, cursor_p,
+                           (int *)nullptr);
+        exclusive_scan(counts_p, fg_start.as<int>(), nb);
+        // every item sits in at most (w + 14) / 8 column groups
+        fg_list.reserve(sizeof(int) * (size_t)items * ((ker.w + 14) / 8));
+        hipLaunchKernelGGL((k_fg_build<T, 1>), gb, dim3(256), 0, stream, N, nfg, btx, bty, bl_idx, flip, scale_dev,
+                           gm, ker, fg_recs.as<unsigned char>(), counts_p, (const int *)fg_start.as<int>(),
+                           cursor_p, fg_list.as<int>());
+        fused_key = key;
+    }
+    fused_args.lstart = fg_start.as<int>();
+    fused_args.list = fg_list.as<int>();
+    fused_args.recs = fg_recs.as<unsigned char>();
+    fused_args.rec = gm.rec;
+    fused_args.ngx = gm.ngx;
+    fused_args.tpol = tpol;
+    fused_args.w = ker.w;
+    fused_args.out = out;
+    for (int r = 0; r < 4; ++r) fused_args.pol_off[r] = out_pol_off ? out_pol_off[r] : 0;
+    fused_active = true;
+    return true;
 }
 
 template <typename T>

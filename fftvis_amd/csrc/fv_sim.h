@@ -1316,15 +1316,25 @@ class Sim : public SimBase {
                     st[0] += 1;
                     st[1] += (double)nufft->geo.cells_a() * ntrans;
                     mhist_log[hist_slot].second += ntrans;
+                    cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
+                    // small 2-D grids: the last FFT pass serves the targets from its LDS tiles (no C
+                    // buffer, no gather kernel); the output block was zeroed at the start of the run
+                    const bool fused =
+                        !nbasis &&
+                        nufft->prepare_fused_gather(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
+                                                    pr.trivial ? nullptr : pr.idx->template as<int>(),
+                                                    pr.trivial ? nullptr : pr.flip->template as<signed char>(),
+                                                    d_freqs.as<double>() + fa, nfg, tpol, obase,
+                                                    (int64_t)nt * per_tf, 1, pol_off);
                     size_t e4 = ev_begin(TM_FFT, ls);
                     nufft->fft(ntrans);
                     ev_end(e4, ls);
                     st[3] += nufft->fft_traffic_cells() * ntrans;
                     size_t e5 = ev_begin(TM_INTERP, ls);
-                    cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
                     BasisTerm bt{d_coefs.p, d_ant1.as<int>(), d_ant2.as<int>(), pr.bi, pr.bj, nbasis,
                                  (int)freqs.size(), fa};
-                    nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
+                    if (!fused)
+                        nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
                                   D > 2 ? d_bls.as<T>() + 2 * nbls : nullptr,
                                   pr.trivial ? nullptr : pr.idx->template as<int>(),
                                   pr.trivial ? nullptr : pr.flip->template as<signed char>(),
