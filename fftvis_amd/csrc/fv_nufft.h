@@ -1328,7 +1328,7 @@ class Nufft3 {
         }
     } fused_key;
     FusedArgs fused_args{};
-    bool fused_active = false;
+    bool fused_active = false, last_fft_fused = false;
     bool fused_possible() const;
     // Arms the fused gather for the next fft() (which then leaves no grid for interp()); false when the
     // configuration does not qualify and the caller must use interp().
@@ -1747,7 +1747,7 @@ double Nufft3<T>::fft_traffic_cells() const {
     rowfft_shape(y, true, tpr, rpw);
     double c = zin * ((double)x.na * y.na + (double)x.no * y.na);        // x-pass
     if (rpw < 4) c += zin * 2.0 * x.no * y.na;                            // transpose
-    c += zin * ((double)x.no * y.na + (double)x.no * y.no);              // y-pass
+    c += zin * ((double)x.no * y.na + (last_fft_fused ? 0.0 : (double)x.no * y.no));  // y-pass (no C when fused)
     if (dim > 2) c += (double)x.no * y.no * (z.na + z.no);               // z-pass
     return c;
 }
@@ -1788,6 +1788,7 @@ void Nufft3<T>::fft(int ntrans) {
         std::swap(cur, oth);
     }
     grid_out = cur;
+    last_fft_fused = fused_active;
     fused_active = false;
 }
 
