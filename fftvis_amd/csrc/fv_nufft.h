@@ -1316,14 +1316,14 @@ class Nufft3 {
     // ---- fused gather plan (see FgHdr): built once per (geometry, target set), reused by every fft()
     DevBuf fg_recs, fg_meta, fg_start, fg_list;
     struct FusedKey {
-        int64_t serial = -1, N = 0, ofs = 0, oks = 0;
+        int64_t serial = -1, N = 0, ofs = 0, oks = 0, targets = 0;  // targets: caller's version of the device arrays' contents
         const void *btx = nullptr, *bl_idx = nullptr, *flip = nullptr, *scale = nullptr;
         int nfg = 0, tpol = 0;
         double g[10] = {0};  // h, btc, xc, no, n2 of both dimensions
         bool operator==(const FusedKey &o) const {
             for (int i = 0; i < 10; ++i)
                 if (g[i] != o.g[i]) return false;
-            return serial == o.serial && N == o.N && ofs == o.ofs && oks == o.oks && btx == o.btx &&
+            return serial == o.serial && targets == o.targets && N == o.N && ofs == o.ofs && oks == o.oks && btx == o.btx &&
                    bl_idx == o.bl_idx && flip == o.flip && scale == o.scale && nfg == o.nfg && tpol == o.tpol;
         }
     } fused_key;
@@ -1334,7 +1334,7 @@ class Nufft3 {
     // configuration does not qualify and the caller must use interp().
     bool prepare_fused_gather(int64_t N, const T *btx, const T *bty, const int *bl_idx, const signed char *flip,
                               const double *scale_dev, int nfg, int tpol, cplx<T> *out, int64_t out_fg_stride,
-                              int64_t out_k_stride, const int64_t *out_pol_off);
+                              int64_t out_k_stride, const int64_t *out_pol_off, int64_t targets_serial = 0);
     int64_t M = 0;            // sources currently binned
     int64_t geom_serial = 0;  // bumps whenever the source->cell mapping changes
 
@@ -1809,11 +1809,12 @@ template <typename T>
 bool Nufft3<T>::prepare_fused_gather(int64_t N, const T *btx, const T *bty, const int *bl_idx,
                                      const signed char *flip, const double *scale_dev, int nfg, int tpol,
                                      cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
-                                     const int64_t *out_pol_off) {
+                                     const int64_t *out_pol_off, int64_t targets_serial) {
     if (N == 0 || nfg == 0 || tpol > 4 || !fused_possible()) return false;
     const DimGeom &x = geo.d[0], &y = geo.d[1];
     FusedKey key;
     key.serial = geom_serial;
+    key.targets = targets_serial;
     key.N = N;
     key.ofs = out_fg_stride;
     key.oks = out_k_stride;

@@ -661,6 +661,7 @@ class Sim : public SimBase {
     // stats / timing
     double st[10] = {0};
     int timing_level = 0;  // 1: spread only (events ride on the dispatches), 2: every kernel family
+    int64_t targets_serial = 1;  // version of the device-side target data (baselines, frequencies, pair lists)
     struct Ev {
         hipEvent_t a, b;
         int kind;
@@ -785,11 +786,13 @@ class Sim : public SimBase {
         upload(d_topo, topo, sizeof(T) * 3 * (size_t)n * ntimes, on_device);
     }
     void set_freqs(int nf, const double *f) override {
+        ++targets_serial;  // tabulated target records (fused gather) are stale now
         FV_HIP(hipSetDevice(device));
         freqs.assign(f, f + nf);
         upload(d_freqs, f, sizeof(double) * nf, 0);
     }
     void set_array(const double *R, int64_t nb, const double *bls, int cop) override {
+        ++targets_serial;  // tabulated target records (fused gather) are stale now
         FV_HIP(hipSetDevice(device));
         std::memcpy(rplane.m, R, 9 * sizeof(double));
         nbls = nb;
@@ -805,6 +808,7 @@ class Sim : public SimBase {
     // Lattice array (cpu_simulate.py:661-681): integer baselines, n_modes = 2 max|bl| + 1 and the
     // basis matrix in seconds; topo is rotated by basis^T instead of the plane rotation (:964-965).
     void set_array_type1(const double *basis, int64_t nb, const int *bls_int, int n_modes) override {
+        ++targets_serial;  // tabulated target records (fused gather) are stale now
         FV_HIP(hipSetDevice(device));
         FV_REQUIRE(n_modes >= 1 && n_modes % 2 == 1, "n_modes must be odd");
         for (int i = 0; i < 3; ++i)
@@ -849,6 +853,7 @@ class Sim : public SimBase {
     }
     void set_beam_pairs(int np, const int *bi, const int *bj, const int64_t *off, const int *idx,
                         const signed char *flipped) override {
+        ++targets_serial;
         FV_HIP(hipSetDevice(device));
         FV_REQUIRE(nbls > 0 || np == 0, "set_array first");
         pairs.clear();
@@ -1325,7 +1330,7 @@ class Sim : public SimBase {
                                                     pr.trivial ? nullptr : pr.idx->template as<int>(),
                                                     pr.trivial ? nullptr : pr.flip->template as<signed char>(),
                                                     d_freqs.as<double>() + fa, nfg, tpol, obase,
-                                                    (int64_t)nt * per_tf, 1, pol_off);
+                                                    (int64_t)nt * per_tf, 1, pol_off, targets_serial);
                     size_t e4 = ev_begin(TM_FFT, ls);
                     nufft->fft(ntrans);
                     ev_end(e4, ls);
