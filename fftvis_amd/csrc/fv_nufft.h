@@ -107,7 +107,10 @@ inline void choose_pq(int nmin, DimGeom &g) {
             pp /= 2;
             ++bb;
         }
-        const double cost = (double)p * q * (1.0 + 0.03 * (pp - 1));
+        // every extra residue re-reads the row (from L2) and re-applies the input twiddles: measured
+        // on C3's mix of grid sizes, 0.15-0.4 per extra residue beats 0.03-0.1 by 4-5 % and >= 0.7
+        static const double pen = std::getenv("FFTVIS_HIP_PQ_PENALTY") ? std::atof(std::getenv("FFTVIS_HIP_PQ_PENALTY")) : 0.25;
+        const double cost = (double)p * q * (1.0 + pen * (pp - 1));
         if (best == 0 || cost < best) {
             best = cost;
             bp = pp;
