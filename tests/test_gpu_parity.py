@@ -400,6 +400,27 @@ def test_sim_c2_full_size(gpu):
     assert rel_l2(fftvis_amd.simulate_vis(**shuf), v) < 1e-11
 
 
+def test_sim_c2_geometry_polarized_pairs_fused_gather(gpu):
+    """HERA-37 geometry (grid 1024 x 512: register-resident row FFT, column-mode last pass, hence
+    the fused gather) with everything the gather has to carry: four polarisation products,
+    a polarized sky, two different beams (three beam pairs, flipped baselines in the mixed pair) and
+    autos -- against the oracle's exact sums."""
+    cfg = synth.make_config("C2", nsrc=1200, nfreq=4, ntimes=2)
+    freqs = cfg["freqs"]
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=91, naz=180), freqs)
+    tab2 = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, diameter=12.0, nza=91, naz=180), freqs)
+    _, _, fl4 = synth.catalog(1200, freqs, 0, polarized_sky=True)
+    nant = len(cfg["ants"])
+    rng = np.random.default_rng(5)
+    bidx = rng.integers(0, 2, nant)
+    bls = [cfg["baselines"][i] for i in sorted(rng.choice(666, 60, replace=False))]
+    bls += [(b, a) for (a, b) in bls[:10]] + [(3, 3), (7, 7)]
+    pol = dict(cfg, polarized=True, beam=[tab, tab2], beam_idx=bidx, fluxes=fl4, baselines=bls, eps=1e-9)
+    got = fftvis_amd.simulate_vis(**pol)
+    assert got.shape == (4, 2, 2, 2, len(bls))
+    assert rel_l2(got, oracle_simulate(pol)) < 1e-8
+
+
 def test_sim_handle_reconfigured_between_runs(gpu):
     """A long-lived engine handle keeps per-geometry tables between runs (bin order, twiddles, the
     fused gather's per-target records): changing the frequencies, then the baselines, on the same
