@@ -419,6 +419,8 @@ def test_sim_c2_geometry_polarized_pairs_fused_gather(gpu):
     got = fftvis_amd.simulate_vis(**pol)
     assert got.shape == (4, 2, 2, 2, len(bls))
     assert rel_l2(got, oracle_simulate(pol)) < 1e-8
+    g32 = fftvis_amd.simulate_vis(**dict(pol, precision=1, eps=1e-4))   # float atomics in the gather
+    assert g32.dtype == np.complex64 and rel_l2(g32, got) < 5e-3
 
 
 def test_sim_handle_reconfigured_between_runs(gpu):
