@@ -635,7 +635,7 @@ class Sim : public SimBase {
     bool type1 = false;
     int t1_nmodes = 0;
     DevBuf d_blint;  // (2, nbls) int
-    DevBuf t1_meta, t1_binstart, t1_rec, t1_cs, t1_dec;
+    DevBuf t1_meta[2], t1_binstart[2], t1_rec[2], t1_cs, t1_dec;  // [2]: pipelined (time, batch) units
     std::unique_ptr<Nufft3<T>> t1fft;
     DevBuf d_coefs, d_ant1, d_ant2;
 
@@ -728,6 +728,7 @@ class Sim : public SimBase {
         lanes[1].own_stream = true;
         FV_HIP(hipStreamCreateWithPriority(&prep_stream, hipStreamNonBlocking, prio_least));
         FV_HIP(hipEventCreateWithFlags(&lanes[1].done, hipEventDisableTiming));
+        FV_HIP(hipEventCreateWithFlags(&lanes[0].done, hipEventDisableTiming));
         for (Lane &L : lanes) {
             FV_HIP(hipEventCreateWithFlags(&L.prep_done, hipEventDisableTiming));
             FV_HIP(hipEventCreateWithFlags(&L.heavy_done, hipEventDisableTiming));
@@ -986,15 +987,15 @@ class Sim : public SimBase {
             for (int r = 0; r < 4; ++r) pol_off[r] = (int64_t)((r % 2) * 2 + r / 2) * nbls;
 
         const int64_t cap = std::max<int64_t>(nsrc, 1);
-        Lane &L = lanes[0];
-        DevBuf &d_xyz = L.d_xyz, &d_az = L.d_az, &d_za = L.d_za, &d_srcidx = L.d_srcidx;
-        d_xyz.reserve(sizeof(T) * 3 * cap);
-        d_az.reserve(sizeof(T) * cap);
-        d_za.reserve(sizeof(T) * cap);
-        d_srcidx.reserve(sizeof(int) * cap);
         const int nblk = (int)cdiv(cap, 256);
-        L.d_blockcnt.reserve(sizeof(int) * (nblk + 1));
-        L.d_blockoff.reserve(sizeof(int) * (nblk + 1));
+        for (Lane &Lr : lanes) {
+            Lr.d_xyz.reserve(sizeof(T) * 3 * cap);
+            Lr.d_az.reserve(sizeof(T) * cap);
+            Lr.d_za.reserve(sizeof(T) * cap);
+            Lr.d_srcidx.reserve(sizeof(int) * cap);
+            Lr.d_blockcnt.reserve(sizeof(int) * (nblk + 1));
+            Lr.d_blockoff.reserve(sizeof(int) * (nblk + 1));
+        }
         d_mhist.reserve(sizeof(int) * rots.size());
         // frequencies per batch: bounded by entries (~1.3 per (source, freq)) and by grid bytes
         const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
@@ -1003,21 +1004,43 @@ class Sim : public SimBase {
         int nfb = (int)std::max(1.0, std::min({(double)nf, budget / plane_bytes, 24.0e6 / (1.3 * cap)}));
         const int64_t ecap = (int64_t)(1.3 * cap * nfb) + 4096;
         const int nbins = nfb * nb1 * nb1;
-        t1_meta.reserve(sizeof(int) * (2 * (size_t)(nbins + 1) + 2));
-        t1_binstart.reserve(sizeof(int) * (nbins + 1));
         const int rec = t1_record_bytes(ker.w, sizeof(T));
-        t1_rec.reserve((size_t)rec * ecap);
+        // Pipelined like the type-3 loop: the entry sort of unit (time, batch) u+1 (three kernels over
+        // every (source, frequency) pair, ~25 % of a step) runs on the low-priority stream beside the
+        // strengths / spread / FFT / pick of unit u; two sets of sort buffers and two sets of
+        // per-time source arrays alternate.
+        const char *ep = std::getenv("FFTVIS_HIP_PIPE");
+        const int nunits = nt * (int)cdiv(nf, nfb);
+        const bool pipe = timing_level < 2 && nunits > 1 && !(ep && std::atoi(ep) == 0);
+        const hipStream_t ps = pipe ? prep_stream : stream;
+        for (int sset = 0; sset < (pipe ? 2 : 1); ++sset) {
+            t1_meta[sset].reserve(sizeof(int) * (2 * (size_t)(nbins + 1) + 2));
+            t1_binstart[sset].reserve(sizeof(int) * (nbins + 1));
+            t1_rec[sset].reserve((size_t)rec * ecap);
+        }
         t1_cs.reserve(sizeof(cplx<T>) * ecap * tpol);
+        bool set_pending[2] = {false, false}, lane_pending[2] = {false, false};
+        if (pipe) {  // the sort may start once the set-up queued on the main stream is done
+            FV_HIP(hipEventRecord(ev_start, stream));
+            FV_HIP(hipStreamWaitEvent(ps, ev_start, 0));
+        }
+        int unit = 0;
 
         for (int ti = t0; ti < t1; ++ti) {
             if (nsrc == 0) continue;
-            size_t e0 = ev_begin(TM_PREP, stream);
-            const int *Mp = horizon_step(L, ti, cap, nblk);
-            ev_end(e0, stream);
+            const int li = pipe ? (ti - t0) % 2 : 0;
+            Lane &L = lanes[li];
+            DevBuf &d_xyz = L.d_xyz, &d_az = L.d_az, &d_za = L.d_za, &d_srcidx = L.d_srcidx;
+            if (pipe && lane_pending[li]) FV_HIP(hipStreamWaitEvent(ps, L.done, 0));  // its strengths are done
+            size_t e0 = ev_begin(TM_PREP, ps);
+            const int *Mp = horizon_step(L, ti, cap, nblk, ps);
+            ev_end(e0, ps);
             mhist_log.push_back({ti, 0.0});
             const size_t hist_slot = mhist_log.size() - 1;
-            for (int fa = f0; fa < f1; fa += nfb) {
+            for (int fa = f0; fa < f1; fa += nfb, ++unit) {
                 const int nfg = std::min(nfb, f1 - fa);
+                const int ss = pipe ? unit % 2 : 0;
+                DevBuf &meta = t1_meta[ss], &binstart = t1_binstart[ss], &recs = t1_rec[ss];
                 T1Args a{};
                 a.n2 = g.n2;
                 a.nb1 = nb1;
@@ -1028,20 +1051,26 @@ class Sim : public SimBase {
                 a.ecap = ecap;
                 a.rec = rec;
                 const int nbn = nfg * nb1 * nb1;
-                int *counts_p = t1_meta.as<int>(), *cursor_p = counts_p + (nbins + 1),
-                    *ovf_p = cursor_p + (nbins + 1);
-                size_t e1 = ev_begin(TM_PREP, stream);
-                FV_HIP(hipMemsetAsync(t1_meta.p, 0, sizeof(int) * (2 * (size_t)(nbins + 1) + 2), stream));
+                int *counts_p = meta.as<int>(), *cursor_p = counts_p + (nbins + 1), *ovf_p = cursor_p + (nbins + 1);
+                if (pipe && set_pending[ss]) FV_HIP(hipStreamWaitEvent(ps, lanes[ss].heavy_done, 0));
+                size_t e1 = ev_begin(TM_PREP, ps);
+                FV_HIP(hipMemsetAsync(meta.p, 0, sizeof(int) * (2 * (size_t)(nbins + 1) + 2), ps));
                 const dim3 gb((unsigned)cdiv(cap * nfg, 256));
-                hipLaunchKernelGGL((k_t1_bin<T, true>), gb, dim3(256), 0, stream, a, Mp, d_xyz.as<T>(),
+                hipLaunchKernelGGL((k_t1_bin<T, true>), gb, dim3(256), 0, ps, a, Mp, d_xyz.as<T>(),
                                    d_freqs.as<double>(), counts_p, (const int *)nullptr, cursor_p,
                                    (unsigned char *)nullptr, (T)ker.beta, (T)ker.c, ovf_p);
-                t1fft->exclusive_scan(counts_p, t1_binstart.as<int>(), nbn);
-                hipLaunchKernelGGL((k_t1_bin<T, false>), gb, dim3(256), 0, stream, a, Mp, d_xyz.as<T>(),
-                                   d_freqs.as<double>(), counts_p, (const int *)t1_binstart.as<int>(),
-                                   cursor_p, t1_rec.as<unsigned char>(), (T)ker.beta, (T)ker.c, ovf_p);
-                ev_end(e1, stream);
-                const int *nent = t1_binstart.as<int>() + nbn;
+                t1fft->stream = ps;
+                t1fft->exclusive_scan(counts_p, binstart.as<int>(), nbn);
+                t1fft->stream = stream;
+                hipLaunchKernelGGL((k_t1_bin<T, false>), gb, dim3(256), 0, ps, a, Mp, d_xyz.as<T>(),
+                                   d_freqs.as<double>(), counts_p, (const int *)binstart.as<int>(),
+                                   cursor_p, recs.as<unsigned char>(), (T)ker.beta, (T)ker.c, ovf_p);
+                ev_end(e1, ps);
+                if (pipe) {
+                    FV_HIP(hipEventRecord(lanes[ss].prep_done, ps));
+                    FV_HIP(hipStreamWaitEvent(stream, lanes[ss].prep_done, 0));
+                }
+                const int *nent = binstart.as<int>() + nbn;
                 for (const Pair &pr : pairs) {
                     if (pr.n == 0) continue;
                     size_t e2 = ev_begin(TM_STRENGTHS, stream);
@@ -1057,7 +1086,7 @@ class Sim : public SimBase {
                     sa.bi = desc(pr.bi);
                     sa.bj = desc(pr.bj);
                     hipLaunchKernelGGL(k_t1_strengths<T>, dim3(cdiv(ecap, 256)), dim3(256), 0, stream,
-                                       sa, nent, (const unsigned char *)t1_rec.as<unsigned char>(), rec,
+                                       sa, nent, (const unsigned char *)recs.as<unsigned char>(), rec,
                                        d_srcidx.as<int>(),
                                        d_az.as<T>(), d_za.as<T>(), d_flux.p, d_freqs.as<double>(),
                                        t1_cs.as<cplx<T>>());
@@ -1068,13 +1097,13 @@ class Sim : public SimBase {
                     const dim3 gs((unsigned)cdiv(g.n2 >> BINLOG, 4), (unsigned)(g.n2 >> BINLOG), (unsigned)nfg);
                     if (polarized)
                         hipLaunchKernelGGL((k_t1_spread<T, 4>), gs, dim3(SPREAD_THREADS), 0, stream, a,
-                                           (const unsigned char *)t1_rec.as<unsigned char>(),
-                                           (const int *)t1_binstart.as<int>(),
+                                           (const unsigned char *)recs.as<unsigned char>(),
+                                           (const int *)binstart.as<int>(),
                                            (const cplx<T> *)t1_cs.as<cplx<T>>(), A);
                     else
                         hipLaunchKernelGGL((k_t1_spread<T, 1>), gs, dim3(SPREAD_THREADS), 0, stream, a,
-                                           (const unsigned char *)t1_rec.as<unsigned char>(),
-                                           (const int *)t1_binstart.as<int>(),
+                                           (const unsigned char *)recs.as<unsigned char>(),
+                                           (const int *)binstart.as<int>(),
                                            (const cplx<T> *)t1_cs.as<cplx<T>>(), A);
                     ev_end(e3, stream);
                     st[0] += 1;
@@ -1102,6 +1131,14 @@ class Sim : public SimBase {
                     st[8] = g.n2 * 65536.0 + g.n2;
                     st[9] = ker.w;
                 }
+                if (pipe) {
+                    FV_HIP(hipEventRecord(lanes[ss].heavy_done, stream));
+                    set_pending[ss] = true;
+                }
+            }
+            if (pipe) {
+                FV_HIP(hipEventRecord(L.done, stream));
+                lane_pending[li] = true;
             }
         }
         if (!out_on_device) {
