@@ -125,7 +125,7 @@ static void beam_eval_host(int device, int polarized, int kind, double diameter,
     FV_HIP(hipSetDevice(device));
     if (n == 0) return;
     StreamGuard sg;
-    DevBuf daz, dza, dout, dtab;
+    DevBuf daz, dza, dout, dtab, dtab_in;
     BeamDesc b{};
     b.kind = kind;
     b.diameter = diameter;
@@ -134,7 +134,15 @@ static void beam_eval_host(int device, int polarized, int kind, double diameter,
         FV_REQUIRE(nft == 1 || (fidx >= 0 && fidx < nft), "freq_index outside the beam table");
         const size_t bytes = (polarized ? 64 : 8) * (size_t)nft * nza * naz;
         dtab.reserve(bytes);
-        FV_HIP(hipMemcpyAsync(dtab.p, table, bytes, hipMemcpyHostToDevice, sg.s));
+        if (!polarized) {
+            FV_HIP(hipMemcpyAsync(dtab.p, table, bytes, hipMemcpyHostToDevice, sg.s));
+        } else {  // Jones tables are read in the interleaved device layout (eval_jones)
+            dtab_in.reserve(bytes);
+            FV_HIP(hipMemcpyAsync(dtab_in.p, table, bytes, hipMemcpyHostToDevice, sg.s));
+            const int64_t nodes = (int64_t)nza * naz;
+            hipLaunchKernelGGL(k_jones_interleave, dim3((unsigned)cdiv(nodes * nft, 256)), dim3(256), 0, sg.s,
+                               dtab_in.as<cplx<double>>(), dtab.as<cplx<double>>(), nodes, (int64_t)nft);
+        }
         b.table = dtab.p;
         b.nfreq_tab = nft;
         b.nza = nza;

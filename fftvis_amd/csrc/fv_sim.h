@@ -124,6 +124,15 @@ __device__ inline Bilin bilin_setup(const BeamDesc &b, double az, double za) {
     return o;
 }
 
+// [freq][4][za][az] (caller's layout) -> [freq][za][az][4] (device layout of Jones tables)
+__global__ void k_jones_interleave(const cplx<double> *__restrict__ in, cplx<double> *__restrict__ out,
+                                   int64_t nodes, int64_t nfreq) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodes * nfreq) return;
+    const int64_t f = i / nodes, nd = i % nodes;
+    for (int j = 0; j < 4; ++j) out[(f * nodes + nd) * 4 + j] = in[(f * 4 + j) * nodes + nd];
+}
+
 // Jones matrix A[ax][feed] (row-major, 4 complex) of one beam at one (source, frequency).
 __device__ inline void eval_jones(const BeamDesc &b, int fidx, double freq, double az, double za,
                                   cplx<double> A[4]) {
@@ -134,13 +143,15 @@ __device__ inline void eval_jones(const BeamDesc &b, int fidx, double freq, doub
     }
     const Bilin w = bilin_setup(b, az, za);
     const int ft = b.nfreq_tab > 1 ? fidx : 0;
+    // device layout [freq][za][az][4 Jones]: the four Jones entries of a node are one 64-B sector (the
+    // caller's [freq][2][2][za][az] planes are interleaved at upload, k_jones_interleave)
     const cplx<double> *tab = (const cplx<double> *)b.table + (int64_t)ft * 4 * b.nza * b.naz;
     const double w00 = (1 - w.wz) * (1 - w.wa), w01 = (1 - w.wz) * w.wa, w10 = w.wz * (1 - w.wa),
                  w11 = w.wz * w.wa;
+    const cplx<double> *n00 = tab + ((int64_t)w.iz0 * b.naz + w.ia0) * 4, *n01 = tab + ((int64_t)w.iz0 * b.naz + w.ia1) * 4,
+                       *n10 = tab + ((int64_t)w.iz1 * b.naz + w.ia0) * 4, *n11 = tab + ((int64_t)w.iz1 * b.naz + w.ia1) * 4;
     for (int i = 0; i < 4; ++i) {
-        const cplx<double> *p = tab + (int64_t)i * b.nza * b.naz;
-        const cplx<double> v00 = p[(int64_t)w.iz0 * b.naz + w.ia0], v01 = p[(int64_t)w.iz0 * b.naz + w.ia1],
-                           v10 = p[(int64_t)w.iz1 * b.naz + w.ia0], v11 = p[(int64_t)w.iz1 * b.naz + w.ia1];
+        const cplx<double> v00 = n00[i], v01 = n01[i], v10 = n10[i], v11 = n11[i];
         A[i] = {v00.re * w00 + v01.re * w01 + v10.re * w10 + v11.re * w11,
                 v00.im * w00 + v01.im * w01 + v10.im * w10 + v11.im * w11};
     }
@@ -850,7 +861,17 @@ class Sim : public SimBase {
         bm.za_max = za_max;
         bm.table.reset(new DevBuf());
         const size_t per = polarized ? 4 * 16 : 8;  // complex128 Jones or float64 power
-        upload(*bm.table, table, per * (size_t)nft * nza * naz, 0);
+        if (!polarized) {
+            upload(*bm.table, table, per * (size_t)nft * nza * naz, 0);
+        } else {  // Jones tables live interleaved on the device (see eval_jones)
+            DevBuf tmp;
+            upload(tmp, table, per * (size_t)nft * nza * naz, 0);
+            bm.table->reserve(per * (size_t)nft * nza * naz);
+            const int64_t nodes = (int64_t)nza * naz;
+            hipLaunchKernelGGL(k_jones_interleave, dim3((unsigned)cdiv(nodes * nft, 256)), dim3(256), 0, stream,
+                               tmp.as<cplx<double>>(), bm.table->template as<cplx<double>>(), nodes, (int64_t)nft);
+            FV_HIP(hipStreamSynchronize(stream));  // tmp goes out of scope
+        }
     }
     void set_beam_pairs(int np, const int *bi, const int *bj, const int64_t *off, const int *idx,
                         const signed char *flipped) override {
