@@ -138,7 +138,11 @@ inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
     n1 += n1 % 2;
     g.n1 = n1;
     g.na = (int)cdiv(n1, 1 << BINLOG) << BINLOG;  // whole source bins
-    choose_pq(std::max(g.na, (int)std::ceil(sigma * n1)), g);
+    // the gather's footprints reach |eta| <= n2 / (2 sigma) + w / 2 and must stay inside the n2 outputs
+    // (no periodic wrap there): n2 (1 - 1 / sigma) >= w + 4.  Only tiny grids at sigma = 1.25 are affected
+    // (they lost up to 250 eps at tight tolerances before).
+    const int nwrap = (int)std::ceil((w + 4) / (1.0 - 1.0 / sigma));
+    choose_pq(std::max({g.na, (int)std::ceil(sigma * n1), nwrap}), g);
     g.h = M_PI / (sigma * Ss);
     // targets sit at |eta| <= n2/(2 sigma) (in transform cells); keep the footprint around them
     g.no = 2 * ((int)std::ceil(0.5 * g.n2 / sigma) + w / 2 + 2);

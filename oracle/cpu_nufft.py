@@ -101,7 +101,8 @@ def _geom(X, S, sigma, w):
         Ss = max(Ss, 1.0 / X)
     n1 = int(np.ceil(2 * sigma * Ss * Xs / np.pi + w + 1))
     n1 += n1 % 2
-    n2 = next235even(int(np.ceil(sigma * n1)))
+    # the gather's footprints (|eta| <= n2 / (2 sigma) + w / 2) must stay inside the n2 outputs
+    n2 = next235even(max(int(np.ceil(sigma * n1)), int(np.ceil((w + 4) / (1.0 - 1.0 / sigma)))))
     h = np.pi / (sigma * Ss)
     return n1, n2, h
 

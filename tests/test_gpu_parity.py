@@ -113,6 +113,37 @@ def test_nufft2d_every_row_fft_length(gpu, Sx, Sy):
     assert f32.dtype == np.complex64 and rel_l2(f32, ex) < 1e-3
 
 
+def test_nufft2d_random_geometries(gpu):
+    """Seeded sweep over target extents (5 .. 1400 per dimension, off-centre boxes), source half-widths,
+    tolerances and both upsampling factors: the relative l2 error stays within a small multiple of eps
+    everywhere -- including tiny grids at upsampfac = 1.25, where the gather's footprints used to fall
+    off the output range (fixed by a minimum n2; 250 eps before).  upsampfac = 1.25 is only asked for
+    eps >= 1e-9: the kernel width is capped at 16 (finufft's limit too)."""
+    rng = np.random.default_rng(11)
+    M, N = 300, 200
+    worst = 0.0
+    for it in range(40):
+        Sx, Sy = np.exp(rng.uniform(np.log(5), np.log(1400), 2))
+        Xh = rng.uniform(0.5, 3.1)
+        x, y = rng.uniform(-Xh, Xh, (2, M))
+        c = rng.normal(size=(2, M)) + 1j * rng.normal(size=(2, M))
+        s = rng.uniform(-Sx, Sx, N) + rng.uniform(-0.3, 0.3) * Sx
+        t = rng.uniform(-Sy, Sy, N) + rng.uniform(-0.3, 0.3) * Sy
+        up = 2.0 if rng.uniform() < 0.7 else 1.25
+        eps = float(10 ** rng.uniform(-12 if up == 2.0 else -9, -3))
+        ex = nudft.nudft_type3([x, y], c, [s, t])
+        err = rel_l2(gpu_nufft2d(x, y, c, s, t, eps, upsample_factor=up), ex)
+        worst = max(worst, err / eps)
+        assert err < 6 * eps + 2e-13, (it, Sx, Sy, Xh, eps, up, err)
+    for (Sx, Sy, Xh) in [(16.75, 5.1, 1.21), (8.0, 8.0, 0.6)]:   # tiny grids, upsampfac 1.25, tight eps
+        x, y = rng.uniform(-Xh, Xh, (2, M))
+        c = rng.normal(size=(2, M)) + 1j * rng.normal(size=(2, M))
+        s, t = rng.uniform(-Sx, Sx, N), rng.uniform(-Sy, Sy, N)
+        ex = nudft.nudft_type3([x, y], c, [s, t])
+        for eps in (1e-7, 7e-9):
+            assert rel_l2(gpu_nufft2d(x, y, c, s, t, eps, upsample_factor=1.25), ex) < 6 * eps
+
+
 @pytest.mark.parametrize("eps", [1e-3, 6e-8, 1e-12])
 def test_nufft3d_meets_eps(gpu, eps):
     """gpu_nufft3d vs the exact sum (reference cpu/nufft.py:62-118 -> finufft.nufft3d3), for a
