@@ -621,6 +621,58 @@ def test_simulate_gridded_type1_vs_type3(gpu, polarized, precision, shear_array,
         assert rel_l2(t1, exp) < 1e-8 and rel_l2(t3, exp) < 1e-8
 
 
+def _random_sim_config(rng, lattice=False):
+    nant = int(rng.integers(3, 12))
+    if lattice:  # random 2-D lattice, random occupied sites
+        b1 = rng.uniform(5, 20) * np.array([1.0, 0.0, 0.0])
+        ang = rng.uniform(0.6, 2.2)
+        b2 = rng.uniform(5, 20) * np.array([np.cos(ang), np.sin(ang), 0.0])
+        sites = set()
+        while len(sites) < nant:
+            sites.add((int(rng.integers(-4, 5)), int(rng.integers(-4, 5))))
+        ants = {i: a * b1 + b * b2 for i, (a, b) in enumerate(sorted(sites))}
+    else:
+        ext = float(np.exp(rng.uniform(np.log(10), np.log(400))))
+        noncop = rng.uniform() < 0.3
+        ants = {i: np.array([rng.uniform(-ext, ext), rng.uniform(-ext, ext), rng.uniform(-3, 3) if noncop else 0.0])
+                for i in range(nant)}
+        if rng.uniform() < 0.3:  # tilted plane
+            tilt = rng.uniform(-0.1, 0.1, 2)
+            ants = {i: np.array([p[0], p[1], p[2] + tilt[0] * p[0] + tilt[1] * p[1]]) for i, p in ants.items()}
+    nsrc, nfreq, ntimes = int(rng.integers(30, 300)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    freqs = np.sort(rng.uniform(50e6, 200e6) * (1 + rng.uniform(0, 0.4, nfreq)))
+    times = np.linspace(2459845.0, 2459845.0 + rng.uniform(0.001, 0.3), ntimes)
+    pol = bool(rng.uniform() < 0.5)
+    ra, dec, flux = synth.catalog(nsrc, freqs, int(rng.integers(1e6)), polarized_sky=pol and rng.uniform() < 0.5)
+    nbeam = int(rng.integers(1, 4))
+    beams = [fftvis_amd.AiryBeam(float(rng.uniform(6, 16))) if rng.uniform() < 0.5 else
+             fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, float(rng.uniform(8, 15)), nza=46, naz=90), freqs)
+             for _ in range(nbeam)]
+    allb = [(i, j) for i in range(nant) for j in range(nant)]
+    sel = rng.choice(len(allb), size=min(len(allb), int(rng.integers(1, 40))), replace=False)
+    return dict(ants=ants, fluxes=flux, ra=ra, dec=dec, freqs=freqs, times=times,
+                beam=beams if nbeam > 1 else beams[0], beam_idx=rng.integers(0, nbeam, nant) if nbeam > 1 else None,
+                telescope_loc=(synth.HERA_LAT, synth.HERA_LON), baselines=[allb[k] for k in sel], polarized=pol,
+                precision=2, eps=float(10 ** rng.uniform(-11, -4)), force_use_type3=not lattice)
+
+
+def test_sim_fuzz_random_configurations(gpu):
+    """Seeded fuzz of the whole engine against the oracle: random arrays (planar, tilted, non-coplanar:
+    2-D and 3-D transforms), catalog sizes, 1-4 channels over a random band, 1-3 times, polarized or
+    not (polarized skies too), 1-3 beams (Airy / tables) with random assignment, random baseline
+    subsets incl. flipped pairs and autos, eps in [1e-11, 1e-4]; then random LATTICE arrays through
+    the type-1 path.  (300 more seeds of the same generator were run clean while writing it.)"""
+    rng = np.random.default_rng(2024)
+    for it in range(32):
+        cfg = _random_sim_config(rng)
+        err = rel_l2(fftvis_amd.simulate_vis(**cfg), oracle_simulate(cfg))
+        assert err < 10 * cfg["eps"] + 1e-12, (it, err, cfg["eps"], cfg["polarized"], len(cfg["ants"]))
+    for it in range(16):
+        cfg = _random_sim_config(rng, lattice=True)
+        err = rel_l2(fftvis_amd.simulate_vis(**cfg), oracle_simulate(cfg))
+        assert err < 10 * cfg["eps"] + 1e-12, ("lattice", it, err, cfg["eps"], cfg["polarized"], len(cfg["ants"]))
+
+
 def test_sim_c3_geometry_subset_and_paths(gpu):
     """configs[2] geometry (HERA-350, 61 075 baselines, polarized table beam, 8192^2-class grid)
     with a reduced catalog and 2 channels x 1 time: a random subset of baselines against the
