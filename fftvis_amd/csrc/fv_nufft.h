@@ -11,16 +11,21 @@
 //    sources touch `na` ~ n2/sigma cells around mode 0 (buffer A, mode m = index - na/2) and the
 //    targets read `no` ~ n2/sigma cells around mode 0 of the transform (mode l = index - no/2).
 //    The uniform step  g_l = sum_m b_m exp(+2 pi i m l / n2)  is therefore a PRUNED FFT: row
-//    kernels read na inputs, run length-Q power-of-two FFTs in LDS (n2 = P*Q, decimation in time
-//    over the P residues) and write no outputs; a tile transpose sits between the x- and y-pass.
-//    HBM traffic ~ 6 na^2 cells per transform instead of the >= 8 n2^2 = 32 na^2 of a full-grid
-//    library FFT (four passes) plus the zero padding the spread would have to write.
-//  * Spread is a GATHER: one thread owns one cell of A for TCH transforms.  Sources are counting-
-//    sorted into 8x8-cell bins of their footprint origin, their 2w kernel weights are evaluated once
-//    per (time, geometry); a cell walks the <= 3x3 bins whose footprints can reach it, multiplies
-//    the two tabulated weights and accumulates strengths in registers, then writes its value once
-//    (zeros included, deconvolution applied), 1 KiB per wave-store.  No atomics (LDS or global), no
-//    memset pass, no LDS; the result is order-deterministic given the bin order.
+//    kernels read na inputs, run length-Q power-of-two FFTs (n2 = P*Q, decimation in frequency
+//    over the P residues: every (row, residue) is an independent job) with the radix passes held
+//    in registers and LDS as the exchange between them (k_rowfft_st; k_rowfft_dif for Q < 512), and
+//    write no outputs; the y-pass reads columns directly when they are short (fusing the
+//    transpose), a tile transpose sits between the passes otherwise.  HBM traffic ~ 4-6 na^2 cells
+//    per transform instead of the >= 8 n2^2 = 32 na^2 of a full-grid library FFT (four passes) plus
+//    the zero padding the spread would have to write.  On small 2-D grids the last pass also
+//    serves the targets from its LDS tiles (fused gather): no output grid at all.
+//  * Spread is a GATHER: one wave owns one 8x8-cell block of A (lane = cell) for TCH transforms.
+//    Sources are counting-sorted into 8x8-cell bins of their footprint origin, their 2w kernel
+//    weights are evaluated once per (time, geometry); the wave walks the <= 3x3 bins whose
+//    footprints can reach its block in chunks of 16 sources staged through registers into its
+//    private LDS slice, multiplies the two tabulated weights and accumulates strengths in
+//    registers, then writes every cell once (zeros included, deconvolution applied).  No atomics,
+//    no memset pass; blocks are processed heaviest-first.
 #pragma once
 
 #include "fv_eskernel.h"
