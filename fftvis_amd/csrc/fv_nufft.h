@@ -768,7 +768,7 @@ struct StPlan<10, COL> {
 };
 template <bool COL>
 struct StPlan<11, COL> {
-    static constexpr int R1 = 16, R2 = 16, R3 = 8, TPR = 128, A = 130, B = 8, ROW = 2080;
+    static constexpr int R1 = 16, R2 = 16, R3 = 8, TPR = 128, A = COL ? 132 : 130, B = 8, ROW = COL ? 2115 : 2080;
 };
 template <bool COL>
 struct StPlan<12, COL> {
@@ -1628,7 +1628,8 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
 // Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision):
 // Q/8 threads per row (16..512), 256..512 threads per workgroup.
 inline bool rowfft_uses_st(const DimGeom &g, bool col) {  // register-resident kernel applies
-    return g.logQ >= 9 && g.logQ <= (col ? 10 : 12) && !debug_switch_old_fft();
+    static const int colmax = std::getenv("FFTVIS_HIP_COL_LOGQ_MAX") ? std::atoi(std::getenv("FFTVIS_HIP_COL_LOGQ_MAX")) : 11;
+    return g.logQ >= 9 && g.logQ <= (col ? colmax : 12) && !debug_switch_old_fft();
 }
 inline void rowfft_shape(const DimGeom &g, bool col, int &tpr, int &rpw) {
     if (rowfft_uses_st(g, col)) {  // Q/16 threads per row (64 for 512); 8 columns / 1-4 rows per workgroup
@@ -1648,7 +1649,7 @@ int64_t Nufft3<T>::b_pitch() const {
     const DimGeom &x = geo.d[0], &y = geo.d[1];
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
-    return rpw >= 8 ? (x.nos() + 7) / 8 * 8 : x.nos();
+    return rpw >= 4 ? (x.nos() + rpw - 1) / rpw * rpw : x.nos();  // whole 64-/128-B segments per workgroup
 }
 
 template <typename T>
@@ -1731,7 +1732,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         } else if (g.logQ == 10) {
             if (col) { FV_ST_NLD(10, true) } else { FV_ST_NLD(10, false) }
         } else if (g.logQ == 11) {
-            FV_ST_NLD(11, false)
+            if (col) { FV_ST_NLD(11, true) } else { FV_ST_NLD(11, false) }
         } else {
             FV_ST_NLD(12, false)
         }
