@@ -88,6 +88,13 @@ def test_nufft2d_shapes_and_edge_cases(gpu):
     xo, yo = x + 11.0, y - 7.0
     so, to = s + 300.0, t - 120.0
     assert rel_l2(gpu_nufft2d(xo, yo, c, so, to, 1e-9), nudft.nudft_type3([xo, yo], c, [so, to])) < 2e-8
+    # tolerance extremes (kernel width 2 and the 16-cell cap), a degenerate dimension, a box of width 1e-6
+    ex = nudft.nudft_type3([x, y], c, [s, t])
+    for eps, lim in ((0.3, 3.0), (1e-14, 2e-12), (3e-15, 2e-12)):
+        assert rel_l2(gpu_nufft2d(x, y, c, s, t, eps), ex) < lim
+    z0, t0 = np.zeros_like(x), np.zeros_like(t)
+    assert rel_l2(gpu_nufft2d(x, z0, c, s, t0, 1e-9), nudft.nudft_type3([x, z0], c, [s, t0])) < 1e-8
+    assert rel_l2(gpu_nufft2d(x * 1e-6, y * 1e-6, c, s, t, 1e-9), nudft.nudft_type3([x * 1e-6, y * 1e-6], c, [s, t])) < 1e-8
 
 
 @pytest.mark.parametrize(
