@@ -15,4 +15,4 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_c2
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c3 -- python3 $R/bench.py --workload C3 --ntimes 1 --nfreq 16 --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_c3.log 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_c3 -- python3 $R/bench.py --workload C3 --ntimes 1 --nfreq 16 --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write_c3.log 2>&1
 echo rc=$?
-cut -c1-400 $O/bench_c2.json; echo; cut -c1-260 $O/bench_c2_lanes2.json; echo; cut -c1-260 $O/bench_c3.json; echo; cut -c1-260 $O/bench_c3_type1.json; echo; cut -c1-300 $O/bench_c5.json
+cut -c1-400 $O/bench_c2.json; echo; cut -c1-260 $O/bench_c2_free.json; echo; cut -c1-260 $O/bench_c3.json; echo; cut -c1-260 $O/bench_c3_type1.json; echo; cut -c1-300 $O/bench_c5.json
