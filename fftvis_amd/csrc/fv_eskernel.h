@@ -70,8 +70,12 @@ inline KerParams make_kernel(double eps, double sigma, int w_override = 0) {
     int w;
     if (sigma == 2.0)
         w = (int)std::ceil(std::log10(10.0 / eps));
-    else
-        w = (int)std::ceil(-std::log(eps) / (M_PI * std::sqrt(1.0 - 1.0 / sigma)));
+    else  // finufft's low-upsampling width + 1: type 3 applies the kernel twice, and seeded engine fuzzing
+        // found 10-16 eps with the bare formula (each extra cell buys a factor ~4).  Capped at 15: the
+        // kernel's transform falls by ~e^{-w/2} per dimension across the band at sigma = 1.25, so a
+        // wider kernel loses more to amplified rounding at band-edge targets than it gains (w = 16
+        // measured 2-3e-8 where w = 15 gives 5-9e-9); ~1e-8 is this sigma's fp64 floor, as in finufft
+        w = std::min(15, (int)std::ceil(-std::log(eps) / (M_PI * std::sqrt(1.0 - 1.0 / sigma))) + 1);
     if (w_override > 0) w = w_override;
     w = std::max(2, std::min(MAX_W, w));
     double bow = 2.30;

@@ -37,8 +37,9 @@ const char *fv_last_error(void);
  * (src/fftvis/cpu/nufft.py:48-59, 105-118; modeord irrelevant for type 3, isign = +1 default).
  * dim = 2: z and u must be NULL.  x,y,z: (M) reals; c: (ntrans, M) complex; s,t,u: (N) reals;
  * out: (ntrans, N) complex, caller-allocated.  upsampfac in {2.0, 1.25}
- * (cpu/nufft.py:19 "upsample_factor"); 1.25 reaches eps ~ 1e-9 at best (kernel width capped at 16,
- * as in finufft).  Host pointers.                                                            */
+ * (cpu/nufft.py:19 "upsample_factor"); 1.25 reaches ~1e-8 at best in fp64 (kernel one cell wider
+ * than finufft's formula, capped at 15: beyond that amplified rounding at band-edge targets
+ * outweighs the truncation gain).  Host pointers.                                            */
 int fv_nufft3(int device, int precision, int dim, int64_t M, const void *x, const void *y,
               const void *z, const void *c, int ntrans, int64_t N, const void *s, const void *t,
               const void *u, double eps, double upsampfac, void *out);

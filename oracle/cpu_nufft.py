@@ -65,7 +65,7 @@ def es_params(eps: float, sigma: float = 2.0):
     if sigma == 2.0:
         w = int(np.ceil(np.log10(10.0 / eps)))
     else:
-        w = int(np.ceil(-np.log(eps) / (np.pi * np.sqrt(1 - 1 / sigma))))
+        w = min(15, int(np.ceil(-np.log(eps) / (np.pi * np.sqrt(1 - 1 / sigma)))) + 1)  # as fv_eskernel.h
     w = max(2, min(16, w))
     bow = {2: 2.20, 3: 2.26, 4: 2.38}.get(w, 2.30)
     if sigma != 2.0:
