@@ -33,7 +33,7 @@ SYMBOLS = {
     "fv_nudft3_direct": (c_int, [c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fv_beam_eval": (c_int, [c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_int, c_double,
-                             c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p]),
+                             c_void_p, c_int, c_int, c_double, c_int64, c_void_p, c_void_p, c_void_p]),
     "fv_apparent_coherency": (c_int, [c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "fv_inplace_rot": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64]),
@@ -47,7 +47,7 @@ SYMBOLS = {
     "fv_sim_set_array_type1": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
     "fv_sim_set_nbeams": (c_int, [c_void_p, c_int]),
     "fv_sim_set_beam_airy": (c_int, [c_void_p, c_int, c_double]),
-    "fv_sim_set_beam_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p]),
+    "fv_sim_set_beam_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int]),
     "fv_sim_set_beam_pairs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "fv_sim_set_basis": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -36,7 +36,18 @@ def spline_order(spline_opts) -> int:
     linear (1) when absent -- the only values the reference's own tests pass
     (tests/test_cpu_beams.py:72,82,411,428)."""
     o = spline_opts or {}
-    return int(max(o.get("order", 1), o.get("kx", 1), o.get("ky", 1)))
+    if "order" in o:
+        return int(o["order"])
+    return int(max(o.get("kx", 1), o.get("ky", 1)))
+
+
+def checked_spline_order(spline_opts) -> int:
+    """The orders the device interpolates: 1 (bilinear) and 3 (cubic B-spline, the reference CLI's
+    default, cli.py:50,146); anything else fails loudly."""
+    order = spline_order(spline_opts)
+    if order not in (1, 3):
+        raise NotImplementedError(f"GPU beam interpolation supports spline orders 1 and 3, not {order}")
+    return order
 
 
 class AiryBeam:
@@ -49,7 +60,7 @@ class AiryBeam:
 
 
 class TabulatedBeam:
-    """Beam sampled on a regular (za, az) grid, interpolated to order 1 on the device.
+    """Beam sampled on a regular (za, az) grid, interpolated on the device (order 1 or 3).
 
     data : (nfreq_tab, 2, 2, nza, naz) complex E-field Jones [vector axis, feed]  -- or --
            (nfreq_tab, nza, naz) real power.  nfreq_tab is 1 (achromatic) or the number of

@@ -118,9 +118,10 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
 
 template <typename T>
 static void beam_eval_host(int device, int polarized, int kind, double diameter, int nft, int nza,
-                           int naz, double za_max, const void *table, int fidx, double freq,
+                           int naz, double za_max, const void *table, int order, int fidx, double freq,
                            int64_t n, const void *az, const void *za, void *out) {
     FV_REQUIRE(kind == 0 || kind == 1, "beam kind must be 0 (Airy) or 1 (table)");
+    FV_REQUIRE(order == 1 || order == 3, "beam interpolation order must be 1 or 3");
     FV_REQUIRE(n >= 0 && (n == 0 || (az && za && out)), "bad beam_eval arrays");
     FV_HIP(hipSetDevice(device));
     if (n == 0) return;
@@ -143,6 +144,7 @@ static void beam_eval_host(int device, int polarized, int kind, double diameter,
             hipLaunchKernelGGL(k_jones_interleave, dim3((unsigned)cdiv(nodes * nft, 256)), dim3(256), 0, sg.s,
                                dtab_in.as<cplx<double>>(), dtab.as<cplx<double>>(), nodes, (int64_t)nft);
         }
+        if (order == 3) bspline3_prefilter(dtab.as<double>(), nft, nza, naz, polarized ? 8 : 1, sg.s);
         b.table = dtab.p;
         b.nfreq_tab = nft;
         b.nza = nza;
@@ -157,7 +159,7 @@ static void beam_eval_host(int device, int polarized, int kind, double diameter,
     dout.reserve(sizeof(cplx<T>) * nout);
     FV_HIP(hipMemcpyAsync(daz.p, az, sizeof(T) * n, hipMemcpyHostToDevice, sg.s));
     FV_HIP(hipMemcpyAsync(dza.p, za, sizeof(T) * n, hipMemcpyHostToDevice, sg.s));
-    hipLaunchKernelGGL(k_beam_eval<T>, dim3(cdiv(n, 256)), dim3(256), 0, sg.s, b, polarized, fidx,
+    hipLaunchKernelGGL((order == 3 ? k_beam_eval<T, 3> : k_beam_eval<T, 1>), dim3(cdiv(n, 256)), dim3(256), 0, sg.s, b, polarized, fidx,
                        freq, n, daz.as<T>(), dza.as<T>(), dout.as<cplx<T>>());
     FV_HIP(hipMemcpyAsync(out, dout.p, sizeof(cplx<T>) * nout, hipMemcpyDeviceToHost, sg.s));
     FV_HIP(hipStreamSynchronize(sg.s));
@@ -262,16 +264,16 @@ int fv_nudft3_direct(int device, int precision, int dim, int64_t M, const void *
 }
 
 int fv_beam_eval(int device, int precision, int polarized, int kind, double diameter,
-                 int nfreq_tab, int nza, int naz, double za_max, const void *table, int freq_index,
-                 double freq, int64_t n, const void *az, const void *za, void *out) {
+                 int nfreq_tab, int nza, int naz, double za_max, const void *table, int order,
+                 int freq_index, double freq, int64_t n, const void *az, const void *za, void *out) {
     return guarded([&] {
         FV_REQUIRE(precision == 1 || precision == 2, "precision must be 1 or 2");
         if (precision == 2)
             beam_eval_host<double>(device, polarized, kind, diameter, nfreq_tab, nza, naz, za_max,
-                                   table, freq_index, freq, n, az, za, out);
+                                   table, order, freq_index, freq, n, az, za, out);
         else
             beam_eval_host<float>(device, polarized, kind, diameter, nfreq_tab, nza, naz, za_max,
-                                  table, freq_index, freq, n, az, za, out);
+                                  table, order, freq_index, freq, n, az, za, out);
     });
 }
 
@@ -351,8 +353,8 @@ int fv_sim_set_beam_airy(fv_sim *h, int beam, double diameter) {
     FV_SIM_CALL(FV_REQUIRE(diameter > 0, "diameter must be positive"); h->impl->set_beam_airy(beam, diameter));
 }
 int fv_sim_set_beam_table(fv_sim *h, int beam, int nfreq_tab, int nza, int naz, double za_max,
-                          const void *table) {
-    FV_SIM_CALL(FV_REQUIRE(table, "null table"); h->impl->set_beam_table(beam, nfreq_tab, nza, naz, za_max, table));
+                          const void *table, int order) {
+    FV_SIM_CALL(FV_REQUIRE(table, "null table"); h->impl->set_beam_table(beam, nfreq_tab, nza, naz, za_max, table, order));
 }
 int fv_sim_set_beam_pairs(fv_sim *h, int npairs, const int *bi, const int *bj, const int64_t *off,
                           const int *idx, const signed char *flipped) {

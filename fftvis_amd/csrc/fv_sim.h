@@ -124,6 +124,109 @@ __device__ inline Bilin bilin_setup(const BeamDesc &b, double az, double za) {
     return o;
 }
 
+// Order-3 interpolation (beam_spline_opts {"order": 3}, the reference CLI's default, cli.py:50,146;
+// scipy.ndimage.map_coordinates semantics: interpolating cubic B-spline): nodes floor(x) - 1 .. + 2
+// with the B-spline weights, on a table whose samples were replaced by spline coefficients at upload
+// (k_bspline3_prefilter).  az is periodic; za mirrors about its first and last node.
+struct Cubic {
+    int ia[4], iz[4];
+    double wa[4], wz[4];
+};
+
+__device__ inline void bspline3_weights(double t, double w[4]) {
+    const double u = 1.0 - t, t2 = t * t, t3 = t2 * t;
+    w[0] = u * u * u * (1.0 / 6.0);
+    w[1] = (4.0 - 6.0 * t2 + 3.0 * t3) * (1.0 / 6.0);
+    w[2] = (1.0 + 3.0 * t + 3.0 * t2 - 3.0 * t3) * (1.0 / 6.0);
+    w[3] = t3 * (1.0 / 6.0);
+}
+
+__device__ inline Cubic cubic_setup(const BeamDesc &b, double az, double za) {
+    Cubic o;
+    const double twopi = 2.0 * M_PI;
+    double a = fmod(az, twopi);
+    if (a < 0) a += twopi;
+    const double fa = a / (twopi / b.naz);
+    const int ia0 = (int)floor(fa);
+    bspline3_weights(fa - ia0, o.wa);
+    for (int k = 0; k < 4; ++k) o.ia[k] = ((ia0 - 1 + k) % b.naz + b.naz) % b.naz;
+    double fz = za / (b.za_max / (b.nza - 1));
+    fz = fmin(fmax(fz, 0.0), (double)(b.nza - 1));
+    const int iz0 = min((int)floor(fz), b.nza - 2);
+    bspline3_weights(fz - iz0, o.wz);
+    const int per = 2 * (b.nza - 1);
+    for (int k = 0; k < 4; ++k) {
+        int j = ((iz0 - 1 + k) % per + per) % per;
+        o.iz[k] = j < b.nza ? j : per - j;
+    }
+    return o;
+}
+
+// scipy.ndimage.spline_filter1d(order = 3) in place, one line per thread, on a table stored as
+// [freq][za][az][C] doubles: axis 0 = za lines (mode "mirror"), axis 1 = az lines ("grid-wrap").
+// Pole z = sqrt(3) - 2, gain 6; boundary sums run over the whole line (exact, as scipy's).
+__global__ void k_bspline3_prefilter(double *__restrict__ data, int64_t nfreq, int nza, int naz, int C,
+                                     int axis) {
+    const int nother = axis == 0 ? naz : nza;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nfreq * nother * C) return;
+    const int c = (int)(t % C);
+    const int64_t r = t / C;
+    const int other = (int)(r % nother);
+    const int64_t f = r / nother;
+    double *p;
+    int64_t st;
+    int n;
+    if (axis == 0) {
+        p = data + ((f * nza) * naz + other) * C + c;
+        st = (int64_t)naz * C;
+        n = nza;
+    } else {
+        p = data + ((f * nza + other) * naz) * C + c;
+        st = C;
+        n = naz;
+    }
+    if (n < 2) return;
+    const double z = sqrt(3.0) - 2.0;
+    for (int i = 0; i < n; ++i) p[i * st] *= 6.0;
+    if (axis == 0) {  // mirror
+        const double zn1 = pow(z, (double)(n - 1));
+        double c0 = p[0] + zn1 * p[(n - 1) * st], zi = z;
+        for (int i = 1; i < n - 1; ++i) {
+            c0 += zi * (p[i * st] + zn1 * p[(n - 1 - i) * st]);
+            zi *= z;
+        }
+        p[0] = c0 / (1.0 - zn1 * zn1);
+    } else {  // periodic
+        double c0 = p[0], zi = z;
+        for (int i = 1; i < n; ++i) {
+            c0 += zi * p[(n - i) * st];
+            zi *= z;
+        }
+        p[0] = c0 / (1.0 - zi);
+    }
+    double prev = p[0];
+    for (int i = 1; i < n; ++i) {
+        prev = p[i * st] + z * prev;
+        p[i * st] = prev;
+    }
+    if (axis == 0) {
+        p[(n - 1) * st] = (z * p[(n - 2) * st] + p[(n - 1) * st]) * z / (z * z - 1.0);
+    } else {
+        double cl = p[(n - 1) * st], zi = z;
+        for (int i = 0; i < n - 1; ++i) {
+            cl += zi * p[i * st];
+            zi *= z;
+        }
+        p[(n - 1) * st] = cl * z / (zi - 1.0);
+    }
+    double next = p[(n - 1) * st];
+    for (int i = n - 2; i >= 0; --i) {
+        next = z * (next - p[i * st]);
+        p[i * st] = next;
+    }
+}
+
 // [freq][4][za][az] (caller's layout) -> [freq][za][az][4] (device layout of Jones tables)
 __global__ void k_jones_interleave(const cplx<double> *__restrict__ in, cplx<double> *__restrict__ out,
                                    int64_t nodes, int64_t nfreq) {
@@ -133,7 +236,17 @@ __global__ void k_jones_interleave(const cplx<double> *__restrict__ in, cplx<dou
     for (int j = 0; j < 4; ++j) out[(f * nodes + nd) * 4 + j] = in[(f * 4 + j) * nodes + nd];
 }
 
+// samples -> cubic B-spline coefficients, both axes (order-3 tables only; once per upload)
+inline void bspline3_prefilter(double *table, int64_t nfreq, int nza, int naz, int C, hipStream_t s) {
+    for (int axis = 0; axis < 2; ++axis) {
+        const int64_t lines = nfreq * (axis == 0 ? naz : nza) * C;
+        hipLaunchKernelGGL(k_bspline3_prefilter, dim3((unsigned)cdiv(lines, 64)), dim3(64), 0, s, table, nfreq,
+                           nza, naz, C, axis);
+    }
+}
+
 // Jones matrix A[ax][feed] (row-major, 4 complex) of one beam at one (source, frequency).
+template <int ORD>
 __device__ inline void eval_jones(const BeamDesc &b, int fidx, double freq, double az, double za,
                                   cplx<double> A[4]) {
     if (b.kind == 0) {
@@ -141,8 +254,24 @@ __device__ inline void eval_jones(const BeamDesc &b, int fidx, double freq, doub
         for (int i = 0; i < 4; ++i) A[i] = {e, 0.0};
         return;
     }
-    const Bilin w = bilin_setup(b, az, za);
     const int ft = b.nfreq_tab > 1 ? fidx : 0;
+    if (ORD == 3) {
+        const Cubic w = cubic_setup(b, az, za);
+        const cplx<double> *tab = (const cplx<double> *)b.table + (int64_t)ft * 4 * b.nza * b.naz;
+        for (int i = 0; i < 4; ++i) A[i] = {0.0, 0.0};
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < 4; ++l) {
+                const double wt = w.wz[k] * w.wa[l];
+                const cplx<double> *nd = tab + ((int64_t)w.iz[k] * b.naz + w.ia[l]) * 4;
+                for (int i = 0; i < 4; ++i) {
+                    const cplx<double> v = nd[i];
+                    A[i].re += v.re * wt;
+                    A[i].im += v.im * wt;
+                }
+            }
+        return;
+    }
+    const Bilin w = bilin_setup(b, az, za);
     // device layout [freq][za][az][4 Jones]: the four Jones entries of a node are one 64-B sector (the
     // caller's [freq][2][2][za][az] planes are interleaved at upload, k_jones_interleave)
     const cplx<double> *tab = (const cplx<double> *)b.table + (int64_t)ft * 4 * b.nza * b.naz;
@@ -159,14 +288,22 @@ __device__ inline void eval_jones(const BeamDesc &b, int fidx, double freq, doub
 
 // Power beam (unpolarized path: prepare_beam_unpolarized in wrapper.py:278-279 hands the engine a
 // single-polarisation power beam; evaluate_beam returns [0,0,0,:], cpu/beams.py:78-81).
+template <int ORD>
 __device__ inline double eval_power(const BeamDesc &b, int fidx, double freq, double az, double za) {
     if (b.kind == 0) {
         const double e = airy_efield(b.diameter, freq, za);
         return e * e;
     }
-    const Bilin w = bilin_setup(b, az, za);
     const int ft = b.nfreq_tab > 1 ? fidx : 0;
     const double *p = (const double *)b.table + (int64_t)ft * b.nza * b.naz;
+    if (ORD == 3) {
+        const Cubic w = cubic_setup(b, az, za);
+        double acc = 0.0;
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < 4; ++l) acc += w.wz[k] * w.wa[l] * p[(int64_t)w.iz[k] * b.naz + w.ia[l]];
+        return acc;
+    }
+    const Bilin w = bilin_setup(b, az, za);
     return p[(int64_t)w.iz0 * b.naz + w.ia0] * (1 - w.wz) * (1 - w.wa) +
            p[(int64_t)w.iz0 * b.naz + w.ia1] * (1 - w.wz) * w.wa +
            p[(int64_t)w.iz1 * b.naz + w.ia0] * w.wz * (1 - w.wa) +
@@ -242,18 +379,18 @@ __global__ void k_apparent_coherency(int variant, int64_t n, const cplx<T> *__re
 
 // Stand-alone beam evaluation (GPUBeamEvaluator.evaluate_beam, gpu/beams.py:18-66):
 // polarized -> (2, 2, n) [ax][feed][src]; else (n) power (imaginary part 0).
-template <typename T>
+template <typename T, int ORD>
 __global__ void k_beam_eval(BeamDesc b, int polarized, int fidx, double freq, int64_t n,
                             const T *__restrict__ az, const T *__restrict__ za,
                             cplx<T> *__restrict__ out) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     if (!polarized) {
-        out[s] = {(T)eval_power(b, fidx, freq, (double)az[s], (double)za[s]), T(0)};
+        out[s] = {(T)eval_power<ORD>(b, fidx, freq, (double)az[s], (double)za[s]), T(0)};
         return;
     }
     cplx<double> A[4];
-    eval_jones(b, fidx, freq, (double)az[s], (double)za[s], A);
+    eval_jones<ORD>(b, fidx, freq, (double)az[s], (double)za[s], A);
     for (int i = 0; i < 4; ++i) out[i * n + s] = {(T)A[i].re, (T)A[i].im};
 }
 
@@ -282,7 +419,7 @@ struct StrengthArgs {
 
 // Strengths of compacted source jc at catalog frequency fidx for one beam pair, times `pre`:
 // tpol values written to dst.
-template <typename T>
+template <typename T, int ORD>
 __device__ inline void strength_eval(const StrengthArgs &a, int jc, int fidx, cplx<double> pre,
                                      const int *__restrict__ src_idx, const T *__restrict__ az,
                                      const T *__restrict__ za, const void *__restrict__ flux,
@@ -292,8 +429,8 @@ __device__ inline void strength_eval(const StrengthArgs &a, int jc, int fidx, cp
     const double azv = az[jc], zav = za[jc];
     if (!a.polarized) {
         // cpu_simulate.py:183-187: sqrt(B_i B_j) * I   (principal square root)
-        const double bi = eval_power(a.bi, fidx, freq, azv, zav);
-        const double bj = a.same_beam ? bi : eval_power(a.bj, fidx, freq, azv, zav);
+        const double bi = eval_power<ORD>(a.bi, fidx, freq, azv, zav);
+        const double bj = a.same_beam ? bi : eval_power<ORD>(a.bj, fidx, freq, azv, zav);
         const double I = (double)((const T *)flux)[js * a.nfreq + fidx];
         cplx<double> c = cscale(csqrt_principal(cplx<double>{bi * bj, 0.0}), I);
         c = cmul(c, pre);
@@ -301,11 +438,11 @@ __device__ inline void strength_eval(const StrengthArgs &a, int jc, int fidx, cp
         return;
     }
     cplx<double> Ai[4], Aj[4];
-    eval_jones(a.bi, fidx, freq, azv, zav, Ai);
+    eval_jones<ORD>(a.bi, fidx, freq, azv, zav, Ai);
     if (a.same_beam) {
         for (int i = 0; i < 4; ++i) Aj[i] = Ai[i];
     } else {
-        eval_jones(a.bj, fidx, freq, azv, zav, Aj);
+        eval_jones<ORD>(a.bj, fidx, freq, azv, zav, Aj);
     }
     cplx<double> o[4];
     if (!a.pol_sky) {
@@ -328,7 +465,7 @@ __device__ inline void strength_eval(const StrengthArgs &a, int jc, int fidx, cp
 
 // thread <-> (sorted source p, frequency fgi); fgi fastest so a wave reads flux rows contiguously
 // and writes its tpol strengths back to back:  cs[p][fgi * tpol + r].
-template <typename T>
+template <typename T, int ORD>
 __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const int *__restrict__ perm,
                             const int *__restrict__ src_idx, const T *__restrict__ az,
                             const T *__restrict__ za, const void *__restrict__ flux,
@@ -348,7 +485,7 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const in
     cplx<double> pre = {1.0, 0.0};
     if (dot != 0.0) sincos(freqs[fidx] * dot, &pre.im, &pre.re);
     const int tp = a.polarized ? 4 : 1;
-    strength_eval<T>(a, perm[p], fidx, pre, src_idx, az, za, flux, freqs, cs + (p * a.nfg + fgi) * tp);
+    strength_eval<T, ORD>(a, perm[p], fidx, pre, src_idx, az, za, flux, freqs, cs + (p * a.nfg + fgi) * tp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -432,7 +569,7 @@ __global__ void k_t1_bin(T1Args a, const int *__restrict__ Mp, const T *__restri
         }
 }
 
-template <typename T>
+template <typename T, int ORD>
 __global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent,
                                const unsigned char *__restrict__ recs, int rec, const int *__restrict__ src_idx,
                                const T *__restrict__ az, const T *__restrict__ za,
@@ -442,7 +579,7 @@ __global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent,
     if (e >= *nent) return;
     const int id = reinterpret_cast<const int *>(recs + e * rec)[2];
     const int tp = a.polarized ? 4 : 1;
-    strength_eval<T>(a, id / a.nfg, a.f_first + id % a.nfg, cplx<double>{1.0, 0.0}, src_idx, az, za,
+    strength_eval<T, ORD>(a, id / a.nfg, a.f_first + id % a.nfg, cplx<double>{1.0, 0.0}, src_idx, az, za,
                      flux, freqs, cs + e * tp);
 }
 
@@ -584,7 +721,7 @@ struct SimBase {
     virtual void set_nbeams(int n) = 0;
     virtual void set_beam_airy(int b, double diameter) = 0;
     virtual void set_beam_table(int b, int nfreq_tab, int nza, int naz, double za_max,
-                                const void *table) = 0;
+                                const void *table, int order) = 0;
     virtual void set_beam_pairs(int npairs, const int *bi, const int *bj, const int64_t *off,
                                 const int *idx, const signed char *flipped) = 0;
     virtual void set_basis(int nant, int K, int nfreq, const void *coefs, const int *ant1,
@@ -624,6 +761,7 @@ class Sim : public SimBase {
     std::vector<double> h_bls;  // (3, nbls) seconds
     DevBuf d_bls;               // (3, nbls) T
 
+    int beam_order = 1;  // interpolation order of the tabulated beams (1 or 3)
     struct Beam {
         int kind = -1;
         double diameter = 0;
@@ -849,10 +987,16 @@ class Sim : public SimBase {
         beams[b].kind = 0;
         beams[b].diameter = diameter;
     }
-    void set_beam_table(int b, int nft, int nza, int naz, double za_max, const void *table) override {
+    void set_beam_table(int b, int nft, int nza, int naz, double za_max, const void *table,
+                        int order) override {
         FV_HIP(hipSetDevice(device));
         FV_REQUIRE(b >= 0 && b < (int)beams.size(), "beam index out of range");
         FV_REQUIRE(nza >= 2 && naz >= 1 && nft >= 1 && za_max > 0, "bad beam table shape");
+        FV_REQUIRE(order == 1 || order == 3, "beam interpolation order must be 1 or 3");
+        for (size_t i = 0; i < beams.size(); ++i)  // one spline_opts per simulation (cpu_simulate.py:557)
+            FV_REQUIRE((int)i == b || beams[i].kind != 1 || beam_order == order,
+                       "all tabulated beams of a handle share one interpolation order");
+        beam_order = order;
         Beam &bm = beams[b];
         bm.kind = 1;
         bm.nfreq_tab = nft;
@@ -872,6 +1016,7 @@ class Sim : public SimBase {
                                tmp.as<cplx<double>>(), bm.table->template as<cplx<double>>(), nodes, (int64_t)nft);
             FV_HIP(hipStreamSynchronize(stream));  // tmp goes out of scope
         }
+        if (order == 3) bspline3_prefilter(bm.table->template as<double>(), nft, nza, naz, polarized ? 8 : 1, stream);
     }
     void set_beam_pairs(int np, const int *bi, const int *bj, const int64_t *off, const int *idx,
                         const signed char *flipped) override {
@@ -1106,7 +1251,8 @@ class Sim : public SimBase {
                     sa.dim = 2;
                     sa.bi = desc(pr.bi);
                     sa.bj = desc(pr.bj);
-                    hipLaunchKernelGGL(k_t1_strengths<T>, dim3(cdiv(ecap, 256)), dim3(256), 0, stream,
+                    hipLaunchKernelGGL((beam_order == 3 ? k_t1_strengths<T, 3> : k_t1_strengths<T, 1>),
+                                       dim3(cdiv(ecap, 256)), dim3(256), 0, stream,
                                        sa, nent, (const unsigned char *)recs.as<unsigned char>(), rec,
                                        d_srcidx.as<int>(),
                                        d_az.as<T>(), d_za.as<T>(), d_flux.p, d_freqs.as<double>(),
@@ -1450,7 +1596,8 @@ class Sim : public SimBase {
         sa.bi = desc(pr.bi);
         sa.bj = desc(pr.bj);
         cplx<T> *cs = nufft->strengths_buffer(nfg * tpol);
-        hipLaunchKernelGGL(k_strengths<T>, dim3(cdiv((int64_t)M * nfg, 256)), dim3(256), 0, on, sa, Mp,
+        hipLaunchKernelGGL((beam_order == 3 ? k_strengths<T, 3> : k_strengths<T, 1>),
+                           dim3(cdiv((int64_t)M * nfg, 256)), dim3(256), 0, on, sa, Mp,
                            nufft->perm.template as<int>(), L.d_srcidx.template as<int>(),
                            L.d_az.template as<T>(), L.d_za.template as<T>(), d_flux.p, d_freqs.as<double>(),
                            nufft->i0s.template as<int>(), nufft->fs.template as<T>(), cs);

@@ -8,7 +8,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import _lib
-from ..core.beams import BeamEvaluator, describe_beam, spline_order
+from ..core.beams import BeamEvaluator, checked_spline_order, describe_beam
 from ..core.utils import prepare_beam_evaluation as _prepare_beam_evaluation
 
 
@@ -45,8 +45,7 @@ class GPUBeamEvaluator(BeamEvaluator):
         self.polarized = polarized
         self.freq = freq
         self.spline_opts = spline_opts or {}
-        if spline_order(self.spline_opts) != 1:
-            raise NotImplementedError("GPU beam interpolation supports spline order 1 only")
+        order = checked_spline_order(self.spline_opts)
         az = np.asarray(az)
         prec = 1 if az.dtype == np.float32 else 2
         rdt, cdt = (np.float32, np.complex64) if prec == 1 else (np.float64, np.complex128)
@@ -59,11 +58,11 @@ class GPUBeamEvaluator(BeamEvaluator):
         _lib.require_gpu()
         if desc[0] == "airy":
             st = L.fv_beam_eval(self.device, prec, int(polarized), 0, desc[1], 0, 0, 0, 0.0, None,
-                                0, float(freq), n, _lib.ptr(az), _lib.ptr(za), _lib.ptr(out))
+                                1, 0, float(freq), n, _lib.ptr(az), _lib.ptr(za), _lib.ptr(out))
         else:
             tab = desc[1]
             st = L.fv_beam_eval(self.device, prec, int(polarized), 1, 0.0, tab.shape[0],
-                                tab.shape[-2], tab.shape[-1], float(desc[2]), _lib.ptr(tab),
+                                tab.shape[-2], tab.shape[-1], float(desc[2]), _lib.ptr(tab), order,
                                 int(freq_index), float(freq), n, _lib.ptr(az), _lib.ptr(za),
                                 _lib.ptr(out))
         _lib.check(st)

@@ -19,7 +19,7 @@ import numpy as np
 from .. import _lib
 from ..core import utils
 from ..core.antenna_gridding import check_antpos_griddability
-from ..core.beams import describe_beam, spline_order
+from ..core.beams import checked_spline_order, describe_beam
 from ..core.coords import SiderealRotation, eq_unit_vectors, julian_dates
 from ..core.simulate import SimulationEngine, default_accuracy_dict
 
@@ -87,7 +87,7 @@ class SimHandle:
         _lib.check(self._L.fv_sim_set_array_type1(self._h, _lib.ptr(B), self.nbls, _lib.ptr(b),
                                                   int(n_modes)))
 
-    def set_beams(self, beam_list, freqs):
+    def set_beams(self, beam_list, freqs, order: int = 1):
         _lib.check(self._L.fv_sim_set_nbeams(self._h, len(beam_list)))
         for i, beam in enumerate(beam_list):
             d = describe_beam(beam, self.polarized, np.asarray(freqs, dtype=float))
@@ -96,7 +96,8 @@ class SimHandle:
             else:
                 tab = d[1]
                 _lib.check(self._L.fv_sim_set_beam_table(self._h, i, tab.shape[0], tab.shape[-2],
-                                                         tab.shape[-1], float(d[2]), _lib.ptr(tab)))
+                                                         tab.shape[-1], float(d[2]), _lib.ptr(tab),
+                                                         int(order)))
 
     def set_beam_pairs(self, pairs, pair_idx, pair_flip):
         bi = np.array([p[0] for p in pairs], dtype=np.int32)
@@ -229,13 +230,12 @@ class GPUSimulationEngine(SimulationEngine):
           implementation", reference gpu/nufft.py:38);
         * ``beam_coefs`` (eigenbeams): like the reference, the (l, k) term reuses V_kl transposed
           (exact for real-valued basis beams, reference cpu_simulate.py:464-468);
-        * ``beam_spline_opts`` must ask for order 1 (or be None): higher spline orders are not
-          built yet;
+        * ``beam_spline_opts``: order 1 (bilinear, also when None) or 3 (cubic B-spline; ``kx/ky``
+          of ``az_za_simple`` are read the same way); other orders raise NotImplementedError;
         * ``time_idx`` / ``freq_idx`` (extra) restrict the run to a block, which is how ranks
           shard a simulation across GPUs.
         """
-        if spline_order(beam_spline_opts) != 1:
-            raise NotImplementedError("GPU beam interpolation supports spline order 1 only")
+        beam_order = checked_spline_order(beam_spline_opts)
         freqs = np.asarray(freqs)
         nfreqs, ntimes, nbeam, nant = np.size(freqs), len(julian_dates(times)), len(beam_list), len(ants)
         real_dtype = np.float32 if precision == 1 else np.float64
@@ -305,7 +305,7 @@ class GPUSimulationEngine(SimulationEngine):
                 h.set_array_type1(basis_matrix.astype(float), bls_int, n_modes)
             else:
                 h.set_array(R.astype(float), bls.astype(float), is_coplanar)
-            h.set_beams(beam_list, freqs.astype(float))
+            h.set_beams(beam_list, freqs.astype(float), beam_order)
             if use_basis:
                 h.set_basis(beam_coefs, ant1_idxs, ant2_idxs)
             else:

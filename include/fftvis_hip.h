@@ -62,8 +62,8 @@ int fv_nudft3_direct(int device, int precision, int dim, int64_t M, const void *
  *   beam_i/beam_j/out: (2,2,n) complex (variant 4: (n)); flux: (n) real or (2,2,n) complex.
  * fv_inplace_rot: gpu.utils.inplace_rot (src/fftvis/gpu/utils.py:8-22): b (3,n) <- rot (3,3) b. */
 int fv_beam_eval(int device, int precision, int polarized, int kind, double diameter,
-                 int nfreq_tab, int nza, int naz, double za_max, const void *table, int freq_index,
-                 double freq, int64_t n, const void *az, const void *za, void *out);
+                 int nfreq_tab, int nza, int naz, double za_max, const void *table, int order,
+                 int freq_index, double freq, int64_t n, const void *az, const void *za, void *out);
 int fv_apparent_coherency(int device, int precision, int variant, int64_t n, const void *beam_i,
                           const void *beam_j, const void *flux, void *out);
 int fv_inplace_rot(int device, int precision, const double *rot, void *b, int64_t n);
@@ -123,14 +123,18 @@ int fv_sim_set_array_type1(fv_sim *h, const double *basis_matrix, int64_t nbls, 
 
 /* Beams (evaluate_beam, cpu/beams.py:12-89).  kind 0: analytic Airy dish, param[0] = diameter
  * [m]; E-field 2 J1(x)/x in all four Jones slots, power beam = its square.
- * kind 1: tabulated on a regular (za, az) grid, order-1 interpolation; table is
+ * kind 1: tabulated on a regular (za, az) grid; table is
  *   polarized:   (nfreq_tab, 2, 2, nza, naz) complex128  [ax, feed]
  *   unpolarized: (nfreq_tab, nza, naz) float64 power
- * with az periodic over 2 pi, za in [0, za_max] inclusive; nfreq_tab is 1 or nfreq.          */
+ * with az periodic over 2 pi, za in [0, za_max] inclusive; nfreq_tab is 1 or nfreq.
+ * order = beam_spline_opts["order"] (cpu/beams.py:69-74 -> pyuvdata az_za_map_coordinates ->
+ * scipy.ndimage.map_coordinates): 1 = bilinear; 3 = interpolating cubic B-spline (the table is
+ * turned into spline coefficients on the device at upload; periodic in az, mirrored in za).
+ * One order per handle.                                                                       */
 int fv_sim_set_nbeams(fv_sim *h, int nbeams);
 int fv_sim_set_beam_airy(fv_sim *h, int beam, double diameter);
 int fv_sim_set_beam_table(fv_sim *h, int beam, int nfreq_tab, int nza, int naz, double za_max,
-                          const void *table);
+                          const void *table, int order);
 
 /* Beam pairs (prepare_beam_evaluation, cpu/beams.py:91-127): for pair p, beams (bi[p], bj[p]),
  * baseline indices idx[off[p] .. off[p+1]) and their `flipped` flags.  npairs = 1, bi=bj=0,

@@ -402,20 +402,60 @@ class AiryBeam:
 
 
 class TabulatedBeam:
-    """A UVBeam-like table on a regular (za, az) grid, order-1 interpolation.
+    """A UVBeam-like table on a regular (za, az) grid, order-1 or order-3 interpolation.
 
     data[freq, ax, feed, iza, iaz] complex (efield) or data[freq, iza, iaz]
     real (power).  az is periodic with period 2*pi (naz cells of width
     2*pi/naz), za runs 0..za_max inclusive over nza nodes.  Stands in for
-    pyuvdata's az_za_map_coordinates(order=1) at cpu/beams.py:69-74.
+    pyuvdata's az_za_map_coordinates(order=spline_opts["order"]) at
+    cpu/beams.py:69-74, i.e. scipy.ndimage.map_coordinates: order 1 is
+    bilinear; order 3 is the interpolating cubic B-spline (scipy's own
+    spline_filter1d makes the coefficients; periodic in az, "mirror" in za).
     """
 
-    def __init__(self, data, freqs, za_max=np.pi, beam_type="efield"):
+    def __init__(self, data, freqs, za_max=np.pi, beam_type="efield", order=1):
         self.data = np.asarray(data)
         self.freqs = np.asarray(freqs, dtype=float)
         self.za_max = float(za_max)
         self.beam_type = beam_type
         self.nza, self.naz = self.data.shape[-2:]
+        if order not in (1, 3):
+            raise ValueError("order must be 1 or 3")
+        self.order = order
+        self._coef = None
+
+    def _cubic(self, fi, az, za):
+        from scipy.ndimage import spline_filter1d
+
+        if self._coef is None:
+            self._coef = {}
+        if fi not in self._coef:
+            t = self.data[fi]
+            parts = []
+            for comp in ((t.real, t.imag) if np.iscomplexobj(t) else (t,)):
+                c = spline_filter1d(np.asarray(comp, float), order=3, axis=-2, mode="mirror")
+                parts.append(spline_filter1d(c, order=3, axis=-1, mode="grid-wrap"))
+            self._coef[fi] = parts[0] + 1j * parts[1] if len(parts) == 2 else parts[0]
+        coef = self._coef[fi]
+
+        def bw(t):
+            return [(1 - t) ** 3 / 6, (4 - 6 * t**2 + 3 * t**3) / 6,
+                    (1 + 3 * t + 3 * t**2 - 3 * t**3) / 6, t**3 / 6]
+
+        fa = np.mod(az, 2 * np.pi) / (2 * np.pi / self.naz)
+        ia = np.floor(fa).astype(int)
+        wa = bw(fa - ia)
+        fz = np.clip(za / (self.za_max / (self.nza - 1)), 0, self.nza - 1)
+        iz = np.minimum(np.floor(fz).astype(int), self.nza - 2)
+        wz = bw(fz - iz)
+        per = 2 * (self.nza - 1)
+        v = 0
+        for k in range(4):
+            jz = np.mod(iz - 1 + k, per)
+            jz = np.where(jz < self.nza, jz, per - jz)
+            for l in range(4):
+                v = v + coef[..., jz, np.mod(ia - 1 + l, self.naz)] * (wz[k] * wa[l])
+        return v
 
     def _weights(self, az, za):
         fa = np.mod(az, 2 * np.pi) / (2 * np.pi / self.naz)
@@ -431,16 +471,19 @@ class TabulatedBeam:
     def compute_response(self, az_array, za_array, freq_array, **_):
         f = float(np.atleast_1d(freq_array)[0])
         fi = int(np.argmin(np.abs(self.freqs - f)))
-        ia0, ia1, wa, iz0, iz1, wz = self._weights(
-            np.asarray(az_array, float), np.asarray(za_array, float)
-        )
-        tab = self.data[fi]
-        v = (
-            tab[..., iz0, ia0] * (1 - wz) * (1 - wa)
-            + tab[..., iz0, ia1] * (1 - wz) * wa
-            + tab[..., iz1, ia0] * wz * (1 - wa)
-            + tab[..., iz1, ia1] * wz * wa
-        )
+        if self.order == 3:
+            v = self._cubic(fi, np.asarray(az_array, float), np.asarray(za_array, float))
+        else:
+            ia0, ia1, wa, iz0, iz1, wz = self._weights(
+                np.asarray(az_array, float), np.asarray(za_array, float)
+            )
+            tab = self.data[fi]
+            v = (
+                tab[..., iz0, ia0] * (1 - wz) * (1 - wa)
+                + tab[..., iz0, ia1] * (1 - wz) * wa
+                + tab[..., iz1, ia0] * wz * (1 - wa)
+                + tab[..., iz1, ia1] * wz * wa
+            )
         if self.beam_type == "power":
             return v[None, None, None, :].astype(complex)
         return v[:, :, None, :].astype(complex)

@@ -274,7 +274,42 @@ def test_evaluate_beam(gpu):
             exp = orc.evaluate_beam(oracle_beam(tab, pol, freqs), az, za, pol, freqs[fi])
             np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-14)
     with pytest.raises(NotImplementedError):
-        ev.evaluate_beam(tab, az, za, True, freqs[0], spline_opts={"order": 3})
+        ev.evaluate_beam(tab, az, za, True, freqs[0], spline_opts={"order": 2})
+
+
+def test_evaluate_beam_order3(gpu):
+    """Cubic B-spline interpolation (beam_spline_opts {"order": 3}: the device's own prefilter and
+    4 x 4 evaluation) against the oracle's (scipy's prefilter): Jones and power tables, several
+    frequencies, both precisions, az far outside [0, 2 pi), za at and beyond the table's ends, and
+    tables so small that the mirrored / wrapped footprint folds onto itself."""
+    rng = np.random.default_rng(5)
+    az = rng.uniform(-10, 10, 3000)
+    za = rng.uniform(0, np.pi / 2, 3000)
+    az[:4] = [0.0, 2 * np.pi - 1e-12, np.pi, -1e-9]
+    za[:4] = [0.0, np.pi / 2, 1e-9, 3.0]
+    ev = GPUBeamEvaluator()
+    freqs = np.linspace(100e6, 200e6, 4)
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs), freqs)
+    for opts in ({"order": 3}, {"kx": 3, "ky": 3}):
+        for pol in (False, True):
+            for fi in (0, 3):
+                got = ev.evaluate_beam(tab, az, za, pol, freqs[fi], freq_index=fi, spline_opts=opts)
+                exp = orc.evaluate_beam(oracle_beam(tab, pol, freqs, 3), az, za, pol, freqs[fi])
+                np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+    lin = ev.evaluate_beam(tab, az, za, True, freqs[0])
+    cub = ev.evaluate_beam(tab, az, za, True, freqs[0], spline_opts={"order": 3})
+    assert 1e-9 < rel_l2(cub, lin) < 1e-2  # a different interpolant of the same smooth table
+    got32 = ev.evaluate_beam(tab, az.astype(np.float32), za.astype(np.float32), True, freqs[1], freq_index=1,
+                             spline_opts={"order": 3})
+    exp32 = orc.evaluate_beam(oracle_beam(tab, True, freqs, 3), az.astype(np.float32).astype(float),
+                              za.astype(np.float32).astype(float), True, freqs[1])
+    assert got32.dtype == np.complex64 and rel_l2(got32, exp32) < 1e-6
+    for nza, naz in ((2, 1), (2, 3), (3, 2), (5, 4), (4, 37)):
+        d = rng.normal(size=(1, 2, 2, nza, naz)) + 1j * rng.normal(size=(1, 2, 2, nza, naz))
+        small = fftvis_amd.TabulatedBeam(d, None, 1.2)
+        got = ev.evaluate_beam(small, az, za, True, 1e8, spline_opts={"order": 3})
+        exp = orc.evaluate_beam(orc.TabulatedBeam(d, [1e8], 1.2, "efield", 3), az, za, True, 1e8)
+        np.testing.assert_allclose(got, exp, rtol=1e-10, atol=1e-12, err_msg=str((nza, naz)))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -371,6 +406,35 @@ def test_sim_basis_beams(gpu):
         fftvis_amd.simulate_vis(**dict(cfg, polarized=False))
     with pytest.raises(ValueError, match="beam_idx should not be provided"):
         fftvis_amd.simulate_vis(**dict(cfg, beam_idx=bidx))
+
+
+def test_sim_beam_spline_order3(gpu):
+    """beam_spline_opts {"order": 3} (the reference CLI's default, cli.py:50,146) through every place
+    a table is read: type-3 strengths (polarized pairs with a polarized sky; unpolarized power
+    beams), the type-1 lattice path, and eigenbeam tables; Airy beams are untouched by the option."""
+    c1 = synth.make_config("C1")
+    freqs = c1["freqs"]
+    opts = {"order": 3}
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=46, naz=90), freqs)
+    tab2 = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, diameter=11.0, nza=61, naz=72), freqs)
+    _, _, fl4 = synth.catalog(100, freqs, 0, polarized_sky=True)
+    bidx = np.array([0, 1, 0, 1, 1, 0, 1])
+    bls = c1["baselines"] + [(3, 0), (6, 1), (2, 2)]
+    pol = dict(c1, polarized=True, beam=[tab, tab2], beam_idx=bidx, fluxes=fl4, baselines=bls, beam_spline_opts=opts)
+    v3 = fftvis_amd.simulate_vis(**pol)
+    assert rel_l2(v3, oracle_simulate(pol)) < TOL
+    v1 = fftvis_amd.simulate_vis(**dict(pol, beam_spline_opts={"order": 1}))
+    assert 1e-6 < rel_l2(v3, v1) < 0.3  # coarse (4 degree) tables: the two interpolants differ visibly
+    unp = dict(c1, beam=tab, beam_spline_opts={"kx": 3, "ky": 3})
+    assert rel_l2(fftvis_amd.simulate_vis(**unp), oracle_simulate(unp)) < TOL
+    lat = dict(pol, force_use_type3=False)
+    assert rel_l2(fftvis_amd.simulate_vis(**lat), oracle_simulate(lat)) < TOL
+    rng = np.random.default_rng(4)
+    coefs = rng.normal(size=(7, 2, len(freqs))) + 1j * rng.normal(size=(7, 2, len(freqs)))
+    bas = dict(c1, polarized=True, beam=[tab, tab2], beam_coefs=coefs, beam_spline_opts=opts)
+    assert rel_l2(fftvis_amd.simulate_vis(**bas), oracle_simulate(bas)) < TOL
+    airy = dict(c1, beam_spline_opts=opts)
+    np.testing.assert_array_equal(fftvis_amd.simulate_vis(**airy), fftvis_amd.simulate_vis(**c1))
 
 
 def test_sim_fp32(gpu):
@@ -540,7 +604,7 @@ def test_sim_empty_sky_and_errors(gpu):
     with pytest.raises(ValueError, match="requires sky_model to be 2D"):
         fftvis_amd.simulate_vis(**dict(cfg, fluxes=np.ones((20, 8, 4))))
     with pytest.raises(NotImplementedError):
-        fftvis_amd.simulate_vis(**dict(cfg, beam_spline_opts={"order": 3}))
+        fftvis_amd.simulate_vis(**dict(cfg, beam_spline_opts={"order": 2}))
 
 
 def test_sim_type1_lattice_path(gpu):
@@ -668,7 +732,8 @@ def test_sim_fuzz_random_configurations(gpu):
     2-D and 3-D transforms), catalog sizes, 1-4 channels over a random band, 1-3 times, polarized or
     not (polarized skies too), 1-3 beams (Airy / tables) with random assignment, random baseline
     subsets incl. flipped pairs and autos, eps in [1e-11, 1e-4]; then random LATTICE arrays through
-    the type-1 path.  (300 more seeds of the same generator were run clean while writing it.)"""
+    the type-1 path; then both with upsample_factor 1.25.  (900 more configurations of the same
+    generator, 600 of them with mixed upsampling factors, were run clean while writing it.)"""
     rng = np.random.default_rng(2024)
     for it in range(32):
         cfg = _random_sim_config(rng)
@@ -678,6 +743,11 @@ def test_sim_fuzz_random_configurations(gpu):
         cfg = _random_sim_config(rng, lattice=True)
         err = rel_l2(fftvis_amd.simulate_vis(**cfg), oracle_simulate(cfg))
         assert err < 10 * cfg["eps"] + 1e-12, ("lattice", it, err, cfg["eps"], cfg["polarized"], len(cfg["ants"]))
+    for it in range(24):  # low upsampling (sigma = 1.25: eps floor ~1e-8 in fp64, see fv_eskernel.h)
+        cfg = _random_sim_config(rng, lattice=it % 4 == 3)
+        cfg.update(upsample_factor=1.25, eps=max(cfg["eps"], 1e-9))
+        err = rel_l2(fftvis_amd.simulate_vis(**cfg), oracle_simulate(cfg))
+        assert err < 10 * cfg["eps"] + 1e-12, ("sigma 1.25", it, err, cfg["eps"], cfg["polarized"], len(cfg["ants"]))
 
 
 def test_sim_c3_geometry_subset_and_paths(gpu):

@@ -198,17 +198,19 @@ def test_benchmark_arrays_are_lattices():
 
 def test_spline_opts_orders():
     """The reference passes {"order": 1} (map_coordinates) or {"kx": 1, "ky": 1} (az_za_simple) in its
-    own tests (tests/test_cpu_beams.py:72,82,411,428): both mean linear interpolation, which is what
-    the device implements; anything higher is refused loudly, never silently downgraded."""
-    from fftvis_amd.core.beams import spline_order
+    own tests (tests/test_cpu_beams.py:72,82,411,428) and its CLI defaults to order 3 (cli.py:50,146):
+    the device implements 1 and 3; anything else is refused loudly, never silently downgraded."""
+    from fftvis_amd.core.beams import checked_spline_order, spline_order
     from fftvis_amd.gpu.gpu_simulate import GPUSimulationEngine
 
     assert spline_order(None) == 1 and spline_order({}) == 1
     assert spline_order({"order": 1}) == 1 and spline_order({"kx": 1, "ky": 1}) == 1
     assert spline_order({"order": 3}) == 3 and spline_order({"kx": 3, "ky": 3}) == 3
+    assert checked_spline_order(None) == 1 and checked_spline_order({"order": 3}) == 3
     cfg = synth.make_config("C1", nsrc=5, nfreq=2, ntimes=1)
     eng = GPUSimulationEngine()
-    with pytest.raises(NotImplementedError, match="spline order 1"):
-        eng.simulate(ants=cfg["ants"], freqs=cfg["freqs"], fluxes=cfg["fluxes"], beam_list=[cfg["beam"]],
-                     ra=cfg["ra"], dec=cfg["dec"], times=cfg["times"], telescope_loc=cfg["telescope_loc"],
-                     beam_spline_opts={"kx": 3, "ky": 3})
+    for opts in ({"kx": 2, "ky": 2}, {"order": 5}, {"order": 0}):
+        with pytest.raises(NotImplementedError, match="spline orders 1 and 3"):
+            eng.simulate(ants=cfg["ants"], freqs=cfg["freqs"], fluxes=cfg["fluxes"], beam_list=[cfg["beam"]],
+                         ra=cfg["ra"], dec=cfg["dec"], times=cfg["times"], telescope_loc=cfg["telescope_loc"],
+                         beam_spline_opts=opts)

@@ -210,3 +210,34 @@ def test_oracle_sim_structure():
     diff = orc.simulate(*args, [orc.AiryBeam(14.0, "power"), orc.AiryBeam(7.0, "power")],
                         beam_idx=np.array([0, 1, 0, 1, 0, 1, 0]), **kw)
     assert not np.allclose(one, diff)
+
+
+def test_oracle_order3_table_is_scipy_map_coordinates():
+    """The oracle's order-3 table interpolation (what pyuvdata's az_za_map_coordinates hands to
+    scipy, cpu/beams.py:69-74) against scipy.ndimage.map_coordinates itself: the periodic az axis is
+    emulated by padding a full period on both sides (the prefilter's boundary influence decays as
+    0.268^k), za uses scipy's "mirror"; and the spline reproduces the table at its nodes."""
+    from scipy.ndimage import map_coordinates
+
+    rng = np.random.default_rng(0)
+    nza, naz, za_max = 23, 36, 1.6
+    tab = rng.normal(size=(1, nza, naz))
+    b = orc.TabulatedBeam(tab, [1e8], za_max=za_max, beam_type="power", order=3)
+    az = rng.uniform(-7, 7, 500)
+    za = rng.uniform(0, za_max, 500)
+    za[:3] = [0, za_max, 0.8]
+    got = b.compute_response(az, za, [1e8])[0, 0, 0].real
+    pad = np.concatenate([tab[0]] * 3, axis=1)
+    fa = np.mod(az, 2 * np.pi) / (2 * np.pi / naz) + naz
+    ref = map_coordinates(pad, [za / (za_max / (nza - 1)), fa], order=3, mode="mirror")
+    np.testing.assert_allclose(got, ref, atol=1e-12)
+    zi, ai = np.meshgrid(np.arange(nza), np.arange(naz), indexing="ij")
+    nodes = b.compute_response((ai * 2 * np.pi / naz).ravel(), (zi * za_max / (nza - 1)).ravel(), [1e8])
+    np.testing.assert_allclose(nodes[0, 0, 0].real, tab[0].ravel(), atol=1e-12)
+    # complex Jones tables: real and imaginary parts are filtered separately
+    jt = rng.normal(size=(2, 2, 2, nza, naz)) + 1j * rng.normal(size=(2, 2, 2, nza, naz))
+    bj = orc.TabulatedBeam(jt, [1e8, 2e8], za_max=za_max, order=3)
+    r = bj.compute_response(az, za, [2e8])
+    padj = np.concatenate([jt[1, 1, 0].imag] * 3, axis=1)
+    np.testing.assert_allclose(r[1, 0, 0].imag, map_coordinates(padj, [za / (za_max / (nza - 1)), fa], order=3,
+                                                                mode="mirror"), atol=1e-12)
