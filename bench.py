@@ -256,7 +256,13 @@ def main():
         spread_bytes = st["source_visits"] * 2 * R8 + (st["sources_above_horizon"] / max(ntimes * a.steps, 1)) \
             * d * R8 * launches + st["spread_cells"] * 2 * R8
         spread_s = tm["spread"] * 1e-3 * launches / timed  # all launches, from the sampled average
-        spread_kernel = "k_spread2d"
+        spread_kernel = "k_spread2d" if coplanar else "k_spread3d"
+        if coplanar and os.environ.get("FFTVIS_HIP_SPREAD_CELL", "") != "1":
+            # Nufft3::launch_spread picks the channel-group lane mapping once the catalog has >= 3
+            # sources per 8 x 8-cell block (all launches of these workloads are chunks of >= 8 transforms)
+            nax, nay = int(st["n2z"]) // 65536, int(st["n2z"]) % 65536
+            if os.environ.get("FFTVIS_HIP_SPREAD_CELL") == "0" or nsrc >= 3 * ((nax + 7) // 8) * ((nay + 7) // 8):
+                spread_kernel = "k_spread2d_cg"
         if a.path == "type1":
             # lattice path: every (source, channel) pair is an entry with its own origin and 2 w
             # weights; timed in the extra step (event records around the launch), not in the
@@ -277,7 +283,7 @@ def main():
         try:
             if a.workload == "C2" and not (a.nsrc or a.nfreq or a.ntimes):
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
-                k = pm["counters"]["c2"]["k_spread2d"]
+                k = pm["counters"]["c2"][spread_kernel]
                 traffic = (2 * k["FETCH_SIZE_KB_avg_per_launch"] + k["WRITE_SIZE_KB_avg_per_launch"]) * 1024
         except Exception:
             traffic = None

@@ -471,6 +471,164 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
     for (int q = 0; q < TCH; ++q) o[q * plane] = {ar[q] * f, ai[q] * f};
 }
 
+// --- 2-D spread, channel-group lanes (TCH >= 8) ----------------------------------------------------
+// Same block / bin / chunk walk as k_spread2d, other lane mapping: lane = (x cell 0..7, channel group
+// 0..7) and a lane accumulates CPL = TCH / 8 transforms for the 8 cells of its block column.  In
+// k_spread2d every lane reads all TCH strengths of a source from LDS (256 B per lane and source
+// visit, and LDS returns bytes per lane whether or not the address is shared: that was the kernel's
+// bound once the sources were staged); here a lane reads its own CPL strengths, one x weight and
+// the 8 y weights of its column (<= 112 B).  The y-weight rows are zero-padded on both sides so
+// that those reads need no range checks (dy = 8 by + k - i0y lies in [-7, w + 13]); the footprint
+// origins come out of the staging registers with v_readlane (wave-uniform, no LDS round trip).
+// Skipping the rows (or half blocks) a footprint misses with scalar branches was measured slower.
+// Pays once blocks hold a few sources each (C2: 33.5 -> 31 us per launch, 4x the catalog: 96 -> 78 us);
+// on sparse grids (C3: < 1 source per block) the lane-per-cell kernel stays ahead, see launch_spread.
+constexpr int SPREAD_KWP = MAX_W + 24;  // padded y-weight row: 8 leading zeros, w weights, zeros
+template <typename T, int TCH>
+__global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d_cg(
+    int64_t M, const int *__restrict__ i0s, const T *__restrict__ kw,
+    const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans, int tbegin,
+    const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid, int nax,
+    int nay, int nbx, int w, const int *__restrict__ order, int nchunk) {
+    static_assert(TCH % 8 == 0, "channel-group lanes need 8 | TCH");
+    constexpr int CPL = TCH / 8;
+    __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TCH];
+    __shared__ T s_kwx[SPREAD_THREADS / 64][SPREAD_CHUNK][MAX_W];
+    __shared__ T s_kwy[SPREAD_THREADS / 64][SPREAD_CHUNK][SPREAD_KWP];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int og = order[blockIdx.x / nchunk];
+    const int bx = (og & 0xffff) * 4 + wave, by = og >> 16;
+    if (bx >= nbx) return;  // wave-uniform
+    const int tbase = tbegin + (blockIdx.x % nchunk) * TCH;
+    const int xl = lane & 7, cg = lane >> 3;
+    const int cx = (bx << BINLOG) + xl, cy0 = by << BINLOG;
+    const int *i0x = i0s, *i0y = i0s + M;
+    const T *kwx = kw, *kwy = kw + M * w;
+    T ar[CPL][8], ai[CPL][8];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ar[c][k] = ai[c][k] = T(0);
+    const int bxl = max((bx << BINLOG) - w + 1, 0) >> BINLOG;
+    const int byl = max((by << BINLOG) - w + 1, 0) >> BINLOG;
+    int rs0[3], rnc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yb = min(byl + r, by);
+        const int s0 = bin_start[yb * nbx + bxl], s1 = bin_start[yb * nbx + bx + 1];
+        rs0[r] = s0;
+        rnc[r] = byl + r <= by ? s1 - s0 : 0;
+    }
+    const int nc0 = (rnc[0] + SPREAD_CHUNK - 1) / SPREAD_CHUNK, nc1 = (rnc[1] + SPREAD_CHUNK - 1) / SPREAD_CHUNK,
+              nc2 = (rnc[2] + SPREAD_CHUNK - 1) / SPREAD_CHUNK;
+    const int nct = nc0 + nc1 + nc2;
+    auto chunk_at = [&](int c, int &n) -> int {
+        int r0 = rs0[0], len = rnc[0], k = c;
+        if (c >= nc0 + nc1) {
+            r0 = rs0[2];
+            len = rnc[2];
+            k = c - nc0 - nc1;
+        } else if (c >= nc0) {
+            r0 = rs0[1];
+            len = rnc[1];
+            k = c - nc0;
+        }
+        n = min(SPREAD_CHUNK, len - k * SPREAD_CHUNK);
+        return r0 + k * SPREAD_CHUNK;
+    };
+    // the padding of the wave's y-weight rows stays zero for the whole kernel (w is fixed)
+    if (nct > 0)
+        for (int e = lane; e < SPREAD_CHUNK * SPREAD_KWP; e += 64) (&s_kwy[wave][0][0])[e] = T(0);
+    constexpr int NS = TCH / 4;                      // strengths per lane: 16 TCH / 64
+    constexpr int NW = (SPREAD_CHUNK * MAX_W) / 64;  // weights per lane and dimension
+    cplx<T> ps[NS];
+    T pkx[NW], pky[NW];
+    int pix = 0, piy = 0;
+    auto request = [&](int base, int n) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int e = lane + 64 * i;
+            ps[i] = {T(0), T(0)};
+            if (e < n * TCH) ps[i] = cs[(int64_t)(base + e / TCH) * ntrans + tbase + e % TCH];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = lane + 64 * i;
+            pkx[i] = pky[i] = T(0);
+            if (e < n * w) {
+                pkx[i] = kwx[(int64_t)base * w + e];
+                pky[i] = kwy[(int64_t)base * w + e];
+            }
+        }
+        if (lane < n) {
+            pix = i0x[base + lane];
+            piy = i0y[base + lane];
+        }
+    };
+    int n = 0, base = 0;
+    if (nct > 0) {
+        base = chunk_at(0, n);
+        request(base, n);
+    }
+    for (int c = 0; c < nct; ++c) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int e = lane + 64 * i;
+            if (e < n * TCH) s_str[wave][e / TCH][e % TCH] = ps[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = lane + 64 * i;
+            if (e < n * w) {
+                const int j = e / w, k = e - j * w;
+                s_kwx[wave][j][k] = pkx[i];
+                s_kwy[wave][j][8 + k] = pky[i];
+            }
+        }
+        const int qx = pix, qy = piy;  // lane j: footprint origin of the chunk's source j
+        const int ncur = n;
+        if (c + 1 < nct) {
+            base = chunk_at(c + 1, n);
+            request(base, n);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < ncur; ++j) {
+            const int dx = cx - __builtin_amdgcn_readlane(qx, j);
+            const int oy = __builtin_amdgcn_readlane(qy, j) - cy0;  // first footprint row, block-relative
+            const T wx = (unsigned)dx < (unsigned)w ? s_kwx[wave][j][dx] : T(0);
+            const T *wyp = &s_kwy[wave][j][8 - oy];  // row k of the block reads weight k - oy (or padding)
+            cplx<T> cv[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) cv[q] = s_str[wave][j][cg * CPL + q];
+            T wy[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wy[k] = wyp[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const T wt = wx * wy[k];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    ar[q][k] += cv[q].re * wt;
+                    ai[q][k] += cv[q].im * wt;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next chunk
+    }
+    const T fx = decx[cx];
+    const int64_t plane = (int64_t)nay * nax;
+    cplx<T> *o = grid + (int64_t)(tbase + cg * CPL) * plane + (int64_t)cy0 * nax + cx;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const T f = fx * decy[cy0 + k];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) o[q * plane + (int64_t)k * nax] = {ar[q][k] * f, ai[q][k] * f};
+    }
+}
+
 // --- 3-D spread (gather): as k_spread2d, one wave per 8x8 (x, y) block of ONE z-plane of A ------
 // grid (ceil(nbx / 4), nby, na_z * chunks); bin index = (bz * nby + by) * nbx + bx.  The z weight of
 // a staged source is folded into its strengths while staging (it is wave-uniform: one z-plane).
@@ -1604,7 +1762,14 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
     hipEvent_t ee = tbegin + nchunk * TCH == ntrans ? e1 : nullptr;
     if (dim == 2) {
         dim3 g((unsigned)(cdiv(geo.nbin[0], 4) * geo.nbin[1] * nchunk));
-        hipExtLaunchKernelGGL((k_spread2d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
+        // lane mapping: channel groups once a block sees a few sources (M counts the catalog before
+        // the horizon cut), lane per cell on sparse grids; FFTVIS_HIP_SPREAD_CELL = 1 / 0 forces one
+        const char *force_cell = std::getenv("FFTVIS_HIP_SPREAD_CELL");
+        const bool dense = (double)M >= 3.0 * (double)geo.nbin[0] * (double)geo.nbin[1];
+        auto kern = k_spread2d<T, TCH>;
+        if constexpr (TCH >= 8)
+            if (force_cell ? std::atoi(force_cell) == 0 : dense) kern = k_spread2d_cg<T, TCH>;
+        hipExtLaunchKernelGGL(kern, g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
                               (const int *)i0s.as<int>(), (const T *)kw.as<T>(),
                               (const int *)bin_start.as<int>(),
                               (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin,

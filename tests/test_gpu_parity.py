@@ -50,6 +50,24 @@ def test_nufft2d_upsample_1p25(gpu, eps):
     assert rel_l2(gpu_nufft2d(x, y, c, s, t, eps, upsample_factor=1.25), ex) < 10 * eps
 
 
+@pytest.mark.parametrize("cell", ["0", "1"])
+def test_nufft2d_both_spread_lane_mappings(gpu, cell, monkeypatch):
+    """The 2-D spread has two lane mappings (lane per cell; lane per (x cell, channel group) for chunks
+    of >= 8 transforms) chosen by source density: force each one over kernel widths 2..16, transform
+    counts that mix 16-, 8- and smaller chunks, clustered sources (many chunks per block) and fp32."""
+    monkeypatch.setenv("FFTVIS_HIP_SPREAD_CELL", cell)
+    for eps, ntr, seed in ((1e-1, 8, 0), (1e-4, 24, 1), (6e-8, 19, 2), (1e-11, 16, 3), (1e-14, 9, 4)):
+        x, y, c, s, t = _problem(4000, 300, 40.0, ntr, seed=seed)
+        x[:1500] = x[0] + 1e-3 * (x[:1500] - x[0])  # a dense cluster: > 16 sources in one bin
+        y[:1500] = y[0] + 1e-3 * (y[:1500] - y[0])
+        ex = nudft.nudft_type3([x, y], c, [s, t])
+        assert rel_l2(gpu_nufft2d(x, y, c, s, t, eps), ex) < 10 * eps + 5e-13, (cell, eps, ntr)
+    x, y, c, s, t = _problem(3000, 200, 30.0, 16, seed=5)
+    got = gpu_nufft2d(x.astype(np.float32), y.astype(np.float32), c.astype(np.complex64),
+                      s.astype(np.float32), t.astype(np.float32), 1e-4)
+    assert rel_l2(got, nudft.nudft_type3([x, y], c, [s, t])) < 1e-3
+
+
 def test_nufft2d_fp32(gpu):
     x, y, c, s, t = _problem(3000, 500, 60.0, 3)
     ex = nudft.nudft_type3([x, y], c, [s, t])

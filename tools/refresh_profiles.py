@@ -32,7 +32,7 @@ for tag in ("c2", "c3"):
     if not F:
         continue
     out["counters"][tag] = {}
-    for k in ("k_strengths", "k_spread2d", "k_rowfft_st", "k_transpose", "k_interp"):
+    for k in ("k_strengths", "k_spread2d", "k_spread2d_cg", "k_rowfft_st", "k_transpose", "k_interp"):
         if k in F and k in W:
             out["counters"][tag][k] = {"FETCH_SIZE_KB_avg_per_launch": F[k][0] / F[k][1], "launches": F[k][1],
                                        "WRITE_SIZE_KB_avg_per_launch": W[k][0] / W[k][1]}
