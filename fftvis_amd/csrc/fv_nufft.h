@@ -321,6 +321,13 @@ __global__ void k_load_strengths(int64_t M, const int *__restrict__ Mp, int ntra
     }
 }
 
+// Second source set of a gang launch (grid.y = 2: two time steps on one geometry in one launch).
+struct SpreadMate {
+    const int *i0s, *bin_start;
+    const void *kw, *cs;
+    void *grid;
+};
+
 // --- 2-D spread (gather) ------------------------------------------------------------------------
 // One wave owns one 8x8-cell block of A, aligned with the 8x8 source bins; lane = cell.  A source
 // touches cell c iff 0 <= c - i0 < w in both dimensions, so only the bins
@@ -337,10 +344,15 @@ constexpr int SPREAD_CHUNK = 16;
 #endif
 template <typename T, int TCH>
 __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
-    int64_t M, const int *__restrict__ i0s, const T *__restrict__ kw,
-    const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans, int tbegin,
-    const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid, int nax,
-    int nay, int nbx, int w, const int *__restrict__ order, int nchunk) {
+    int64_t M, const int *__restrict__ i0s_a, const T *__restrict__ kw_a,
+    const int *__restrict__ bin_start_a, const cplx<T> *__restrict__ cs_a, int ntrans, int tbegin,
+    const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid_a, int nax,
+    int nay, int nbx, int w, const int *__restrict__ order, int nchunk, SpreadMate mate) {
+    const int *__restrict__ i0s = blockIdx.y ? mate.i0s : i0s_a;
+    const T *__restrict__ kw = blockIdx.y ? static_cast<const T *>(mate.kw) : kw_a;
+    const int *__restrict__ bin_start = blockIdx.y ? mate.bin_start : bin_start_a;
+    const cplx<T> *__restrict__ cs = blockIdx.y ? static_cast<const cplx<T> *>(mate.cs) : cs_a;
+    cplx<T> *__restrict__ grid = blockIdx.y ? static_cast<cplx<T> *>(mate.grid) : grid_a;
     __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TCH];
     __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][MAX_W];
     __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
@@ -486,10 +498,15 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
 constexpr int SPREAD_KWP = MAX_W + 24;  // padded y-weight row: 8 leading zeros, w weights, zeros
 template <typename T, int TCH>
 __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d_cg(
-    int64_t M, const int *__restrict__ i0s, const T *__restrict__ kw,
-    const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans, int tbegin,
-    const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid, int nax,
-    int nay, int nbx, int w, const int *__restrict__ order, int nchunk) {
+    int64_t M, const int *__restrict__ i0s_a, const T *__restrict__ kw_a,
+    const int *__restrict__ bin_start_a, const cplx<T> *__restrict__ cs_a, int ntrans, int tbegin,
+    const T *__restrict__ decx, const T *__restrict__ decy, cplx<T> *__restrict__ grid_a, int nax,
+    int nay, int nbx, int w, const int *__restrict__ order, int nchunk, SpreadMate mate) {
+    const int *__restrict__ i0s = blockIdx.y ? mate.i0s : i0s_a;
+    const T *__restrict__ kw = blockIdx.y ? static_cast<const T *>(mate.kw) : kw_a;
+    const int *__restrict__ bin_start = blockIdx.y ? mate.bin_start : bin_start_a;
+    const cplx<T> *__restrict__ cs = blockIdx.y ? static_cast<const cplx<T> *>(mate.cs) : cs_a;
+    cplx<T> *__restrict__ grid = blockIdx.y ? static_cast<cplx<T> *>(mate.grid) : grid_a;
     static_assert(TCH % 8 == 0, "channel-group lanes need 8 | TCH");
     constexpr int CPL = TCH / 8;
     __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TCH];
@@ -806,6 +823,8 @@ struct RowDifArgs {
     int cnt;  // outputs per residue: row position of l is ((l + n_out/2) mod P) cnt + (l + n_out/2) / P;
               // 0 = natural order (position l + n_out/2)
     int64_t nrows, rpp, rpp_valid, in_plane, in_row, in_elem, out_pitch;  // rows k >= rpp_valid of a plane are padding
+    const void *in1;  // gang launch (grid.y = 2): input / output of the second, identically shaped problem
+    void *out1;
 };
 
 template <typename T>
@@ -984,6 +1003,7 @@ struct FusedArgs {
     const unsigned char *recs;    // records, rec bytes each
     int rec, ngx, tpol, w;
     void *out;                    // cplx<T> *, base of this (time, frequency-group) block
+    void *out1;                   // the same for the second problem of a gang launch
     int64_t pol_off[4];
 };
 struct FgGeom {
@@ -1055,9 +1075,12 @@ __global__ void k_fg_build(int64_t N, int nfg, const T *__restrict__ btx, const 
 // staging the merged row in LDS, was measured slower than separate workgroups on Q = 4096, P = 2.)
 template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false>
 __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_ST_MINW12 : 4) void k_rowfft_st(
-    const cplx<T> *__restrict__ in, cplx<T> *__restrict__ out, const cplx<T> *__restrict__ tw, RowDifArgs a,
+    const cplx<T> *__restrict__ in0, cplx<T> *__restrict__ out0, const cplx<T> *__restrict__ tw, RowDifArgs a,
     FusedArgs fz) {
     static_assert(!FUSED || COL, "the fused gather rides on the column-mode last pass");
+    // gang launch: blockIdx.y = 1 runs the same transform on a second pair of buffers
+    const cplx<T> *__restrict__ in = blockIdx.y ? static_cast<const cplx<T> *>(a.in1) : in0;
+    cplx<T> *__restrict__ out = blockIdx.y ? static_cast<cplx<T> *>(a.out1) : out0;
     using PL = StPlan<LOGQ, COL>;
     constexpr int R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, TPR = PL::TPR, A = PL::A, B = PL::B;
     constexpr int THREADS = COL ? ST_THREADS_COL : ST_THREADS;
@@ -1253,7 +1276,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         const int64_t rk0 = row0 % a.rpp;                    // first column of the workgroup
         const int pol = (int)(row0 / a.rpp) % fz.tpol;       // transform = (frequency, polarisation)
         const int c = tid & 7;
-        cplx<T> *obase = reinterpret_cast<cplx<T> *>(fz.out) + fz.pol_off[pol];
+        cplx<T> *obase = reinterpret_cast<cplx<T> *>(blockIdx.y ? fz.out1 : fz.out) + fz.pol_off[pol];
         for (int e = fz_e; e < fz_s1; e += (COL ? ST_THREADS_COL : ST_THREADS) / 8) {
             if (e != fz_e) {  // beyond the prefetched first round
                 fz_item = fz.list[e];
@@ -1504,7 +1527,8 @@ class Nufft3 {
     // configuration does not qualify and the caller must use interp().
     bool prepare_fused_gather(int64_t N, const T *btx, const T *bty, const int *bl_idx, const signed char *flip,
                               const double *scale_dev, int nfg, int tpol, cplx<T> *out, int64_t out_fg_stride,
-                              int64_t out_k_stride, const int64_t *out_pol_off, int64_t targets_serial = 0);
+                              int64_t out_k_stride, const int64_t *out_pol_off, int64_t targets_serial = 0,
+                              cplx<T> *out_mate = nullptr);
     int64_t M = 0;            // sources currently binned
     int64_t geom_serial = 0;  // bumps whenever the source->cell mapping changes
 
@@ -1729,11 +1753,20 @@ class Nufft3 {
                            scale_dev, cs);
     }
 
-    void spread(int ntrans, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+    // mate: a second plan with the same geometry, source capacity and transform count (another time
+    // step of the same array); spread / fft then run both in one launch each (grid.y = 2)
+    void spread(int ntrans, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, Nufft3 *mate = nullptr);
     template <int TCH>
-    int launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e1);
+    int launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e1, Nufft3 *mate);
     void buffer_cells(int64_t &c0, int64_t &c1) const;
-    void fft(int ntrans);
+    void fft(int ntrans, Nufft3 *mate = nullptr);
+    bool gang_compatible(const Nufft3 &o) const {
+        bool ok = dim == 2 && o.dim == 2 && M == o.M && ker.w == o.ker.w;
+        for (int d = 0; d < 2 && ok; ++d)
+            ok = geo.d[d].na == o.geo.d[d].na && geo.d[d].n2 == o.geo.d[d].n2 && geo.d[d].no == o.geo.d[d].no &&
+                 geo.d[d].h == o.geo.d[d].h && geo.d[d].xc == o.geo.d[d].xc && geo.d[d].btc == o.geo.d[d].btc;
+        return ok;
+    }
     double fft_traffic_cells() const;  // cells read + written by all FFT passes, per transform
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
     // index list / flip flags of length N, per-group scale (device, nfg doubles).
@@ -1745,14 +1778,15 @@ class Nufft3 {
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                 int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row, int64_t in_elem,
-                int64_t out_pitch = 0, int64_t rpp_valid = 0, const FusedArgs *fused = nullptr);
+                int64_t out_pitch = 0, int64_t rpp_valid = 0, const FusedArgs *fused = nullptr,
+                const cplx<T> *in1 = nullptr, cplx<T> *out1 = nullptr);
     int64_t b_pitch() const;  // row pitch of the x-pass output
     cplx<T> *grid_out = nullptr;  // where the last fft() left Ct
 };
 
 template <typename T>
 template <int TCH>
-int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e1) {
+int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e1, Nufft3 *mate) {
     const int nchunk = (ntrans - tbegin) / TCH;
     if (nchunk == 0) return tbegin;
     const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
@@ -1761,7 +1795,15 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
     hipEvent_t es = tbegin == 0 ? e0 : nullptr;
     hipEvent_t ee = tbegin + nchunk * TCH == ntrans ? e1 : nullptr;
     if (dim == 2) {
-        dim3 g((unsigned)(cdiv(geo.nbin[0], 4) * geo.nbin[1] * nchunk));
+        dim3 g((unsigned)(cdiv(geo.nbin[0], 4) * geo.nbin[1] * nchunk), mate ? 2 : 1);
+        SpreadMate sm{};
+        if (mate) {
+            sm.i0s = mate->i0s.template as<int>();
+            sm.bin_start = mate->bin_start.template as<int>();
+            sm.kw = mate->kw.p;
+            sm.cs = mate->strengths.p;
+            sm.grid = mate->buf0.p;
+        }
         // lane mapping: channel groups once a block sees a few sources (M counts the catalog before
         // the horizon cut), lane per cell on sparse grids; FFTVIS_HIP_SPREAD_CELL = 1 / 0 forces one
         const char *force_cell = std::getenv("FFTVIS_HIP_SPREAD_CELL");
@@ -1775,7 +1817,7 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
                               (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin,
                               (const T *)dec[0].as<T>(), (const T *)dec[1].as<T>(),
                               buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0], ker.w,
-                              order_ptr, nchunk);
+                              order_ptr, nchunk, sm);
     } else {
         dim3 g((unsigned)cdiv(geo.nbin[0], 4), (unsigned)geo.nbin[1], (unsigned)(z.na * nchunk));
         hipExtLaunchKernelGGL((k_spread3d<T, TCH>), g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
@@ -1828,23 +1870,28 @@ void Nufft3<T>::buffer_cells(int64_t &c0, int64_t &c1) const {
 }
 
 template <typename T>
-void Nufft3<T>::spread(int ntrans, hipEvent_t e0, hipEvent_t e1) {
+void Nufft3<T>::spread(int ntrans, hipEvent_t e0, hipEvent_t e1, Nufft3 *mate) {
     int64_t c0, c1;
     buffer_cells(c0, c1);
     buf0.reserve(sizeof(cplx<T>) * c0 * ntrans);
+    if (mate) {
+        FV_REQUIRE(gang_compatible(*mate), "gang launch needs two plans of one geometry");
+        mate->buf0.reserve(sizeof(cplx<T>) * c0 * ntrans);
+    }
     // whole chunks of 16 transforms per thread, then the binary remainder (<= 4 more launches)
-    int t = launch_spread<16>(ntrans, 0, e0, e1);
-    t = launch_spread<8>(ntrans, t, e0, e1);
-    t = launch_spread<4>(ntrans, t, e0, e1);
-    t = launch_spread<2>(ntrans, t, e0, e1);
-    launch_spread<1>(ntrans, t, e0, e1);
+    int t = launch_spread<16>(ntrans, 0, e0, e1, mate);
+    t = launch_spread<8>(ntrans, t, e0, e1, mate);
+    t = launch_spread<4>(ntrans, t, e0, e1, mate);
+    t = launch_spread<2>(ntrans, t, e0, e1, mate);
+    launch_spread<1>(ntrans, t, e0, e1, mate);
 }
 
 // rows = nplanes * rpp; element ia of row (plane, k) sits at plane*in_plane + k*in_row + ia*in_elem.
 template <typename T>
 void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                        int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row,
-                       int64_t in_elem, int64_t out_pitch, int64_t rpp_valid, const FusedArgs *fused) {
+                       int64_t in_elem, int64_t out_pitch, int64_t rpp_valid, const FusedArgs *fused,
+                       const cplx<T> *in1, cplx<T> *out1) {
     static const int plans[9][4] = {{4, 0, 0, 0}, {3, 2, 0, 0}, {3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0},
                                     {3, 3, 3, 0}, {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 4 .. 12
     FV_REQUIRE(g.logQ >= 4 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
@@ -1872,7 +1919,19 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.out_pitch = out_pitch ? out_pitch : g.nos();
     a.cnt = g.sP() > 1 ? g.cnt() : 0;
     const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
-    const dim3 jobs((unsigned)(ngroups8 * 8 * g.P));
+    if (in1 && !rowfft_uses_st(g, a.colmode != 0)) {  // no gang variant of the LDS kernel: two launches
+        rowfft(in, out, g, twd, nplanes, rpp, in_plane, in_row, in_elem, out_pitch, rpp_valid, fused);
+        FusedArgs f1{};
+        if (fused) {
+            f1 = *fused;
+            f1.out = fused->out1;
+        }
+        rowfft(in1, out1, g, twd, nplanes, rpp, in_plane, in_row, in_elem, out_pitch, rpp_valid, fused ? &f1 : nullptr);
+        return;
+    }
+    a.in1 = in1;
+    a.out1 = out1;
+    const dim3 jobs((unsigned)(ngroups8 * 8 * g.P), in1 ? 2 : 1);
     if (rowfft_uses_st(g, a.colmode != 0)) {
         const int s1 = g.Q / (g.logQ == 9 ? 8 : 16);       // stride of the first radix pass
         const int need = (int)cdiv(std::min(a.n_in, g.Q), s1);
@@ -1931,18 +1990,26 @@ double Nufft3<T>::fft_traffic_cells() const {
 }
 
 template <typename T>
-void Nufft3<T>::fft(int ntrans) {
+void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
     const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
     int64_t c0, c1;
     buffer_cells(c0, c1);
     buf1.reserve(sizeof(cplx<T>) * c1 * ntrans);
     cplx<T> *cur = buf0.as<cplx<T>>(), *oth = buf1.as<cplx<T>>();
+    cplx<T> *cur1 = nullptr, *oth1 = nullptr;
+    if (mate) {
+        FV_REQUIRE(gang_compatible(*mate), "gang launch needs two plans of one geometry");
+        mate->buf1.reserve(sizeof(cplx<T>) * c1 * ntrans);
+        cur1 = mate->buf0.template as<cplx<T>>();
+        oth1 = mate->buf1.template as<cplx<T>>();
+    }
     const int64_t zin = dim > 2 ? z.na : 1;       // planes per transform before the z-pass
     const int64_t np = (int64_t)ntrans * zin;     // (trans, z) planes
     // x-pass: A [p][na_y][na_x] -> B [p][na_y][xp]   (xp = no_x, padded to 8 for column mode)
     const int64_t xp = b_pitch();
-    rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp);
+    rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp, 0, nullptr, cur1, oth1);
     std::swap(cur, oth);
+    std::swap(cur1, oth1);
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
     if (rpw >= 4) {
@@ -1950,13 +2017,16 @@ void Nufft3<T>::fft(int ntrans) {
         // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
         // plane are skipped as rows
         rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.nos(),
-               fused_active ? &fused_args : nullptr);
+               fused_active ? &fused_args : nullptr, cur1, oth1);
         std::swap(cur, oth);
+        std::swap(cur1, oth1);
     } else {
         // long columns: explicit tile transpose B -> Bt [p][no_x][na_y], then contiguous rows
         dim3 tg((unsigned)cdiv(x.nos(), 32), (unsigned)cdiv(y.na, 32), (unsigned)np);
         hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, cur, oth, y.na, x.nos());
-        rowfft(oth, cur, y, tw[1].as<cplx<T>>(), np, x.nos(), (int64_t)x.nos() * y.na, y.na, 1);
+        if (mate) hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, cur1, oth1, y.na, x.nos());
+        rowfft(oth, cur, y, tw[1].as<cplx<T>>(), np, x.nos(), (int64_t)x.nos() * y.na, y.na, 1, 0, 0, nullptr,
+               oth1, cur1);
     }
     if (dim > 2) {
         // z-pass: C [t][na_z][nc] (nc = no_x no_y) -> D [t][nc][no_z]; adjacent (lx, ly) columns
@@ -1967,6 +2037,10 @@ void Nufft3<T>::fft(int ntrans) {
     }
     grid_out = cur;
     last_fft_fused = fused_active;
+    if (mate) {
+        mate->grid_out = cur1;
+        mate->last_fft_fused = fused_active;
+    }
     fused_active = false;
 }
 
@@ -1987,7 +2061,7 @@ template <typename T>
 bool Nufft3<T>::prepare_fused_gather(int64_t N, const T *btx, const T *bty, const int *bl_idx,
                                      const signed char *flip, const double *scale_dev, int nfg, int tpol,
                                      cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
-                                     const int64_t *out_pol_off, int64_t targets_serial) {
+                                     const int64_t *out_pol_off, int64_t targets_serial, cplx<T> *out_mate) {
     if (N == 0 || nfg == 0 || tpol > 4 || !fused_possible()) return false;
     const DimGeom &x = geo.d[0], &y = geo.d[1];
     FusedKey key;
@@ -2048,6 +2122,7 @@ bool Nufft3<T>::prepare_fused_gather(int64_t N, const T *btx, const T *bty, cons
     fused_args.tpol = tpol;
     fused_args.w = ker.w;
     fused_args.out = out;
+    fused_args.out1 = out_mate;
     for (int r = 0; r < 4; ++r) fused_args.pol_off[r] = out_pol_off ? out_pol_off[r] : 0;
     fused_active = true;
     return true;

@@ -801,7 +801,7 @@ class Sim : public SimBase {
         int binned_ti = -1;
         int64_t binned_serial = -1;
     };
-    Lane lanes[2];
+    Lane lanes[4];  // [2], [3]: second pair of the gang mode (see run())
     hipStream_t prep_stream = nullptr;  // low priority: per-time preparation of the next step
     hipEvent_t ev_start = nullptr;
     DevBuf d_out, d_mhist;
@@ -1435,10 +1435,19 @@ class Sim : public SimBase {
         // and tails.  FFTVIS_HIP_PIPE=0: the two lanes run freely on two streams instead.
         const char *ep = std::getenv("FFTVIS_HIP_PIPE");
         const bool pipe = nlanes > 1 && !(ep && std::atoi(ep) == 0);
-        for (int li = 0; li < nlanes; ++li) {
+        // Gang mode (pipelined 2-D runs): two consecutive time steps share one launch each of the
+        // spread and of every FFT pass (grid.y = 2: same geometry, their own sources and grids), which
+        // halves the kernel boundaries per time step and doubles the workgroups that hide each other's
+        // latency chains and tails.  Two pairs of lanes alternate, so that the preparation of the next
+        // pair still runs beside this pair's big kernels.  FFTVIS_HIP_GANG=0 turns it off.
+        const char *eg = std::getenv("FFTVIS_HIP_GANG");
+        const bool gang = pipe && D == 2 && nt >= 2 && timing_level < 2 && !(eg && std::atoi(eg) == 0);
+        const int nlanes_used = gang ? 4 : nlanes;
+        for (int li = 0; li < nlanes_used; ++li) {
             Lane &L = lanes[li];
             L.heavy_pending = false;
-            if (!L.nufft || L.nufft->dim != D) L.nufft.reset(new Nufft3<T>(D, eps, sigma, L.stream));
+            if (!L.nufft || L.nufft->dim != D)
+                L.nufft.reset(new Nufft3<T>(D, eps, sigma, li < 2 ? L.stream : stream));
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
             L.d_az.reserve(sizeof(T) * cap);
             L.d_za.reserve(sizeof(T) * cap);
@@ -1452,47 +1461,67 @@ class Sim : public SimBase {
             FV_HIP(hipStreamWaitEvent(lanes[1].stream, ev_start, 0));
         }
 
-        for (int ti = t0; ti < t1; ++ti) {
+        const int sample_step = std::min(TIMING_STRIDE / 2, nt - 1);  // level-1 timing: this step of every 16
+        for (int ti = t0, unit = 0; ti < t1; ++unit) {
+            const int nm = gang && ti + 1 < t1 ? 2 : 1;  // time steps in this unit
+            const int tu = ti;
+            ti += nm;
             if (nsrc == 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
-            Lane &L = lanes[(ti - t0) % nlanes];
-            const hipStream_t ls = pipe ? stream : L.stream;        // big kernels
-            const hipStream_t ps = pipe ? prep_stream : L.stream;   // per-time preparation
-            Nufft3<T> *nufft = L.nufft.get();
+            Lane *Ls[2];
+            if (gang) {
+                Ls[0] = &lanes[(unit % 2) * 2];
+                Ls[1] = &lanes[(unit % 2) * 2 + 1];
+            } else {
+                Ls[0] = Ls[1] = &lanes[(tu - t0) % nlanes];
+            }
+            Lane &L0 = *Ls[0];
+            const hipStream_t ls = pipe ? stream : L0.stream;        // big kernels
+            const hipStream_t ps = pipe ? prep_stream : L0.stream;   // per-time preparation
+            Nufft3<T> *mate = nm == 2 ? Ls[1]->nufft.get() : nullptr;
+            bool sampled = false;
+            for (int m = 0; m < nm; ++m) sampled = sampled || (tu + m - t0) % TIMING_STRIDE == sample_step;
             // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
-            if (pipe && L.heavy_pending) FV_HIP(hipStreamWaitEvent(ps, L.heavy_done, 0));  // lane scratch is free
-            nufft->stream = ps;
+            if (pipe && L0.heavy_pending) FV_HIP(hipStreamWaitEvent(ps, L0.heavy_done, 0));  // lane scratch is free
             const Pair *first_pair = nullptr;
             bool strengths_ahead = false;
-            size_t e0 = ev_begin(TM_PREP, ps);
-            const int *Mp = horizon_step(L, ti, cap, nblk, ps);
             const int64_t M = cap;  // capacity: array stride and launch bound
-            if (pipe) {  // the first (group, pair)'s bin sort belongs to the preparation as well
-                for (const Pair &pr : pairs) {
-                    if (pr.n == 0 || groups.empty()) continue;
-                    double smax0 = 0;
-                    for (int f = groups[0].first; f < groups[0].second; ++f)
-                        smax0 = std::max(smax0, std::fabs(freqs[f]));
-                    nufft->set_geometry(xc, X, pr.btc, pr.B, smax0);
-                    nufft->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
-                                       D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mp);
-                    L.binned_ti = ti;
-                    L.binned_serial = nufft->geom_serial;
-                    // ... and so do its strengths (beam x coherency, pre-phase): they depend on this
-                    // step's sources only, not on the previous step's big kernels
-                    launch_strengths(L, pr, groups[0].first, groups[0].second - groups[0].first, M, Mp, ps);
-                    first_pair = &pr;
-                    strengths_ahead = true;
-                    break;
+            const int *Mps[2] = {nullptr, nullptr};
+            size_t hist_slot[2] = {0, 0};
+            size_t e0 = ev_begin(TM_PREP, ps);
+            for (int m = 0; m < nm; ++m) {
+                Lane &L = *Ls[m];
+                Nufft3<T> *nufft = L.nufft.get();
+                nufft->stream = ps;
+                Mps[m] = horizon_step(L, tu + m, cap, nblk, ps);
+                if (pipe) {  // the first (group, pair)'s bin sort belongs to the preparation as well
+                    for (const Pair &pr : pairs) {
+                        if (pr.n == 0 || groups.empty()) continue;
+                        double smax0 = 0;
+                        for (int f = groups[0].first; f < groups[0].second; ++f)
+                            smax0 = std::max(smax0, std::fabs(freqs[f]));
+                        nufft->set_geometry(xc, X, pr.btc, pr.B, smax0);
+                        nufft->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
+                                           D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mps[m]);
+                        L.binned_ti = tu + m;
+                        L.binned_serial = nufft->geom_serial;
+                        // ... and so do its strengths (beam x coherency, pre-phase): they depend on this
+                        // step's sources only, not on the previous step's big kernels
+                        launch_strengths(L, pr, groups[0].first, groups[0].second - groups[0].first, M, Mps[m], ps);
+                        first_pair = &pr;
+                        strengths_ahead = true;
+                        break;
+                    }
                 }
+                hist_slot[m] = mhist_log.size();
+                mhist_log.push_back({tu + m, 0.0});
             }
             ev_end(e0, ps);
             if (pipe) {
-                FV_HIP(hipEventRecord(L.prep_done, ps));
-                FV_HIP(hipStreamWaitEvent(ls, L.prep_done, 0));
+                FV_HIP(hipEventRecord(L0.prep_done, ps));
+                FV_HIP(hipStreamWaitEvent(ls, L0.prep_done, 0));
             }
-            nufft->stream = ls;
-            size_t hist_slot = mhist_log.size();
-            mhist_log.push_back({ti, 0.0});
+            for (int m = 0; m < nm; ++m) Ls[m]->nufft->stream = ls;
+            Nufft3<T> *nufft = L0.nufft.get();
 
             for (const auto &grp : groups) {
                 const int fa = grp.first, fb = grp.second, nfg = fb - fa;
@@ -1501,31 +1530,35 @@ class Sim : public SimBase {
                 for (int f = fa; f < fb; ++f) smax = std::max(smax, std::fabs(freqs[f]));
                 for (const Pair &pr : pairs) {
                     if (pr.n == 0) continue;
-                    // ---- geometry + bin sort (skipped when unchanged since last set) -------
-                    size_t e1 = ev_begin(TM_PREP, ls);
-                    nufft->set_geometry(xc, X, pr.btc, pr.B, smax);
-                    if (L.binned_ti != ti || L.binned_serial != nufft->geom_serial || nufft->M != M) {
-                        nufft->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
-                                           D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mp);
-                        L.binned_ti = ti;
-                        L.binned_serial = nufft->geom_serial;
+                    for (int m = 0; m < nm; ++m) {
+                        Lane &L = *Ls[m];
+                        Nufft3<T> *nf_ = L.nufft.get();
+                        // ---- geometry + bin sort (skipped when unchanged since last set) -------
+                        size_t e1 = ev_begin(TM_PREP, ls);
+                        nf_->set_geometry(xc, X, pr.btc, pr.B, smax);
+                        if (L.binned_ti != tu + m || L.binned_serial != nf_->geom_serial || nf_->M != M) {
+                            nf_->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
+                                             D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mps[m]);
+                            L.binned_ti = tu + m;
+                            L.binned_serial = nf_->geom_serial;
+                        }
+                        ev_end(e1, ls);
+                        // ---- strengths (already queued with the preparation for the first pair) -------
+                        if (!(strengths_ahead && &grp == &groups.front() && &pr == first_pair))
+                            launch_strengths(L, pr, fa, nfg, M, Mps[m], ls);
                     }
-                    ev_end(e1, ls);
-                    // ---- strengths (already queued with the preparation for the first pair) -------
-                    if (!(strengths_ahead && &grp == &groups.front() && &pr == first_pair))
-                        launch_strengths(L, pr, fa, nfg, M, Mp, ls);
                     // ---- NUFFT ----------------------------------------------------------
-                    if (timing_level >= 2 || (timing_level == 1 && (ti - t0) % TIMING_STRIDE == std::min(TIMING_STRIDE / 2, nt - 1))) {
+                    if (timing_level >= 2 || (timing_level == 1 && sampled)) {
                         const size_t e3 = ev_slot(TM_SPREAD);
-                        nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b);
+                        nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b, mate);
                         spread_timed += 1;
                     } else {
-                        nufft->spread(ntrans);
+                        nufft->spread(ntrans, nullptr, nullptr, mate);
                     }
                     st[0] += 1;
-                    st[1] += (double)nufft->geo.cells_a() * ntrans;
-                    mhist_log[hist_slot].second += ntrans;
-                    cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
+                    st[1] += (double)nufft->geo.cells_a() * ntrans * nm;
+                    for (int m = 0; m < nm; ++m) mhist_log[hist_slot[m]].second += ntrans;
+                    cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (tu - t0)) * per_tf;
                     // small 2-D grids: the last FFT pass serves the targets from its LDS tiles (no C
                     // buffer, no gather kernel); the output block was zeroed at the start of the run
                     const bool fused =
@@ -1534,23 +1567,25 @@ class Sim : public SimBase {
                                                     pr.trivial ? nullptr : pr.idx->template as<int>(),
                                                     pr.trivial ? nullptr : pr.flip->template as<signed char>(),
                                                     d_freqs.as<double>() + fa, nfg, tpol, obase,
-                                                    (int64_t)nt * per_tf, 1, pol_off, targets_serial);
+                                                    (int64_t)nt * per_tf, 1, pol_off, targets_serial,
+                                                    mate ? obase + per_tf : nullptr);
                     size_t e4 = ev_begin(TM_FFT, ls);
-                    nufft->fft(ntrans);
+                    nufft->fft(ntrans, mate);
                     ev_end(e4, ls);
-                    st[3] += nufft->fft_traffic_cells() * ntrans;
+                    st[3] += nufft->fft_traffic_cells() * ntrans * nm;
                     size_t e5 = ev_begin(TM_INTERP, ls);
                     BasisTerm bt{d_coefs.p, d_ant1.as<int>(), d_ant2.as<int>(), pr.bi, pr.bj, nbasis,
                                  (int)freqs.size(), fa};
                     if (!fused)
-                        nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
+                        for (int m = 0; m < nm; ++m)
+                            Ls[m]->nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
                                   D > 2 ? d_bls.as<T>() + 2 * nbls : nullptr,
                                   pr.trivial ? nullptr : pr.idx->template as<int>(),
                                   pr.trivial ? nullptr : pr.flip->template as<signed char>(),
-                                  d_freqs.as<double>() + fa, nfg, tpol, obase,
+                                  d_freqs.as<double>() + fa, nfg, tpol, obase + (int64_t)m * per_tf,
                                   (int64_t)nt * per_tf, 1, pol_off, false, nbasis ? &bt : nullptr);
                     ev_end(e5, ls);
-                    st[4] += (double)pr.n * ntrans;
+                    st[4] += (double)pr.n * ntrans * nm;
                     st[6] = nufft->geo.d[0].n2;
                     st[7] = nufft->geo.d[1].n2;
                     st[8] = nufft->geo.d[0].na * 65536.0 + nufft->geo.d[1].na;
@@ -1558,8 +1593,8 @@ class Sim : public SimBase {
                 }
             }
             if (pipe) {
-                FV_HIP(hipEventRecord(L.heavy_done, ls));
-                L.heavy_pending = true;
+                FV_HIP(hipEventRecord(L0.heavy_done, ls));
+                L0.heavy_pending = true;
             }
         }
         if (nlanes > 1 && !pipe) {  // join: everything queued on the main stream afterwards sees both lanes

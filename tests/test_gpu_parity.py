@@ -543,6 +543,38 @@ def test_sim_c2_geometry_polarized_pairs_fused_gather(gpu):
     assert g32.dtype == np.complex64 and rel_l2(g32, got) < 5e-3
 
 
+def test_sim_gang_launches_match_single_steps(gpu, monkeypatch):
+    """Pipelined 2-D runs put two consecutive time steps into one launch of the spread and of every
+    FFT pass (gang mode).  With an odd number of times (a single-step tail), several frequency groups
+    (a small grid budget), three beam pairs with flips, a polarized sky, fp32, and the eigenbeam path
+    (whose gather is not fused), the result must equal the one-step-per-launch result up to the order
+    of the gather's atomic additions -- and the oracle."""
+    cfg = synth.make_config("C2", nsrc=1500, nfreq=6, ntimes=5)
+    freqs = cfg["freqs"]
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=91, naz=180), freqs)
+    tab2 = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, diameter=12.0, nza=91, naz=180), freqs)
+    _, _, fl4 = synth.catalog(1500, freqs, 0, polarized_sky=True)
+    rng = np.random.default_rng(6)
+    bidx = rng.integers(0, 2, len(cfg["ants"]))
+    bls = [cfg["baselines"][i] for i in sorted(rng.choice(666, 50, replace=False))]
+    bls += [(b, a) for (a, b) in bls[:8]] + [(5, 5)]
+    pol = dict(cfg, polarized=True, beam=[tab, tab2], beam_idx=bidx, fluxes=fl4, baselines=bls, eps=1e-9)
+    coefs = rng.normal(size=(len(cfg["ants"]), 2, len(freqs))) + 1j * rng.normal(size=(len(cfg["ants"]), 2, len(freqs)))
+    cases = {"unpolarized": dict(cfg, eps=1e-9), "pairs": pol,
+             "basis": dict(cfg, polarized=True, beam=[tab, tab2], beam_coefs=coefs, baselines=bls, eps=1e-9),
+             "fp32": dict(pol, precision=1, eps=1e-4)}
+    monkeypatch.setenv("FFTVIS_HIP_GRID_BYTES", str(48 * 1024 * 1024))  # a few channels per launch
+    for name, c in cases.items():
+        monkeypatch.setenv("FFTVIS_HIP_GANG", "1")
+        ganged = fftvis_amd.simulate_vis(**c)
+        monkeypatch.setenv("FFTVIS_HIP_GANG", "0")
+        single = fftvis_amd.simulate_vis(**c)
+        tol = 1e-5 if name == "fp32" else 1e-13
+        assert rel_l2(ganged, single) < tol, name
+        if name != "fp32":
+            assert rel_l2(ganged, oracle_simulate(c)) < 1e-8, name
+
+
 def test_sim_handle_reconfigured_between_runs(gpu):
     """A long-lived engine handle keeps per-geometry tables between runs (bin order, twiddles, the
     fused gather's per-target records): changing the frequencies, then the baselines, on the same
