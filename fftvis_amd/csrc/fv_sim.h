@@ -802,6 +802,8 @@ class Sim : public SimBase {
         int64_t binned_serial = -1;
     };
     Lane lanes[4];  // [2], [3]: second pair of the gang mode (see run())
+    int lane_mode = -1;       // 0 one stream per lane, 1 pipelined, 2 pipelined gangs: what the lanes last ran as
+    int64_t lane_serial = 0;  // units processed in that mode (lane rotation continues across runs)
     hipStream_t prep_stream = nullptr;  // low priority: per-time preparation of the next step
     hipEvent_t ev_start = nullptr;
     DevBuf d_out, d_mhist;
@@ -1186,6 +1188,7 @@ class Sim : public SimBase {
         }
         t1_cs.reserve(sizeof(cplx<T>) * ecap * tpol);
         bool set_pending[2] = {false, false}, lane_pending[2] = {false, false};
+        lane_mode = -1;  // a type-3 run after this one drains the streams before it reuses the lanes
         if (pipe) {  // the sort may start once the set-up queued on the main stream is done
             FV_HIP(hipEventRecord(ev_start, stream));
             FV_HIP(hipStreamWaitEvent(ps, ev_start, 0));
@@ -1443,9 +1446,22 @@ class Sim : public SimBase {
         const char *eg = std::getenv("FFTVIS_HIP_GANG");
         const bool gang = pipe && D == 2 && nt >= 2 && timing_level < 2 && !(eg && std::atoi(eg) == 0);
         const int nlanes_used = gang ? 4 : nlanes;
+        // Lane scratch outlives a run: with a device-side output buffer nothing synchronises between
+        // two fv_sim_run calls, so the "last big kernels of this lane" events carry over (the next
+        // run's first preparation waits for them) and the lane rotation continues where the previous
+        // run stopped -- its first unit then takes the lanes that have been idle longest and prepares
+        // beside the previous run's last big kernels.  A change of mode drains the streams instead.
+        const int mode = gang ? 2 : pipe ? 1 : 0;
+        if (mode != lane_mode) {
+            FV_HIP(hipStreamSynchronize(stream));
+            FV_HIP(hipStreamSynchronize(prep_stream));
+            if (lanes[1].stream) FV_HIP(hipStreamSynchronize(lanes[1].stream));
+            for (Lane &L : lanes) L.heavy_pending = false;
+            lane_mode = mode;
+            lane_serial = 0;
+        }
         for (int li = 0; li < nlanes_used; ++li) {
             Lane &L = lanes[li];
-            L.heavy_pending = false;
             if (!L.nufft || L.nufft->dim != D)
                 L.nufft.reset(new Nufft3<T>(D, eps, sigma, li < 2 ? L.stream : stream));
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
@@ -1462,17 +1478,18 @@ class Sim : public SimBase {
         }
 
         const int sample_step = std::min(TIMING_STRIDE / 2, nt - 1);  // level-1 timing: this step of every 16
-        for (int ti = t0, unit = 0; ti < t1; ++unit) {
+        for (int ti = t0; ti < t1;) {
             const int nm = gang && ti + 1 < t1 ? 2 : 1;  // time steps in this unit
             const int tu = ti;
             ti += nm;
             if (nsrc == 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
+            const int64_t unit = lane_serial++;
             Lane *Ls[2];
             if (gang) {
                 Ls[0] = &lanes[(unit % 2) * 2];
                 Ls[1] = &lanes[(unit % 2) * 2 + 1];
             } else {
-                Ls[0] = Ls[1] = &lanes[(tu - t0) % nlanes];
+                Ls[0] = Ls[1] = &lanes[unit % nlanes];
             }
             Lane &L0 = *Ls[0];
             const hipStream_t ls = pipe ? stream : L0.stream;        // big kernels
