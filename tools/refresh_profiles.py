@@ -37,6 +37,15 @@ for tag in ("c2", "c3"):
             out["counters"][tag][k] = {"FETCH_SIZE_KB_avg_per_launch": F[k][0] / F[k][1], "launches": F[k][1],
                                        "WRITE_SIZE_KB_avg_per_launch": W[k][0] / W[k][1]}
 json.dump(out, open(path, "w"), indent=1)
+# the C2 bench line was taken before the PMC passes of the same collection: fill its traffic field from them
+p2 = f"profiles/{tagr}_c2_bench.json"
+if os.path.exists(p2) and "c2" in out["counters"]:
+    d = json.load(open(p2))
+    k = out["counters"]["c2"].get(d["roofline"]["kernel"])
+    if k and d["roofline"].get("traffic") is None:
+        d["roofline"]["traffic"] = (2 * k["FETCH_SIZE_KB_avg_per_launch"] + k["WRITE_SIZE_KB_avg_per_launch"]) * 1024
+        d["roofline"]["traffic_source"] = path + " (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE; filled in by tools/refresh_profiles.py)"
+        json.dump(d, open(p2, "w"))
 for dst in names.values():
     p = f"profiles/{tagr}_{dst}.json"
     if os.path.exists(p):
