@@ -1127,50 +1127,77 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     }
 
     // ---- pass 1: load (+ twiddle / fold for the residue), radix R1, twiddle ---------------------
+    // The transform is centred on input element hshift = n_in / 2: element ia enters at the cyclic
+    // position s = ia - hshift (mod n2), i.e. the first hshift elements wrap to the END of the row.
+    // exp(2 pi i (ia - hshift) l / n2) is then the plain DFT kernel of the shifted row and no output
+    // needs a phase factor (an earlier version multiplied every output by w^{-hshift l}: a complex
+    // multiply plus a step of the phase chain per output).  Slot q of the length-Q row holds the
+    // elements with s = q (mod Q): one of them when n_in <= Q, else the extras are folded on top.
     cplx<T> va[R1];
+    const int hshift = a.n_in / 2;
     {
         // branch-free loads (clamped index, masked afterwards) so that a chunk's requests issue
         // back to back; chunks of 8 bound the registers held by data + residue twiddles in flight
         const cplx<T> *rin = in + (ok ? rplane * a.in_plane + rk * a.in_row : 0);
         const int qmax = a.n_in - 1;
+        const int nlo = a.n_in - hshift;  // elements with s >= 0
         constexpr int CH = NLD < 8 ? NLD : 8;
+        constexpr int NH = NLD / 2;  // NLD < R1: only the first and the last NH registers can be non-zero
 #pragma unroll
         for (int h = 0; h < NLD; h += CH) {
             cplx<T> x[CH];
+            bool live[CH];
+            int widx[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                const int qq = min(u + (h + j) * S1, qmax);
-                x[j] = rin[COL ? (int64_t)qq * a.in_elem : (int64_t)qq];
+                const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
+                const int q = u + jr * S1;
+                // slot q: the element with s = q if there is one, else the wrapped one with s = q - Q
+                const bool hi = NLD == R1 ? q >= nlo : h + j >= NH;
+                const int ia = (hi ? q - Q : q) + hshift;
+                live[j] = ok && ia >= 0 && ia <= qmax;
+                widx[j] = hi ? n2 - (Q - q) * p : q * p;  // (s p) mod n2; (Q - q) p < Q P = n2
+                const int iac = min(max(ia, 0), qmax);
+                x[j] = rin[COL ? (int64_t)iac * a.in_elem : (int64_t)iac];
             }
             if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
                 cplx<T> w[CH];
 #pragma unroll
-                for (int j = 0; j < CH; ++j) w[j] = tw[min(u + (h + j) * S1, qmax) * p];  // q p < Q P = n2
+                for (int j = 0; j < CH; ++j) w[j] = tw[live[j] ? widx[j] : 0];
 #pragma unroll
                 for (int j = 0; j < CH; ++j) x[j] = cmul(x[j], w[j]);
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                const bool live = ok && u + (h + j) * S1 <= qmax;
-                va[h + j] = {live ? x[j].re : T(0), live ? x[j].im : T(0)};
+                const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
+                va[jr] = {live[j] ? x[j].re : T(0), live[j] ? x[j].im : T(0)};
             }
             if (h + CH < NLD) __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (NLD < R1) {
 #pragma unroll
-        for (int n1 = NLD; n1 < R1; ++n1) va[n1] = {T(0), T(0)};
-        if (NLD == R1 && a.n_in > Q && ok) {  // fold: x[q + k Q] w^{(q + k Q) p}
-            for (int ia = u + Q; ia < a.n_in; ia += TPR) {  // the few elements beyond Q: n1 = 0 slots first
-                // element ia folds onto q = ia mod Q, held by thread q mod S1 in register q / S1
-                const int q = ia & (Q - 1);
-                const int kq = ia >> LOGQ;
-                int ti = (int)(((int64_t)q * p + (int64_t)Q * ((kq * p) % a.P)) % n2);
-                const cplx<T> xv = cmul(rin[COL ? (int64_t)ia * a.in_elem : (int64_t)ia], tw[ti]);
-                // q mod S1 == u because ia = u + Q + m TPR and TPR == S1 divides Q
-                const int n1 = q / S1;
+            for (int n1 = NH; n1 < R1 - NH; ++n1) va[n1] = {T(0), T(0)};
+        }
+        if (NLD == R1 && a.n_in > Q && ok) {
+            // fold: the elements the slots above did not take, as ranges of s (thread u owns the slots
+            // q = u mod S1, and S1 divides Q, so it walks each range in steps of S1)
+            auto fold = [&](int s_lo, int s_hi) {
+                if (s_lo >= s_hi) return;
+                for (int sv = s_lo + (((u - s_lo) % S1) + S1) % S1; sv < s_hi; sv += S1) {
+                    const int ia = sv + hshift;
+                    const int q = sv & (Q - 1);
+                    int64_t e = ((int64_t)sv * p) % n2;
+                    if (e < 0) e += n2;
+                    const cplx<T> xv = cmul(rin[COL ? (int64_t)ia * a.in_elem : (int64_t)ia], tw[e]);
+                    const int n1 = q / S1;
 #pragma unroll
-                for (int j = 0; j < R1; ++j)
-                    if (j == n1) va[j] = {va[j].re + xv.re, va[j].im + xv.im};
-            }
+                    for (int j = 0; j < R1; ++j)
+                        if (j == n1) va[j] = {va[j].re + xv.re, va[j].im + xv.im};
+                }
+            };
+            fold(max(-hshift, -Q), min(0, nlo - Q));  // wrapped elements whose slot a direct one took
+            fold(Q, nlo);                              // direct elements beyond one period
+            fold(-hshift, -Q);                         // wrapped elements beyond one period
         }
     }
     dif_regs<T, R1>(va);
@@ -1239,10 +1266,6 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     // ---- pass 3 and this residue's outputs: k' = v + k3 Q/R3, l = P k' + p (mod n2, signed) ------
     if (!FUSED && !ok) return;
     const int half_n = a.n_out / 2;
-    const int hshift = a.n_in / 2;
-    int si = (int)((-(int64_t)hshift * a.P * (Q / R3)) % n2);
-    if (si < 0) si += n2;
-    const cplx<T> step = tw[si];
     // residue-major storage: l = P ks + p sits at ((p + half_n) mod P) cnt + (p + half_n) / P + ks
     // (natural order when cnt == 0: position l + half_n = base + P ks)
     cplx<T> *rout = out + (rplane * a.rpp_valid + rk) * a.out_pitch;
@@ -1257,16 +1280,12 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     for (int i = 0; i < NI3; ++i) {
         const int v = u + i * TPR;
         dif_regs<T, R3>(vc[i]);
-        // (-hshift (P v + p)) mod n2 in 32 bits: hshift <= n2 / 2, P v + p < n2 <= 2^16
-        const unsigned tm = ((unsigned)hshift * (unsigned)(a.P * v + p)) % (unsigned)n2;
-        cplx<T> t = tw[tm ? n2 - (int)tm : 0];
 #pragma unroll
         for (int k = 0; k < R3; ++k) {
             const int kk = v + k * (Q / R3);
             const int ks = kk < Q / 2 ? kk : kk - Q;
             const int l = a.P * ks + p;
-            if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = cmul(vc[i][bitrev_small(k, L3)], t);
-            if (k + 1 < R3) t = cmul(t, step);
+            if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
         }
     }
     if constexpr (FUSED) {
@@ -1934,8 +1953,10 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     const dim3 jobs((unsigned)(ngroups8 * 8 * g.P), in1 ? 2 : 1);
     if (rowfft_uses_st(g, a.colmode != 0)) {
         const int s1 = g.Q / (g.logQ == 9 ? 8 : 16);       // stride of the first radix pass
-        const int need = (int)cdiv(std::min(a.n_in, g.Q), s1);
-        const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;  // possibly non-zero inputs per thread
+        // possibly non-zero inputs per thread: the row is centred (see the kernel), so the elements sit in
+        // the first ceil(n_in / 2) and the last n_in / 2 slots -- NLD / 2 registers at either end
+        const int need = a.n_in > g.Q ? 16 : 2 * (int)cdiv(a.n_in - a.n_in / 2, s1);
+        const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;
         const bool col = a.colmode != 0;
 #define FV_ST_GO(LQ, COLM, NLD)                                                                        \
     if (COLM && fused)                                                                                 \
