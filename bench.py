@@ -45,7 +45,8 @@ def parse():
     p.add_argument("--nfreq", type=int, default=None)
     p.add_argument("--ntimes", type=int, default=None)
     p.add_argument("--eps", type=float, default=None, help="default: the workload's (6e-8; C5: 1e-4)")
-    p.add_argument("--upsample", type=float, default=2.0)
+    p.add_argument("--upsample", type=float, default=2.0,
+                   help="2 (the reference's default upsample_factor), 1.25, or 0 = the engine picks per run")
     p.add_argument("--path", default="type3", choices=["type3", "type1"],
                    help="type3 = the benchmarked NUFFT path (BASELINE.json); type1 = the lattice path "
                         "the reference takes by default on these arrays (reported for comparison)")
@@ -345,7 +346,8 @@ def main():
                 "workload": f"{a.workload}: {synth.CONFIGS[a.workload][0]}, {nsrc} sources, "
                             f"{nfreq} freqs, {ntimes} times/GPU, {nbls} baselines, "
                             f"{('%d basis beams (eigenbeam path), polarized' % len(blist)) if 'beam_coefs' in cfg else 'polarized table beam' if pol else 'unpolarized Airy beam'}, "
-                            f"{a.path} NUFFT eps={a.eps:g} upsampfac={a.upsample:g}",
+                            f"{a.path} NUFFT eps={a.eps:g} upsampfac={st.get('upsample_used', a.upsample):g}"
+                            + (" (chosen by the engine)" if a.upsample == 0 else ""),
                 "slices_per_step": nfreq * ntimes,
                 "lanes": a.lanes if a.lanes is not None else "engine default (2 pipelined lanes for small grids)",
                 "pipe": a.pipe if a.pipe is not None else 1,

@@ -304,7 +304,7 @@ int fv_sim_create(fv_sim **h, int device, int precision, double eps, double upsa
         FV_REQUIRE(h, "null handle pointer");
         *h = nullptr;
         FV_REQUIRE(precision == 1 || precision == 2, "precision must be 1 or 2");
-        FV_REQUIRE(upsampfac == 2.0 || upsampfac == 1.25, "upsample factor must be 2 or 1.25");
+        FV_REQUIRE(upsampfac == 2.0 || upsampfac == 1.25 || upsampfac == 0.0, "upsample factor must be 2, 1.25 or 0 (auto)");
         FV_REQUIRE(eps > 0 && eps < 1, "eps must be in (0, 1)");
         std::unique_ptr<fv_sim> s(new fv_sim());
         s->precision = precision;

@@ -740,7 +740,8 @@ template <typename T>
 class Sim : public SimBase {
     int device;
     hipStream_t stream = nullptr;
-    double eps, sigma;
+    double eps, sigma;       // sigma: the caller's upsampling factor, 0 = chosen per run (see run())
+    double sigma_run = 2.0;  // the factor the last run used
     bool polarized;
     int tpol;
 
@@ -810,7 +811,7 @@ class Sim : public SimBase {
     std::vector<std::pair<int, double>> mhist_log;  // (time index, transforms spread) per processed time
 
     // stats / timing
-    double st[10] = {0};
+    double st[11] = {0};
     int timing_level = 0;  // 1: spread only (events ride on the dispatches), 2: every kernel family
     int64_t targets_serial = 1;  // version of the device-side target data (baselines, frequencies, pair lists)
     struct Ev {
@@ -1137,6 +1138,8 @@ class Sim : public SimBase {
             dout = d_out.as<cplx<T>>();
         }
         FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
+        const double sigma = this->sigma == 0.0 ? 2.0 : this->sigma;  // "auto" is a type-3 matter
+        sigma_run = sigma;
         if (!t1fft) t1fft.reset(new Nufft3<T>(2, eps, sigma, stream));
         const KerParams &ker = t1fft->ker;
         // grid: n2 = P Q >= sigma n_modes (and >= 2 w), all n2 inputs live, n_modes + 1 outputs kept
@@ -1401,6 +1404,34 @@ class Sim : public SimBase {
         const int64_t cap = std::max<int64_t>(nsrc, 1);
         const int nblk = (int)cdiv(cap, 256);
 
+        // Upsampling factor "auto" (fv_sim_create upsampfac = 0): sigma = 1.25 shrinks the fine grid and
+        // all FFT work by (2 / 1.25)^D at the price of a kernel 13-14 cells wide instead of 9 (every
+        // source and target costs ~2x in 2-D), with NUFFT errors at or below sigma = 2's down to
+        // eps ~ 1e-8 (fv_eskernel.h).  It pays when the grid dwarfs the point counts: C3 (8192^2 cells,
+        // 1.1e5 points per transform) 3.06 -> 1.57 s per step, C2 (1024 x 512, 5.7e3) 1.38 -> 1.58 ms.
+        double sigma = this->sigma;
+        if (sigma == 0.0) {
+            const KerParams k2 = make_kernel(eps, 2.0);
+            double fmax = 0, cells2 = 1.0;
+            for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
+            int64_t nmax = 0;
+            for (const Pair &p : pairs) nmax = std::max<int64_t>(nmax, p.n);
+            for (int d = 0; d < D; ++d) {
+                DimGeom g;
+                g.X = X[d];
+                double Bm = 0;
+                for (const Pair &p : pairs) Bm = std::max(Bm, p.B[d]);
+                g.B = Bm;
+                set_dim_geom(g, 2.0, k2.w, fmax);
+                cells2 *= g.n2;
+            }
+            const double points = 0.5 * (double)nsrc + (double)nmax;
+            // fp64 only: at sigma = 1.25 the kernel transform falls by ~e^{-w/2} per dimension across the
+            // band and fp32 rounding, amplified by that factor at band-edge targets, can exceed eps
+            sigma = sizeof(T) == 8 && eps >= 1e-8 && cells2 >= (D == 2 ? 300.0 : 2000.0) * points ? 1.25 : 2.0;
+        }
+        sigma_run = sigma;
+        st[10] = sigma;
         // grid-buffer cells per transform at the top frequency, for the grouping heuristic
         double cells_top = 1.0;
         {
@@ -1462,7 +1493,7 @@ class Sim : public SimBase {
         }
         for (int li = 0; li < nlanes_used; ++li) {
             Lane &L = lanes[li];
-            if (!L.nufft || L.nufft->dim != D)
+            if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma)
                 L.nufft.reset(new Nufft3<T>(D, eps, sigma, li < 2 ? L.stream : stream));
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
             L.d_az.reserve(sizeof(T) * cap);
@@ -1688,7 +1719,7 @@ class Sim : public SimBase {
             }
             mhist_log.clear();
         }
-        for (int i = 0; i < n && i < 10; ++i) v[i] = st[i];
+        for (int i = 0; i < n && i < 11; ++i) v[i] = st[i];
     }
     void reset_stats() override {
         for (double &x : st) x = 0;

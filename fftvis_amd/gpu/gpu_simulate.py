@@ -38,6 +38,8 @@ class SimHandle:
         self.rdt = np.float32 if precision == 1 else np.float64
         self.cdt = np.complex64 if precision == 1 else np.complex128
         self._h = ctypes.c_void_p()
+        if upsample_factor in (None, "auto"):
+            upsample_factor = 0.0  # the engine picks 2 or 1.25 per run (include/fftvis_hip.h, fv_sim_create)
         _lib.check(self._L.fv_sim_create(ctypes.byref(self._h), device, precision, float(eps),
                                          float(upsample_factor), int(polarized)))
         self.nbls = 0
@@ -141,10 +143,10 @@ class SimHandle:
         _lib.check(self._L.fv_sim_sync(self._h))
 
     def stats(self):
-        v = np.zeros(10)
-        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 10))
+        v = np.zeros(11)
+        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 11))
         keys = ["spread_launches", "spread_cells", "source_visits", "fft_cells", "interp_items",
-                "sources_above_horizon", "n2x", "n2y", "n2z", "w"]
+                "sources_above_horizon", "n2x", "n2y", "n2z", "w", "upsample_used"]
         return dict(zip(keys, v))
 
     def reset_stats(self):
@@ -232,6 +234,9 @@ class GPUSimulationEngine(SimulationEngine):
           (exact for real-valued basis beams, reference cpu_simulate.py:464-468);
         * ``beam_spline_opts``: order 1 (bilinear, also when None) or 3 (cubic B-spline; ``kx/ky``
           of ``az_za_simple`` are read the same way); other orders raise NotImplementedError;
+        * ``upsample_factor``: 2 (default, as the reference) or 1.25 are used as given; ``None`` /
+          ``"auto"`` (extra) lets the engine pick per run -- 1.25 when eps >= 1e-8 and the fine grid
+          dwarfs the source and baseline counts (HERA-350 class arrays: ~2x faster), else 2;
         * ``time_idx`` / ``freq_idx`` (extra) restrict the run to a block, which is how ranks
           shard a simulation across GPUs.
         """

@@ -79,7 +79,10 @@ int fv_inplace_rot(int device, int precision, const double *rot, void *b, int64_
 typedef struct fv_sim fv_sim;
 
 /* precision 1|2; eps: NUFFT accuracy (core/simulate.py:16-19 defaults are the caller's job);
- * upsampfac 2.0|1.25; polarized: nfeeds = 2 (cpu_simulate.py:589). */
+ * upsampfac 2.0|1.25 (cpu/nufft.py:19 "upsample_factor", handed to finufft as is), or 0 = let every
+ * fv_sim_run pick: 1.25 when precision = 2, eps >= 1e-8 and the fine grid at sigma = 2 holds >= 300 cells per source
+ * and target (2000 in 3-D), else 2 -- the accuracy contract is eps either way;
+ * polarized: nfeeds = 2 (cpu_simulate.py:589). */
 int fv_sim_create(fv_sim **h, int device, int precision, double eps, double upsampfac,
                   int polarized);
 int fv_sim_destroy(fv_sim *h);
@@ -164,7 +167,8 @@ int fv_sim_sync(fv_sim *h);
  * [0] spread kernel launches, [1] fine-grid cells written by spread (all trans, summed),
  * [2] source x trans visits, [3] cells moved through HBM by the pruned FFT passes,
  * [4] interp targets x trans, [5] above-horizon sources summed over times, [6] last n2x,
- * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w.                          */
+ * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w, [10] upsampling factor the
+ * last run used.                                                                             */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,

@@ -575,6 +575,26 @@ def test_sim_gang_launches_match_single_steps(gpu, monkeypatch):
             assert rel_l2(ganged, oracle_simulate(c)) < 1e-8, name
 
 
+def test_sim_auto_upsample_factor(gpu):
+    """upsample_factor "auto": the engine picks 1.25 when the fine grid dwarfs the point counts (a
+    wide array with few sources and baselines) and 2 otherwise or when eps < 1e-8; each result equals
+    the run with that factor given explicitly, and stays within the eps contract."""
+    from fftvis_amd.gpu.gpu_simulate import SimHandle  # noqa: F401  (stats key below)
+
+    wide = synth.make_config("C3", nsrc=3000, nfreq=2, ntimes=2)
+    rng = np.random.default_rng(2)
+    wide["baselines"] = [wide["baselines"][i] for i in sorted(rng.choice(61075, 300, replace=False))]
+    compact = synth.make_config("C2", nsrc=4000, nfreq=3, ntimes=2)
+    for cfg, expect in ((wide, 1.25), (compact, 2), (dict(wide, eps=1e-10), 2)):
+        auto = fftvis_amd.simulate_vis(**dict(cfg, upsample_factor="auto"))
+        same = fftvis_amd.simulate_vis(**dict(cfg, upsample_factor=expect))
+        other = fftvis_amd.simulate_vis(**dict(cfg, upsample_factor=2 if expect == 1.25 else 1.25))
+        assert np.array_equal(auto, same) or rel_l2(auto, same) < 1e-14
+        assert 0 < rel_l2(auto, other) < 20 * max(cfg["eps"], 1e-9)  # a different grid, the same answer
+    sub = dict(wide, baselines=wide["baselines"][:40])
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(sub, upsample_factor=None)), oracle_simulate(sub)) < TOL
+
+
 def test_sim_handle_reconfigured_between_runs(gpu):
     """A long-lived engine handle keeps per-geometry tables between runs (bin order, twiddles, the
     fused gather's per-target records): changing the frequencies, then the baselines, on the same

@@ -6,6 +6,7 @@ python3 $R/bench.py > $O/bench_c2.json 2>$O/bench_c2.err &&
 python3 $R/bench.py --lanes 1 --no-cpu-baseline > $O/bench_c2_lanes1.json 2>/dev/null &&
 python3 $R/bench.py --lanes 2 --pipe 0 --no-cpu-baseline > $O/bench_c2_free.json 2>/dev/null &&
 python3 $R/bench.py --workload C3 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2>/dev/null &&
+python3 $R/bench.py --workload C3 --upsample 0 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c3_auto.json 2>/dev/null &&
 python3 $R/bench.py --workload C3 --path type1 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c3_type1.json 2>/dev/null &&
 python3 $R/bench.py --workload C5 --ntimes 2 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -- python3 $R/bench.py --no-cpu-baseline --no-breakdown > $O/prof_c2.log 2>&1 &&
