@@ -1509,6 +1509,11 @@ class Sim : public SimBase {
         }
 
         const int sample_step = std::min(TIMING_STRIDE / 2, nt - 1);  // level-1 timing: this step of every 16
+        const Pair *last_pair = nullptr;
+        for (const Pair &pr : pairs)
+            if (pr.n) last_pair = &pr;
+        const char *erh = std::getenv("FFTVIS_HIP_RIDE_EVENT");
+        const bool ride_heavy_done = !(erh && std::atoi(erh) == 0);
         for (int ti = t0; ti < t1;) {
             const int nm = gang && ti + 1 < t1 ? 2 : 1;  // time steps in this unit
             const int tu = ti;
@@ -1526,7 +1531,7 @@ class Sim : public SimBase {
             const hipStream_t ls = pipe ? stream : L0.stream;        // big kernels
             const hipStream_t ps = pipe ? prep_stream : L0.stream;   // per-time preparation
             Nufft3<T> *mate = nm == 2 ? Ls[1]->nufft.get() : nullptr;
-            bool sampled = false;
+            bool sampled = false, heavy_recorded = false;
             for (int m = 0; m < nm; ++m) sampled = sampled || (tu + m - t0) % TIMING_STRIDE == sample_step;
             // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
             if (pipe && L0.heavy_pending) FV_HIP(hipStreamWaitEvent(ps, L0.heavy_done, 0));  // lane scratch is free
@@ -1600,6 +1605,12 @@ class Sim : public SimBase {
                         const size_t e3 = ev_slot(TM_SPREAD);
                         nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b, mate);
                         spread_timed += 1;
+                    } else if (ride_heavy_done && pipe && &grp == &groups.back() && &pr == last_pair) {
+                        // the unit's last spread is the last reader of the lanes' per-time arrays (the FFT
+                        // passes and the gather work on the grids): its dispatch carries the "lane scratch
+                        // is free" event, which saves the main stream a marker packet per unit
+                        nufft->spread(ntrans, nullptr, L0.heavy_done, mate);
+                        heavy_recorded = true;
                     } else {
                         nufft->spread(ntrans, nullptr, nullptr, mate);
                     }
@@ -1641,7 +1652,7 @@ class Sim : public SimBase {
                 }
             }
             if (pipe) {
-                FV_HIP(hipEventRecord(L0.heavy_done, ls));
+                if (!heavy_recorded) FV_HIP(hipEventRecord(L0.heavy_done, ls));
                 L0.heavy_pending = true;
             }
         }
