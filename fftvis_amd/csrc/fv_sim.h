@@ -1512,8 +1512,12 @@ class Sim : public SimBase {
         const Pair *last_pair = nullptr;
         for (const Pair &pr : pairs)
             if (pr.n) last_pair = &pr;
+        // only when every unit runs one geometry (one frequency group, one beam pair): with several, the
+        // next preparation's set_geometry may rewrite the twiddle tables the FFT passes still read
+        int active_pairs = 0;
+        for (const Pair &pr : pairs) active_pairs += pr.n > 0;
         const char *erh = std::getenv("FFTVIS_HIP_RIDE_EVENT");
-        const bool ride_heavy_done = !(erh && std::atoi(erh) == 0);
+        const bool ride_heavy_done = !(erh && std::atoi(erh) == 0) && groups.size() == 1 && active_pairs == 1;
         for (int ti = t0; ti < t1;) {
             const int nm = gang && ti + 1 < t1 ? 2 : 1;  // time steps in this unit
             const int tu = ti;
