@@ -593,6 +593,15 @@ def test_sim_auto_upsample_factor(gpu):
         assert 0 < rel_l2(auto, other) < 20 * max(cfg["eps"], 1e-9)  # a different grid, the same answer
     sub = dict(wide, baselines=wide["baselines"][:40])
     assert rel_l2(fftvis_amd.simulate_vis(**dict(sub, upsample_factor=None)), oracle_simulate(sub)) < TOL
+    # fp32: 1.25 from eps = 1e-4 upwards (where it is as accurate as 2), 2 below
+    exact = oracle_simulate(sub)
+    for eps, expect in ((1e-4, 1.25), (1e-5, 2)):
+        c32 = dict(sub, precision=1, eps=eps)
+        auto = fftvis_amd.simulate_vis(**dict(c32, upsample_factor="auto"))
+        same = fftvis_amd.simulate_vis(**dict(c32, upsample_factor=expect))
+        other = fftvis_amd.simulate_vis(**dict(c32, upsample_factor=2 if expect == 1.25 else 1.25))
+        assert rel_l2(auto, same) < 1e-6 < rel_l2(auto, other)  # fp32 atomics: equal up to summation order
+        assert auto.dtype == np.complex64 and rel_l2(auto, exact) < 1e-3
 
 
 def test_sim_handle_reconfigured_between_runs(gpu):

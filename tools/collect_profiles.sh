@@ -9,6 +9,7 @@ python3 $R/bench.py --workload C3 --steps 1 --warmup 1 --no-cpu-baseline > $O/be
 python3 $R/bench.py --workload C3 --upsample 0 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c3_auto.json 2>/dev/null &&
 python3 $R/bench.py --workload C3 --path type1 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c3_type1.json 2>/dev/null &&
 python3 $R/bench.py --workload C5 --ntimes 2 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null &&
+python3 $R/bench.py --workload C5 --ntimes 2 --upsample 0 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c5_auto.json 2>/dev/null &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -- python3 $R/bench.py --no-cpu-baseline --no-breakdown > $O/prof_c2.log 2>&1 &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python3 $R/bench.py --workload C3 --ntimes 2 --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_c3.log 2>&1 &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $O/pmc_fetch_c2.log 2>&1 &&

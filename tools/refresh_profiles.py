@@ -5,7 +5,8 @@ import collections, csv, glob, json, os, re, shutil, sys
 tagr = sys.argv[1] if len(sys.argv) > 1 else "r01"
 O = "gpurun_out/final"
 names = {"bench_c2": "c2_bench", "bench_c2_lanes1": "c2_bench_lanes1", "bench_c2_free": "c2_bench_lanes2_free",
-         "bench_c3": "c3_bench", "bench_c3_auto": "c3_bench_upsample_auto", "bench_c3_type1": "c3_bench_type1", "bench_c5": "c5_bench"}
+         "bench_c3": "c3_bench", "bench_c3_auto": "c3_bench_upsample_auto", "bench_c3_type1": "c3_bench_type1", "bench_c5": "c5_bench",
+         "bench_c5_auto": "c5_bench_upsample_auto"}
 for src, dst in names.items():
     if os.path.exists(f"{O}/{src}.json"):
         shutil.copy(f"{O}/{src}.json", f"profiles/{tagr}_{dst}.json")
