@@ -1407,8 +1407,8 @@ class Sim : public SimBase {
         // Upsampling factor "auto" (fv_sim_create upsampfac = 0): sigma = 1.25 shrinks the fine grid and
         // all FFT work by (2 / 1.25)^D at the price of a kernel 13-14 cells wide instead of 9 (every
         // source and target costs ~2x in 2-D), with NUFFT errors at or below sigma = 2's down to
-        // eps ~ 1e-8 (fv_eskernel.h).  It pays when the grid dwarfs the point counts: C3 (8192^2 cells,
-        // 1.1e5 points per transform) 3.06 -> 1.57 s per step, C2 (1024 x 512, 5.7e3) 1.38 -> 1.58 ms.
+        // eps ~ 1e-8 (fv_eskernel.h).  It pays when the FFT dominates: C3 (8192^2 cells, 1.1e5 points
+        // per transform) 3.06 -> 1.57 s per step; C2 (1024 x 512, 5.7e3) would lose, 1.38 -> 1.58 ms.
         double sigma = this->sigma;
         if (sigma == 0.0) {
             const KerParams k2 = make_kernel(eps, 2.0);
@@ -1431,7 +1431,12 @@ class Sim : public SimBase {
             // fp32 it matches sigma = 2 down to eps = 1e-4 (HERA-350, top of the band: worst baseline
             // 5.8e-4 vs 9.9e-4, rel. l2 4.1e-5 vs 6.4e-5) and falls behind at 1e-5
             const double eps_floor = sizeof(T) == 8 ? 1e-8 : 1e-4;
-            sigma = eps >= eps_floor && cells2 >= (D == 2 ? 300.0 : 2000.0) * points ? 1.25 : 2.0;
+            // measured (2-D): 8192^2 grids win with 1.25 from 1e5 sources (3.06 -> 1.57 s) up to 4e6 per
+            // time step (31.1 -> 29.7 ms per 16-channel slice, ~30 cells per point); a 1024 x 512 grid
+            // loses slightly even with 1e3 sources (its kernels are latency-bound, a smaller grid buys
+            // little): so large grids only, and not when points outnumber the cells they save
+            const double per_point = D == 2 ? 30.0 : 200.0;
+            sigma = eps >= eps_floor && cells2 >= 4.0e6 && cells2 >= per_point * points ? 1.25 : 2.0;
         }
         sigma_run = sigma;
         st[10] = sigma;

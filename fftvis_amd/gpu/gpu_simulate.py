@@ -235,8 +235,8 @@ class GPUSimulationEngine(SimulationEngine):
         * ``beam_spline_opts``: order 1 (bilinear, also when None) or 3 (cubic B-spline; ``kx/ky``
           of ``az_za_simple`` are read the same way); other orders raise NotImplementedError;
         * ``upsample_factor``: 2 (default, as the reference) or 1.25 are used as given; ``None`` /
-          ``"auto"`` (extra) lets the engine pick per run -- 1.25 when eps >= 1e-8 and the fine grid
-          dwarfs the source and baseline counts (HERA-350 class arrays: ~2x faster), else 2;
+          ``"auto"`` (extra) lets the engine pick per run -- 1.25 when eps >= 1e-8 (fp32: 1e-4) and
+          the fine grid is large (HERA-350 class arrays: ~2x faster), else 2;
         * ``time_idx`` / ``freq_idx`` (extra) restrict the run to a block, which is how ranks
           shard a simulation across GPUs.
         """
