@@ -462,6 +462,11 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
         __builtin_amdgcn_wave_barrier();
         // ---- accumulate from LDS --------------------------------------------------------------
         for (int j = 0; j < ncur; ++j) {
+            if (w > 9) {  // the bins two back reach this block only with the far end of their footprints
+                const int sx = __builtin_amdgcn_readfirstlane(s_i0[wave][j][0]);
+                const int sy = __builtin_amdgcn_readfirstlane(s_i0[wave][j][1]);
+                if (sx + w <= (bx << BINLOG) || sy + w <= (by << BINLOG)) continue;  // wave-uniform
+            }
             const int dx = cx - s_i0[wave][j][0], dy = cy - s_i0[wave][j][1];
             T wt = T(0);
             if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
@@ -612,8 +617,11 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d_cg(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int j = 0; j < ncur; ++j) {
-            const int dx = cx - __builtin_amdgcn_readlane(qx, j);
+            const int sx = __builtin_amdgcn_readlane(qx, j);
             const int oy = __builtin_amdgcn_readlane(qy, j) - cy0;  // first footprint row, block-relative
+            // w > 9: the bins two back reach this block only with the far end of their footprints
+            if (w > 9 && (sx + w <= (bx << BINLOG) || oy + w <= 0)) continue;  // wave-uniform
+            const int dx = cx - sx;
             const T wx = (unsigned)dx < (unsigned)w ? s_kwx[wave][j][dx] : T(0);
             const T *wyp = &s_kwy[wave][j][8 - oy];  // row k of the block reads weight k - oy (or padding)
             cplx<T> cv[CPL];
