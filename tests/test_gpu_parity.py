@@ -604,6 +604,23 @@ def test_sim_auto_upsample_factor(gpu):
         assert auto.dtype == np.complex64 and rel_l2(auto, exact) < 1e-3
 
 
+def test_sim_c3_full_catalog_two_grids_agree(gpu):
+    """configs[2] at its full catalog and baseline set (1e5 sources, 61 075 baselines, polarized table
+    beam; 3 channels x 1 time): the sigma = 2 run (8192^2 grid, w = 9) and the sigma = 1.25 run the
+    engine picks by itself (4096^2 grid, w = 13) share nothing but the inputs and must agree to a few
+    eps; a random subset of baselines is also checked against the oracle's exact sums."""
+    cfg = synth.make_config("C3", nfreq=3, ntimes=1)
+    v2 = fftvis_amd.simulate_vis(**dict(cfg, upsample_factor=2))
+    va = fftvis_amd.simulate_vis(**dict(cfg, upsample_factor="auto"))
+    assert v2.shape == (3, 1, 2, 2, 61075) and np.isfinite(v2).all()
+    d = rel_l2(va, v2)
+    assert 1e-12 < d < 5 * cfg["eps"], d  # different grids (not the same run twice), same answer
+    rng = np.random.default_rng(7)
+    sub = sorted(rng.choice(61075, 24, replace=False))
+    exact = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
+    assert rel_l2(v2[..., sub], exact) < TOL and rel_l2(va[..., sub], exact) < TOL
+
+
 def test_sim_handle_reconfigured_between_runs(gpu):
     """A long-lived engine handle keeps per-geometry tables between runs (bin order, twiddles, the
     fused gather's per-target records): changing the frequencies, then the baselines, on the same
