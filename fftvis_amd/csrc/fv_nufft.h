@@ -624,19 +624,21 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d_cg(
             const int dx = cx - sx;
             const T wx = (unsigned)dx < (unsigned)w ? s_kwx[wave][j][dx] : T(0);
             const T *wyp = &s_kwy[wave][j][8 - oy];  // row k of the block reads weight k - oy (or padding)
-            cplx<T> cv[CPL];
+            cplx<T> cv[CPL];  // strengths times the x weight: 2 CPL multiplies instead of 8 weight products
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) cv[q] = s_str[wave][j][cg * CPL + q];
+            for (int q = 0; q < CPL; ++q) {
+                const cplx<T> c0 = s_str[wave][j][cg * CPL + q];
+                cv[q] = {c0.re * wx, c0.im * wx};
+            }
             T wy[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) wy[k] = wyp[k];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const T wt = wx * wy[k];
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
-                    ar[q][k] += cv[q].re * wt;
-                    ai[q][k] += cv[q].im * wt;
+                    ar[q][k] += cv[q].re * wy[k];
+                    ai[q][k] += cv[q].im * wy[k];
                 }
             }
         }
