@@ -1996,12 +1996,9 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         return;
     }
     const size_t smem = sizeof(cplx<T>) * (size_t)a.lds_row * a.rpw;
-    static bool attr_set_dif = false;
-    if (!attr_set_dif) {
+    if (smem > 48 * 1024)  // per device, so not cached in a process-wide flag (handles may sit on several GPUs)
         FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowfft_dif<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set_dif = true;
-    }
     hipLaunchKernelGGL(k_rowfft_dif<T>, jobs, dim3(a.tpr * a.rpw), smem, stream, in, out, twd, a);
 }
 
