@@ -1083,6 +1083,9 @@ __global__ void k_fg_build(int64_t N, int nfg, const T *__restrict__ btx, const 
 // compile-time zeros, which prunes the first butterfly stages.
 // (Running the P residue jobs of a row group as one lock-stepped workgroup, with or without
 // staging the merged row in LDS, was measured slower than separate workgroups on Q = 4096, P = 2.)
+#ifndef FV_ST_DUAL
+#define FV_ST_DUAL 1
+#endif
 template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false>
 __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_ST_MINW12 : 4) void k_rowfft_st(
     const cplx<T> *__restrict__ in0, cplx<T> *__restrict__ out0, const cplx<T> *__restrict__ tw, RowDifArgs a,
@@ -1100,7 +1103,11 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     constexpr int L1 = ilog2_c(R1), L2 = ilog2_c(R2), L3 = ilog2_c(R3);
     constexpr bool WAVE = TPR == 64 && !COL;
     static_assert(S1 == TPR, "one pass-1 item per thread");
-    __shared__ __attribute__((aligned(16))) T smem[RPW * ROW];
+    // DUAL: separate buffers for the real and imaginary halves of an exchange, so that one barrier per
+    // exchange suffices (column mode spreads a column's threads over all waves: its barriers are
+    // workgroup-wide)
+    constexpr bool DUAL = FV_ST_DUAL && COL && LOGQ == 9;
+    __shared__ __attribute__((aligned(16))) T smem[(DUAL ? 2 : 1) * RPW * ROW];
 
     const int tid = threadIdx.x;
     const int vb = blockIdx.x;
@@ -1116,6 +1123,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     const bool ok = row < a.nrows && rk < a.rpp_valid;
     const int n2 = a.n2;
     T *rb = smem + r * ROW;
+    T *rbi = DUAL ? rb + RPW * ROW : rb;
 
     // fused gather: this 8-lane slot's first item (id, header, x weight) is requested now, so that
     // two of the three dependent round trips of the gather are long over when the tile is ready
@@ -1230,19 +1238,27 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     cplx<T> vb2[NI2][R2];
 #pragma unroll
     for (int k = 0; k < R1; ++k) rb[s1 + k * A] = va[bitrev_small(k, L1)].re;
+    if constexpr (!DUAL) {
+        st_sync<WAVE>();
+#pragma unroll
+        for (int i = 0; i < NI2; ++i)
+#pragma unroll
+            for (int n = 0; n < R2; ++n) vb2[i][n].re = rb[base2[i] + n * B];
+        st_sync<WAVE>();
+    }
+#pragma unroll
+    for (int k = 0; k < R1; ++k) rbi[s1 + k * A] = va[bitrev_small(k, L1)].im;
     st_sync<WAVE>();
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int i = 0; i < NI2; ++i)
+#pragma unroll
+            for (int n = 0; n < R2; ++n) vb2[i][n].re = rb[base2[i] + n * B];
+    }
 #pragma unroll
     for (int i = 0; i < NI2; ++i)
 #pragma unroll
-        for (int n = 0; n < R2; ++n) vb2[i][n].re = rb[base2[i] + n * B];
-    st_sync<WAVE>();
-#pragma unroll
-    for (int k = 0; k < R1; ++k) rb[s1 + k * A] = va[bitrev_small(k, L1)].im;
-    st_sync<WAVE>();
-#pragma unroll
-    for (int i = 0; i < NI2; ++i)
-#pragma unroll
-        for (int n = 0; n < R2; ++n) vb2[i][n].im = rb[base2[i] + n * B];
+        for (int n = 0; n < R2; ++n) vb2[i][n].im = rbi[base2[i] + n * B];
 
 #pragma unroll
     for (int i = 0; i < NI2; ++i) {
@@ -1257,21 +1273,29 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     for (int i = 0; i < NI2; ++i)
 #pragma unroll
         for (int k = 0; k < R2; ++k) rb[base2[i] + k * B] = vb2[i][bitrev_small(k, L2)].re;
-    st_sync<WAVE>();
+    if constexpr (!DUAL) {
+        st_sync<WAVE>();
 #pragma unroll
-    for (int i = 0; i < NI3; ++i)
+        for (int i = 0; i < NI3; ++i)
 #pragma unroll
-        for (int n = 0; n < R3; ++n) vc[i][n].re = rb[base3[i] + n];
-    st_sync<WAVE>();
+            for (int n = 0; n < R3; ++n) vc[i][n].re = rb[base3[i] + n];
+        st_sync<WAVE>();
+    }
 #pragma unroll
     for (int i = 0; i < NI2; ++i)
 #pragma unroll
-        for (int k = 0; k < R2; ++k) rb[base2[i] + k * B] = vb2[i][bitrev_small(k, L2)].im;
+        for (int k = 0; k < R2; ++k) rbi[base2[i] + k * B] = vb2[i][bitrev_small(k, L2)].im;
     st_sync<WAVE>();
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int i = 0; i < NI3; ++i)
+#pragma unroll
+            for (int n = 0; n < R3; ++n) vc[i][n].re = rb[base3[i] + n];
+    }
 #pragma unroll
     for (int i = 0; i < NI3; ++i)
 #pragma unroll
-        for (int n = 0; n < R3; ++n) vc[i][n].im = rb[base3[i] + n];
+        for (int n = 0; n < R3; ++n) vc[i][n].im = rbi[base3[i] + n];
 
     // ---- pass 3 and this residue's outputs: k' = v + k3 Q/R3, l = P k' + p (mod n2, signed) ------
     if (!FUSED && !ok) return;
