@@ -18,14 +18,18 @@
 //    transpose), a tile transpose sits between the passes otherwise.  HBM traffic ~ 4-6 na^2 cells
 //    per transform instead of the >= 8 n2^2 = 32 na^2 of a full-grid library FFT (four passes) plus
 //    the zero padding the spread would have to write.  On small 2-D grids the last pass also
-//    serves the targets from its LDS tiles (fused gather): no output grid at all.
+//    serves the targets from its LDS tiles (fused gather): no output grid at all.  Rows are centred
+//    by entering element ia at the cyclic slot (ia - n_in/2) mod Q, so no output carries a phase.
 //  * Spread is a GATHER: one wave owns one 8x8-cell block of A (lane = cell) for TCH transforms.
 //    Sources are counting-sorted into 8x8-cell bins of their footprint origin, their 2w kernel
 //    weights are evaluated once per (time, geometry); the wave walks the <= 3x3 bins whose
 //    footprints can reach its block in chunks of 16 sources staged through registers into its
 //    private LDS slice, multiplies the two tabulated weights and accumulates strengths in
 //    registers, then writes every cell once (zeros included, deconvolution applied).  No atomics,
-//    no memset pass; blocks are processed heaviest-first.
+//    no memset pass; blocks are processed heaviest-first.  Source-dense 2-D grids use a second lane
+//    mapping (lane = block column x channel group, k_spread2d_cg) that reads far less LDS per visit.
+//  * spread() and fft() take a `mate`: a second plan of the same geometry (another time step) whose
+//    sources / grids the same launches serve through blockIdx.y (gang launches, see fv_sim.h).
 #pragma once
 
 #include "fv_eskernel.h"
