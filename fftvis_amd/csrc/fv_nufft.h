@@ -1603,6 +1603,9 @@ class Nufft3 {
         FV_REQUIRE(sigma == 2.0 || sigma == 1.25, "upsample factor must be 2 or 1.25");
         FV_REQUIRE(eps > 0 && eps < 1, "eps must be in (0, 1)");
         ker = make_kernel(eps, sigma, w_override);
+        // 3-D transforms carry a larger error constant (seeded fuzzing: 12 eps on band-edge baselines of a
+        // non-coplanar array at every eps, against <= 2 eps in 2-D): one more cell of kernel width there
+        if (dim == 3 && !w_override && ker.w < (sigma == 2.0 ? MAX_W : 15)) ker = make_kernel(eps, sigma, ker.w + 1);
         geo.dim = dim;
     }
 
