@@ -80,7 +80,7 @@ typedef struct fv_sim fv_sim;
 
 /* precision 1|2; eps: NUFFT accuracy (core/simulate.py:16-19 defaults are the caller's job);
  * upsampfac 2.0|1.25 (cpu/nufft.py:19 "upsample_factor", handed to finufft as is), or 0 = let every
- * fv_sim_run pick: 1.25 when eps >= 1e-8 (fp32: 1e-4), the fine grid at sigma = 2 has >= 4e6 cells
+ * fv_sim_run pick: 1.25 when eps >= 1e-8 (fp32: 1e-4; ten times that in 3-D), the fine grid at sigma = 2 has >= 4e6 cells
  * and >= 30 cells per source and target (200 in 3-D), else 2 -- the accuracy contract is eps either way;
  * polarized: nfeeds = 2 (cpu_simulate.py:589). */
 int fv_sim_create(fv_sim **h, int device, int precision, double eps, double upsampfac,
