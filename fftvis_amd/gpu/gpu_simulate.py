@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import logging
+import warnings
 
 import numpy as np
 
@@ -247,6 +248,12 @@ class GPUSimulationEngine(SimulationEngine):
         complex_dtype = np.complex64 if precision == 1 else np.complex128
         if eps is None:
             eps = default_accuracy_dict[precision]
+        if upsample_factor == 1.25 and eps < (1e-8 if precision == 2 else 1e-4):
+            # finufft's upsampfac = 1.25 has the same floor (its kernel width is capped likewise)
+            warnings.warn(
+                f"upsample_factor=1.25 delivers about {1e-8 if precision == 2 else 1e-4:g} at best "
+                f"(eps={eps:g} was asked for); use upsample_factor=2 or 'auto' for tighter tolerances.",
+                RuntimeWarning, stacklevel=2)
         # precision = 1 rounds ra/dec/freqs to float32 first (reference cpu_simulate.py:601-606)
         ra = np.asarray(ra).astype(real_dtype)
         dec = np.asarray(dec).astype(real_dtype)

@@ -575,6 +575,7 @@ def test_sim_gang_launches_match_single_steps(gpu, monkeypatch):
             assert rel_l2(ganged, oracle_simulate(c)) < 1e-8, name
 
 
+@pytest.mark.filterwarnings("ignore:upsample_factor=1.25 delivers")  # the "other factor" runs below ask for it on purpose
 def test_sim_auto_upsample_factor(gpu):
     """upsample_factor "auto": the engine picks 1.25 when the fine grid dwarfs the point counts (a
     wide array with few sources and baselines) and 2 otherwise or when eps < 1e-8; each result equals
@@ -841,7 +842,7 @@ def test_sim_fuzz_random_configurations(gpu):
         assert err < 10 * cfg["eps"] + 1e-12, ("lattice", it, err, cfg["eps"], cfg["polarized"], len(cfg["ants"]))
     for it in range(24):  # low upsampling (sigma = 1.25: eps floor ~1e-8 in fp64, see fv_eskernel.h)
         cfg = _random_sim_config(rng, lattice=it % 4 == 3)
-        cfg.update(upsample_factor=1.25, eps=max(cfg["eps"], 1e-9))
+        cfg.update(upsample_factor=1.25, eps=max(cfg["eps"], 1e-8))
         err = rel_l2(fftvis_amd.simulate_vis(**cfg), oracle_simulate(cfg))
         assert err < 10 * cfg["eps"] + 1e-12, ("sigma 1.25", it, err, cfg["eps"], cfg["polarized"], len(cfg["ants"]))
 

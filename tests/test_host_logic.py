@@ -214,3 +214,19 @@ def test_spline_opts_orders():
             eng.simulate(ants=cfg["ants"], freqs=cfg["freqs"], fluxes=cfg["fluxes"], beam_list=[cfg["beam"]],
                          ra=cfg["ra"], dec=cfg["dec"], times=cfg["times"], telescope_loc=cfg["telescope_loc"],
                          beam_spline_opts=opts)
+
+
+def test_upsample_1p25_below_its_floor_warns():
+    """upsample_factor=1.25 cannot deliver better than ~1e-8 in fp64 (1e-4 in fp32): asking for less
+    is answered with a RuntimeWarning before anything touches the GPU."""
+    from fftvis_amd.gpu.gpu_simulate import GPUSimulationEngine
+
+    cfg = synth.make_config("C1", nsrc=5, nfreq=2, ntimes=1)
+    kw = dict(ants=cfg["ants"], freqs=cfg["freqs"], fluxes=cfg["fluxes"], beam_list=[cfg["beam"]], ra=cfg["ra"],
+              dec=cfg["dec"], times=cfg["times"], telescope_loc=cfg["telescope_loc"], upsample_factor=1.25)
+    for prec, eps in ((2, 1e-10), (1, 1e-6)):
+        with pytest.warns(RuntimeWarning, match="upsample_factor=1.25 delivers about"):
+            try:
+                GPUSimulationEngine().simulate(precision=prec, eps=eps, **kw)
+            except Exception:  # no GPU here: the warning comes first
+                pass
