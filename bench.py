@@ -113,14 +113,23 @@ def cpu_baseline(cfg, seconds: float):
         if t_used > seconds:
             break
     nbls = len(cfg["baselines"])
+    try:
+        ncores = len(os.sched_getaffinity(0))  # the cores this process may run on
+    except AttributeError:
+        ncores = os.cpu_count()
+    w = cpu_nufft.es_params(cfg["eps"], 2.0)[0]
+    nfe = (nfeeds * nfeeds)
+    thr_spread = cpu_nufft._nthreads(n * nfe * w * w)
+    thr_interp = cpu_nufft._nthreads(nbls * nfe * w * w)
     return {
         "value": nbls * nslices / t_used,
         "unit": "visibilities/s",
-        "cores": os.cpu_count(),
+        "cores": ncores,
         "kind": "port",
-        "sample": f"{nslices} (time,freq) slices of the workload in {t_used:.1f} s; C/OpenMP "
-                  "spread + interp (oracle/cpu_nufft.c), scipy.fft on all cores, numpy beam/coherency "
-                  "-- CPU restatement of the type-3 NUFFT path, not finufft",
+        "sample": f"{nslices} (time,freq) slices of the workload in {t_used:.1f} s; scipy.fft with {ncores} "
+                  f"workers, C/OpenMP spread / interp (oracle/cpu_nufft.c) with {thr_spread} / {thr_interp} "
+                  "threads (one per 2e6 kernel-cell updates), numpy beam/coherency -- CPU restatement of "
+                  "the type-3 NUFFT path, not finufft",
     }
 
 
