@@ -221,6 +221,10 @@ struct fv_sim {
 extern "C" {
 
 int fv_version(void) { return 100; /* 0.1.0 */ }
+int fv_device_bytes(int64_t *bytes) {
+    if (bytes) *bytes = (int64_t)fv::dev_bytes_held().load();
+    return bytes ? 0 : 1;
+}
 
 int fv_device_count(int *count) {
     return guarded([&] {

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -35,6 +37,12 @@ struct Error : std::runtime_error {
     } while (0)
 
 // Growable device buffer owned by a plan / engine (never shrinks; freed in dtor).
+// bytes of device memory this process holds in DevBufs (all handles): fv_device_bytes()
+inline std::atomic<size_t> &dev_bytes_held() {
+    static std::atomic<size_t> v{0};
+    return v;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -43,14 +51,17 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() {
         if (p) (void)hipFree(p);
+        dev_bytes_held() -= cap;
     }
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
         if (p) FV_HIP(hipFree(p));
+        dev_bytes_held() -= cap;
         p = nullptr;
         cap = 0;
         FV_HIP(hipMalloc(&p, bytes));
         cap = bytes;
+        dev_bytes_held() += cap;
     }
     template <typename U>
     U *as() const {

@@ -12,6 +12,7 @@ fallback: without the library or a GPU the calls raise.
 from __future__ import annotations
 
 import ctypes
+import atexit
 import logging
 import warnings
 
@@ -25,6 +26,44 @@ from ..core.coords import SiderealRotation, eq_unit_vectors, julian_dates
 from ..core.simulate import SimulationEngine, default_accuracy_dict
 
 logger = logging.getLogger(__name__)
+
+
+# Handles kept between ``simulate`` calls.  Creating and destroying a handle (streams, events, device
+# buffers, per-geometry tables) costs ~15 ms, ten times the GPU work of a HERA-37 simulation; every
+# ``fv_sim_set_*`` call fully replaces what it configures, so a handle whose creation parameters
+# match can serve the next call.  At most two idle handles, and only while this process holds less
+# than FFTVIS_HIP_HANDLE_CACHE_BYTES of device memory (default 2 GiB; 0 = never keep one).
+_IDLE_HANDLES: dict = {}
+atexit.register(lambda: release_handles())
+
+
+def _cache_limit() -> int:
+    import os
+
+    return int(float(os.environ.get("FFTVIS_HIP_HANDLE_CACHE_BYTES", 2 * 1024**3)))
+
+
+def release_handles():
+    """Destroy the idle handles (and free their device memory)."""
+    while _IDLE_HANDLES:
+        _IDLE_HANDLES.popitem()[1].close()
+
+
+def _acquire_handle(device, precision, eps, upsample_factor, polarized):
+    key = (int(device), int(precision), float(eps), str(upsample_factor), bool(polarized))
+    h = _IDLE_HANDLES.pop(key, None)
+    return key, (h if h is not None else SimHandle(device, precision, eps, upsample_factor, polarized))
+
+
+def _return_handle(key, h):
+    held = ctypes.c_int64(0)
+    _lib.check(_lib.lib().fv_device_bytes(ctypes.byref(held)))
+    if _cache_limit() <= 0 or held.value > _cache_limit():
+        h.close()
+        return
+    while len(_IDLE_HANDLES) >= 2:
+        _IDLE_HANDLES.pop(next(iter(_IDLE_HANDLES))).close()
+    _IDLE_HANDLES[key] = h
 
 
 class SimHandle:
@@ -296,7 +335,8 @@ class GPUSimulationEngine(SimulationEngine):
         else:
             pairs, pair_idx, pair_flip = utils.prepare_beam_evaluation(antnums, baselines, beam_idx)
 
-        h = SimHandle(self.device, precision, eps, upsample_factor, polarized)
+        key, h = _acquire_handle(self.device, precision, eps, upsample_factor, polarized)
+        ok = False
         try:
             h.set_sources(eq_unit_vectors(ra.astype(float), dec.astype(float)), coherency, polarized_sky)
             if coord_mgr is not None:
@@ -325,8 +365,12 @@ class GPUSimulationEngine(SimulationEngine):
             t0, t1, _ = time_idx.indices(ntimes)
             f0, f1, _ = freq_idx.indices(nfreqs)
             vis = h.run(t0, t1, f0, f1)
+            ok = True
         finally:
-            h.close()
+            if ok:
+                _return_handle(key, h)
+            else:  # an error may have left it half configured
+                h.close()
         return vis.astype(complex_dtype, copy=False)
 
     def _evaluate_vis_chunk(self, time_idx: slice, freq_idx: slice, **kw) -> np.ndarray:

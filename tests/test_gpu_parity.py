@@ -622,6 +622,46 @@ def test_sim_c3_full_catalog_two_grids_agree(gpu):
     assert rel_l2(v2[..., sub], exact) < TOL and rel_l2(va[..., sub], exact) < TOL
 
 
+def test_sim_idle_handles_are_reused_safely(gpu, monkeypatch):
+    """simulate() keeps up to two idle fv_sim handles and reconfigures them for the next call with the
+    same creation parameters (device, precision, eps, upsampling factor, polarized).  A sequence that
+    flips everything a handle can hold -- type-3 <-> type-1 array, beam pairs <-> eigenbeams, table
+    (order 3) <-> Airy beams, catalog / band / times of other sizes -- must give what fresh handles
+    give, and release_handles() must return the device memory."""
+    import ctypes
+
+    from fftvis_amd import _lib
+    from fftvis_amd.gpu import gpu_simulate
+
+    c1 = synth.make_config("C1")
+    freqs = c1["freqs"]
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=46, naz=90), freqs)
+    rng = np.random.default_rng(8)
+    coefs = rng.normal(size=(7, 2, len(freqs))) + 1j * rng.normal(size=(7, 2, len(freqs)))
+    c2 = synth.make_config("C2", nsrc=800, nfreq=3, ntimes=3)
+    pol = dict(c1, polarized=True)
+    seq = [pol, dict(pol, force_use_type3=False), dict(pol, beam=[tab, fftvis_amd.AiryBeam(9.0)], beam_coefs=coefs),
+           dict(pol, beam=tab, beam_spline_opts={"order": 3}), dict(c2, polarized=True, eps=6e-8), pol,
+           c1, dict(c1, force_use_type3=False), c2, dict(c1, beam=tab), c1]
+
+    def held():
+        v = ctypes.c_int64(0)
+        _lib.check(_lib.lib().fv_device_bytes(ctypes.byref(v)))
+        return v.value
+
+    gpu_simulate.release_handles()
+    assert held() == 0
+    reused = [fftvis_amd.simulate_vis(**c) for c in seq]
+    assert 0 < len(gpu_simulate._IDLE_HANDLES) <= 2 and held() > 0
+    gpu_simulate.release_handles()
+    assert held() == 0
+    monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", "0")
+    for c, got in zip(seq, reused):
+        fresh = fftvis_amd.simulate_vis(**c)
+        assert not gpu_simulate._IDLE_HANDLES and held() == 0
+        assert rel_l2(got, fresh) < 1e-13
+
+
 def test_sim_handle_reconfigured_between_runs(gpu):
     """A long-lived engine handle keeps per-geometry tables between runs (bin order, twiddles, the
     fused gather's per-target records): changing the frequencies, then the baselines, on the same
