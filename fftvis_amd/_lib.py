@@ -28,6 +28,7 @@ SYMBOLS = {
     "fv_device_count": (c_int, [POINTER(c_int)]),
     "fv_last_error": (c_char_p, []),
     "fv_device_bytes": (c_int, [POINTER(c_int64)]),
+    "fv_release_workspaces": (c_int, []),
     "fv_nufft3": (c_int, [c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_int, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_double,
                           c_void_p]),

@@ -48,6 +48,42 @@ static void minmax(const double *v, int64_t n, double &c, double &h) {
     h = h * (1.0 + 1e-6) + 1e-300;
 }
 
+// Stream, device buffers and plan of the stand-alone transform, kept per host thread between calls
+// with the same (device, dim, eps, upsampling factor): setting them up costs ~5 ms, more than a small
+// transform.  Held through plain pointers that only fv_release_workspaces() deletes (static
+// destructors must not call into a HIP runtime that may be gone); dropped after a call that leaves the
+// process above FFTVIS_HIP_HANDLE_CACHE_BYTES (default 2 GiB) of device memory.
+template <typename T>
+struct NufftWorkspace {
+    int device = -1, dim = 0;
+    double eps = 0, sigma = 0;
+    hipStream_t st = nullptr;
+    DevBuf dx[3], ds[3], dc, dout, dscale;
+    std::unique_ptr<Nufft3<T>> plan;
+    ~NufftWorkspace() {
+        plan.reset();
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+template <typename T>
+static NufftWorkspace<T> *&workspace_slot() {
+    static thread_local NufftWorkspace<T> *ws = nullptr;
+    return ws;
+}
+static size_t workspace_limit() {
+    const char *e = std::getenv("FFTVIS_HIP_HANDLE_CACHE_BYTES");
+    return e ? (size_t)std::atof(e) : ((size_t)2 << 30);
+}
+template <typename T>
+static void drop_workspace() {
+    NufftWorkspace<T> *&ws = workspace_slot<T>();
+    if (ws) {
+        (void)hipSetDevice(ws->device);
+        delete ws;
+        ws = nullptr;
+    }
+}
+
 template <typename T>
 static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3], const void *cin,
                         int ntrans, int64_t N, const void *const sin_[3], double eps,
@@ -64,9 +100,26 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
         std::memset(out, 0, sizeof(cplx<T>) * (size_t)ntrans * N);
         return;
     }
-    StreamGuard sg;
-    hipStream_t st = sg.s;
-    DevBuf dx[3], ds[3], dc, dout, dscale;
+    NufftWorkspace<T> *&slot = workspace_slot<T>();
+    if (slot && (slot->device != device || slot->dim != dim || slot->eps != eps || slot->sigma != upsampfac))
+        drop_workspace<T>();
+    if (!slot) {
+        slot = new NufftWorkspace<T>();
+        slot->device = device;
+        slot->dim = dim;
+        slot->eps = eps;
+        slot->sigma = upsampfac;
+        FV_HIP(hipStreamCreateWithFlags(&slot->st, hipStreamNonBlocking));
+    }
+    struct DropOnError {  // an exception may leave the plan half configured
+        bool armed = true;
+        ~DropOnError() {
+            if (armed) drop_workspace<T>();
+        }
+    } guard;
+    NufftWorkspace<T> &W = *slot;
+    hipStream_t st = W.st;
+    DevBuf(&dx)[3] = W.dx, (&ds)[3] = W.ds, &dc = W.dc, &dout = W.dout, &dscale = W.dscale;
     double xc[3] = {0, 0, 0}, X[3] = {0, 0, 0}, sc[3] = {0, 0, 0}, S[3] = {0, 0, 0};
     std::vector<double> tmp;
     for (int d = 0; d < dim; ++d) {
@@ -95,7 +148,8 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
         const double one = 1.0;
         dscale.reserve(sizeof(double));
         FV_HIP(hipMemcpyAsync(dscale.p, &one, sizeof(double), hipMemcpyHostToDevice, st));
-        Nufft3<T> plan(dim, eps, upsampfac, st);
+        if (!W.plan) W.plan.reset(new Nufft3<T>(dim, eps, upsampfac, st));
+        Nufft3<T> &plan = *W.plan;
         plan.set_geometry(xc, X, sc, S, 1.0);
         plan.set_sources(M, dx[0].as<T>(), dx[1].as<T>(), dx[2].as<T>());
         plan.load_strengths(dc.as<cplx<T>>(), ntrans, ntrans, dscale.as<double>());
@@ -109,11 +163,13 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
                               hipMemcpyDeviceToHost, st));
         FV_HIP(hipStreamSynchronize(st));
         FV_HIP(hipGetLastError());
+        guard.armed = fv::dev_bytes_held().load() > workspace_limit();
         return;
     }
     FV_HIP(hipMemcpyAsync(out, dout.p, sizeof(cplx<T>) * (size_t)ntrans * N, hipMemcpyDeviceToHost, st));
     FV_HIP(hipStreamSynchronize(st));
     FV_HIP(hipGetLastError());
+    guard.armed = fv::dev_bytes_held().load() > workspace_limit();
 }
 
 template <typename T>
@@ -221,6 +277,12 @@ struct fv_sim {
 extern "C" {
 
 int fv_version(void) { return 100; /* 0.1.0 */ }
+int fv_release_workspaces(void) {
+    return guarded([&] {
+        drop_workspace<double>();
+        drop_workspace<float>();
+    });
+}
 int fv_device_bytes(int64_t *bytes) {
     if (bytes) *bytes = (int64_t)fv::dev_bytes_held().load();
     return bytes ? 0 : 1;

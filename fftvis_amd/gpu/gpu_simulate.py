@@ -44,9 +44,12 @@ def _cache_limit() -> int:
 
 
 def release_handles():
-    """Destroy the idle handles (and free their device memory)."""
+    """Destroy the idle handles and this thread's cached stand-alone NUFFT workspace (and free their
+    device memory)."""
     while _IDLE_HANDLES:
         _IDLE_HANDLES.popitem()[1].close()
+    if _lib._lib is not None:  # only if the library was ever loaded
+        _lib._lib.fv_release_workspaces()
 
 
 def _acquire_handle(device, precision, eps, upsample_factor, polarized):

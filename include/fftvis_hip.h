@@ -29,6 +29,7 @@ extern "C" {
 int fv_version(void);                 /* 10000*major + 100*minor + patch */
 int fv_device_count(int *count);      /* number of visible HIP devices (0 on a CPU-only box) */
 int fv_device_bytes(int64_t *bytes);  /* device memory this process's handles hold right now (all devices) */
+int fv_release_workspaces(void);      /* free the calling thread's cached fv_nufft3 workspace (stream, buffers, plan) */
 const char *fv_last_error(void);
 
 /* ---- standalone type-3 NUFFT ---------------------------------------------------------------
