@@ -29,7 +29,10 @@ extern "C" {
 int fv_version(void);                 /* 10000*major + 100*minor + patch */
 int fv_device_count(int *count);      /* number of visible HIP devices (0 on a CPU-only box) */
 int fv_device_bytes(int64_t *bytes);  /* device memory this process's handles hold right now (all devices) */
-int fv_release_workspaces(void);      /* free the calling thread's cached fv_nufft3 workspace (stream, buffers, plan) */
+/* fv_nufft3 / fv_nudft3_direct keep a stream, device buffers and a plan per host thread between calls
+ * (while the process holds < FFTVIS_HIP_HANDLE_CACHE_BYTES, default 2 GiB, of device memory): this frees
+ * the calling thread's; call it before a thread that used them exits.                              */
+int fv_release_workspaces(void);
 const char *fv_last_error(void);
 
 /* ---- standalone type-3 NUFFT ---------------------------------------------------------------
