@@ -3,14 +3,17 @@
 
 A "step" is one pass of the hot path (rotate -> beam -> coherency -> type-3 NUFFT for every
 (time, frequency) slice) over one BASELINE.json configuration with seeded synthetic inputs that
-are already resident in HBM when the timed region starts.  Default workload: configs[1]
-("C2": HERA-37, 1e4 sources, 64 freqs, 10 times, unpolarized Airy, fp64, eps = 6e-8).
+are already resident in HBM when the timed region starts.  Default workload: configs[2]
+("C3": HERA-350, 1e5 sources, 128 freqs, 20 times, polarized table beam, fp64, eps = 6e-8,
+upsample_factor 2) -- the largest configuration BASELINE.json lists for one GPU.  `--workload C2`
+keeps the HERA-37 case of round 1, C4 / C5 run the 8-GPU configurations' shapes.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the path shards by
-independent (time, frequency) slices with no data-path collective, so every rank simulates its
-own block of `ntimes` consecutive integrations of one long observation (weak scaling); the only
-communication is the one-off RCCL broadcast of the source catalog from rank 0 before the timed
-region, plus the barriers / MAX-reduce of the timing contract.
+Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): ONE observation is
+sharded over the ranks by independent (time, frequency) blocks (parallel.shard_blocks_weighted:
+time-major, frequency cuts balanced by the nu^2 grid cost) with no data-path collective; the only
+communication is the one-off RCCL broadcast of the source catalog from rank 0 into every rank's
+HBM before the timed region, plus the barriers / MAX-reduce of the timing contract.  Total work
+is fixed as N grows: "scaling": "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -29,17 +32,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+PMC_FILE = os.path.join("profiles", "r02_hbm_traffic_pmc.json")
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=None, help="timed steps (default: 50 for C2, 2 otherwise)")
+    p.add_argument("--steps", type=int, default=None, help="timed steps (default: 3; 50 for C2)")
     p.add_argument("--warmup", type=int, default=None,
-                   help="untimed steps first (default: 20 for C2 -- a 1.5 ms step needs ~30 ms of work "
-                        "before clocks and caches settle: 2 warm-up steps read 1.65 ms/step, 20 read 1.53 -- "
-                        "1 otherwise)")
-    p.add_argument("--workload", default=os.environ.get("FFTVIS_BENCH_WORKLOAD", "C2"),
+                   help="untimed steps first (default: 1; 20 for C2 -- a 1.5 ms step needs ~30 ms of work "
+                        "before clocks and caches settle)")
+    p.add_argument("--workload", default=os.environ.get("FFTVIS_BENCH_WORKLOAD", "C3"),
                    choices=["C1", "C2", "C3", "C4", "C5"])
     p.add_argument("--nsrc", type=int, default=None)
     p.add_argument("--nfreq", type=int, default=None)
@@ -50,31 +53,27 @@ def parse():
     p.add_argument("--path", default="type3", choices=["type3", "type1"],
                    help="type3 = the benchmarked NUFFT path (BASELINE.json); type1 = the lattice path "
                         "the reference takes by default on these arrays (reported for comparison)")
-    p.add_argument("--lanes", type=int, default=None, choices=[1, 2],
-                   help="FFTVIS_HIP_LANES (default: the engine's own choice -- 2 pipelined lanes for small "
-                        "grids: the per-time preparation of the next step runs on a low-priority stream "
-                        "beside the current step, all big kernels stay on one stream, so the per-kernel "
-                        "durations behind `roofline` are uncontended)")
-    p.add_argument("--pipe", type=int, default=None, choices=[0, 1],
-                   help="FFTVIS_HIP_PIPE=0: two lanes run freely on two streams (kernel durations inflate)")
+    p.add_argument("--lanes", type=int, default=None, choices=[1, 2], help="FFTVIS_HIP_LANES (small grids)")
+    p.add_argument("--pipe", type=int, default=None, choices=[0, 1], help="FFTVIS_HIP_PIPE (small grids)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-breakdown", action="store_true",
-                   help="skip the extra single-stream step that times every kernel family (its launches are "
-                        "one time step each and would mix into a rocprofv3 --stats average)")
+                   help="skip the extra single-stream step that times every kernel family (profiling runs)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     a = p.parse_args()
-    light = a.workload == "C2" and not (a.nsrc and a.nsrc > 200000)
+    a.light = a.workload in ("C1", "C2") and not (a.nsrc and a.nsrc > 200000)
     if a.steps is None:
-        a.steps = 50 if light else 2
+        a.steps = 50 if a.light else 3
     if a.warmup is None:
-        a.warmup = 20 if light else 1
+        a.warmup = 20 if a.light else 1
     return a
 
 
 def cpu_baseline(cfg, seconds: float):
     """Time the CPU port of the reference's per-slice work (oracle/: numpy beam + coherency,
-    type-3 NUFFT port = C/OpenMP spread + interp around scipy.fft on all host cores) on a bounded
-    sample of slices, one NUFFT call per (time, frequency) as the reference does."""
+    type-3 NUFFT port = C/OpenMP spread + interp around scipy.fft, every stage on all host cores) on a
+    bounded sample of slices, one NUFFT call per (time, frequency) as the reference does.  Slices are
+    taken from the top of the band downwards and the bottom upwards alternately so that the sample's
+    mean cost is the band's."""
     from oracle import cpu_nufft
     from oracle import fftvis_oracle as orc
     from tests.helpers import oracle_beam
@@ -93,14 +92,16 @@ def cpu_baseline(cfg, seconds: float):
     beams = [oracle_beam(b, pol, freqs) for b in blist]
     # eigenbeam workloads: one NUFFT per basis pair k <= l (reference cpu_simulate.py:416-417)
     bpairs = [(k, l) for k in range(len(beams)) for l in range(k, len(beams))] if "beam_coefs" in cfg else [(0, 0)]
-    nslices, t_used = 0, 0.0
+    nf = len(freqs)
+    order = [i // 2 if i % 2 == 0 else nf - 1 - i // 2 for i in range(nf)]  # bottom, top, bottom + 1, ...
+    nslices, t_used, n = 0, 0.0, 0
     t_start = time.perf_counter()
     for ti in range(len(times)):
         mgr.rotate(ti)
         topo, flux, n = mgr.select_chunk(0, ti)
         az, za = orc.enu_to_az_za(topo[0], topo[1])
         topo = 2 * np.pi * topo
-        for fi in range(len(freqs)):
+        for fi in order:
             bev = [orc.evaluate_beam(b, az, za, pol, freqs[fi]).astype(complex) for b in beams]
             uvw = bls * freqs[fi]
             for (k, l) in bpairs:
@@ -108,7 +109,7 @@ def cpu_baseline(cfg, seconds: float):
                 cpu_nufft.nufft_type3([topo[0], topo[1]], c, [uvw[0], uvw[1]], eps=cfg["eps"])
             nslices += 1
             t_used = time.perf_counter() - t_start
-            if t_used > seconds:
+            if t_used > seconds and nslices % 2 == 0:
                 break
         if t_used > seconds:
             break
@@ -126,9 +127,9 @@ def cpu_baseline(cfg, seconds: float):
         "unit": "visibilities/s",
         "cores": ncores,
         "kind": "port",
-        "sample": f"{nslices} (time,freq) slices of the workload in {t_used:.1f} s; scipy.fft with {ncores} "
-                  f"workers, C/OpenMP spread / interp (oracle/cpu_nufft.c) with {thr_spread} / {thr_interp} "
-                  "threads (one per 2e6 kernel-cell updates), numpy beam/coherency -- CPU restatement of "
+        "sample": f"{nslices} (time,freq) slices of the workload (alternating from both ends of the band) in "
+                  f"{t_used:.1f} s; scipy.fft with {ncores} workers, C/OpenMP spread / interp (oracle/cpu_nufft.c) "
+                  f"with {thr_spread} / {thr_interp} threads, numpy beam/coherency -- CPU restatement of "
                   "the type-3 NUFFT path, not finufft",
     }
 
@@ -140,9 +141,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
-    from fftvis_amd import _lib, synth
+    from fftvis_amd import _lib, parallel, synth
     from fftvis_amd.core import utils
-    from fftvis_amd.core.coords import SiderealRotation, eq_unit_vectors
+    from fftvis_amd.core.coords import SiderealRotation
     from fftvis_amd.gpu.gpu_simulate import SimHandle, prepare_array
 
     if a.lanes is not None:
@@ -171,44 +172,38 @@ def main():
         a.eps = cfg["eps"]
     cfg["eps"] = a.eps
     precision = cfg.get("precision", 2)
-    rdt = torch.float32 if precision == 1 else torch.float64
     cdt = torch.complex64 if precision == 1 else torch.complex128
     RB = 4.0 if precision == 1 else 8.0  # bytes per real
     freqs, pol = cfg["freqs"], cfg["polarized"]
     ntimes, nfreq = len(cfg["times"]), len(freqs)
     baselines = cfg["baselines"]
     nbls = len(baselines)
-
-    # ---- catalog: built on rank 0, broadcast over RCCL/xGMI, handed over as device pointers --
     nsrc = len(cfg["ra"])
-    if rank == 0:
-        coh, pol_sky = utils.prepare_source_catalog(cfg["fluxes"], pol)
-        eq = torch.from_numpy(eq_unit_vectors(cfg["ra"], cfg["dec"])).to(dev, rdt)
-        flux = torch.from_numpy(np.ascontiguousarray(coh)).to(dev, rdt)
-    else:
-        pol_sky = False  # the synthetic catalogs are unpolarized: flux is (nsrc, nfreq) real
-        eq = torch.empty((3, nsrc), dtype=rdt, device=dev)
-        flux = torch.empty((nsrc, nfreq), dtype=rdt, device=dev)
+
+    # ---- catalog: prepared on rank 0, broadcast over RCCL/xGMI into every rank's HBM ------------
     if dist is not None:
-        if backend == "nccl":
-            dist.broadcast(eq, 0)
-            dist.broadcast(flux, 0)
-        else:  # rehearsal: host-side broadcast
-            for tns in (eq, flux):
-                hcopy = tns.cpu()
-                dist.broadcast(hcopy, 0)
-                tns.copy_(hcopy)
+        cat = parallel.broadcast_catalog_device(cfg["ra"] if rank == 0 else None, cfg["dec"] if rank == 0 else None,
+                                                cfg["fluxes"] if rank == 0 else None, pol, precision, dev,
+                                                via_host=backend != "nccl")
+    else:
+        from fftvis_amd.core.coords import eq_unit_vectors
+
+        coh, pol_sky = utils.prepare_source_catalog(cfg["fluxes"], pol)
+        rdt = torch.float32 if precision == 1 else torch.float64
+        cat = parallel.DeviceCatalog(torch.from_numpy(eq_unit_vectors(cfg["ra"], cfg["dec"])).to(dev, rdt),
+                                     torch.from_numpy(np.ascontiguousarray(coh)).to(dev, cdt if pol_sky else rdt),
+                                     pol_sky)
     torch.cuda.synchronize()
 
-    # ---- this rank's block of the observation: ntimes integrations after rank * span ----------
-    dt = cfg["times"][1] - cfg["times"][0] if ntimes > 1 else 0.0
-    my_times = cfg["times"] + rank * ntimes * dt
+    # ---- this rank's block of the observation ----------------------------------------------------
+    blocks = parallel.shard_blocks_weighted(world, freqs, ntimes)
+    mine = blocks[rank]
     R, bls, coplanar = prepare_array(cfg["ants"], baselines, 1e-6, np.float64)
     pairs, pidx, pflip = utils.prepare_beam_evaluation(list(cfg["ants"]), baselines, None)
 
     h = SimHandle(local_rank, precision, a.eps, a.upsample, pol)
-    h.set_sources_device(nsrc, nfreq, eq.data_ptr(), flux.data_ptr(), pol_sky)
-    h.set_times(SiderealRotation(my_times, cfg["telescope_loc"]).matrices())
+    h.set_sources_device(cat.nsrc, cat.nfreq, cat.eq.data_ptr(), cat.flux.data_ptr(), cat.polarized_sky)
+    h.set_times(SiderealRotation(cfg["times"], cfg["telescope_loc"]).matrices())
     h.set_freqs(freqs)
     if a.path == "type1":
         from fftvis_amd.core.antenna_gridding import check_antpos_griddability
@@ -227,29 +222,32 @@ def main():
                     [antnums.index(b[1]) for b in baselines])
     else:
         h.set_beam_pairs(pairs, pidx, pflip)
-    out = torch.empty(h.out_shape(ntimes, nfreq), dtype=cdt, device=dev)
+    outs = []
+    for tsl, fsl in mine:
+        outs.append(torch.empty(h.out_shape(tsl.stop - tsl.start, fsl.stop - fsl.start), dtype=cdt, device=dev))
 
     def step():
-        h.run_device(0, ntimes, 0, nfreq, out.data_ptr())
+        for (tsl, fsl), o in zip(mine, outs):
+            h.run_device(tsl.start, tsl.stop, fsl.start, fsl.stop, o.data_ptr())
 
     # First launches build per-geometry tables (bin order, twiddles, gather plans); then the W untimed
-    # warm-up steps.  A C2 step is 1.5 ms, and the first ~30 ms after idle run at lower clocks: when W
-    # steps are shorter than that, identical steps are repeated (untimed) until 40 ms have been queued,
-    # so that a small --warmup does not time the clock ramp instead of the kernels.
+    # warm-up steps.  Small workloads (a C2 step is 1.5 ms) repeat identical untimed steps until 40 ms have
+    # been queued, so that a small --warmup does not time the clock ramp instead of the kernels.
     t_settle = time.perf_counter()
     for _ in range(a.warmup):
         step()
     h.sync()
     extra = 0
-    while time.perf_counter() - t_settle < 0.040 and extra < 64:
+    while a.light and time.perf_counter() - t_settle < 0.040 and extra < 64:
         step()
         h.sync()
         extra += 1
     h.reset_stats()
-    # HIP events on the engine's own stream, attached to the spread dispatches (level 1); the
-    # other kernel families are timed in one extra, untimed step afterwards (level 2) because
-    # bracketing every launch with event records costs ~15 % of a C2 step.
-    h.enable_timing(1)
+    # HIP events on the engine's own stream, attached to the spread dispatches themselves: on large grids
+    # (a launch is hundreds of us) on EVERY launch (level 3); on C2-sized grids on the launches of one
+    # time step in 16 (level 1), because even attached events idle the queue for 5-8 us around a 50 us
+    # launch.  The other kernel families are timed in one extra, untimed step afterwards (level 2).
+    h.enable_timing(1 if a.light else 3)
 
     if dist is not None:
         dist.barrier()
@@ -259,38 +257,44 @@ def main():
         step()
     h.sync()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0  # this rank's own work, before it waits for the others
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [own]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, own)
 
     st, tm = h.stats(), h.timing()
     h.reset_stats()
-    if a.no_breakdown:  # profiling runs: only launches shaped like the timed region's
-        tm_all, st_all = {k: 0.0 for k in tm}, st
-    else:
+    breakdown = not a.no_breakdown and rank == 0 and len(mine) > 0
+    if breakdown:
         h.enable_timing(2)
         step()
         h.sync()
         tm_all, st_all = h.timing(), h.stats()
+    else:  # profiling runs: only launches shaped like the timed region's
+        tm_all, st_all = None, st
     h.enable_timing(0)
-    finite = bool(torch.isfinite(torch.view_as_real(out)).all().item())
-    vis_per_step = nbls * nfreq * ntimes
-    value = vis_per_step * world * a.steps / elapsed
+    finite = all(bool(torch.isfinite(torch.view_as_real(o)).all().item()) for o in outs)
+    vis_per_step = nbls * nfreq * ntimes  # the whole observation, all ranks together
+    value = vis_per_step * a.steps / elapsed
 
     if rank == 0:
         # ---- roofline of the spread kernel (the kernel BASELINE.json's metric names) ----------
         launches = max(st["spread_launches"], 1.0)
-        timed = max(tm.get("spread_launches_timed", 0.0), 1.0)  # level 1 times the launches of every 16th time step
+        timed = max(tm.get("spread_launches_timed", 0.0), 1.0)
         R8 = RB
         d = 2 if coplanar else 3
+        my_times = sum(t.stop - t.start for t, _ in mine)
         # algorithmic bytes:  M (d R + T 2R)  +  T G1 2R   summed over launches
-        spread_bytes = st["source_visits"] * 2 * R8 + (st["sources_above_horizon"] / max(ntimes * a.steps, 1)) \
+        spread_bytes = st["source_visits"] * 2 * R8 + (st["sources_above_horizon"] / max(my_times * a.steps, 1)) \
             * d * R8 * launches + st["spread_cells"] * 2 * R8
-        spread_s = tm["spread"] * 1e-3 * launches / timed  # all launches, from the sampled average
+        spread_s = tm["spread"] * 1e-3 * launches / timed  # all launches (level 3: timed == launches)
         spread_kernel = "k_spread2d" if coplanar else "k_spread3d"
         if coplanar and os.environ.get("FFTVIS_HIP_SPREAD_CELL", "") != "1":
             # Nufft3::launch_spread picks the channel-group lane mapping once the catalog has >= 3
@@ -298,10 +302,9 @@ def main():
             nax, nay = int(st["n2z"]) // 65536, int(st["n2z"]) % 65536
             if os.environ.get("FFTVIS_HIP_SPREAD_CELL") == "0" or nsrc >= 3 * ((nax + 7) // 8) * ((nay + 7) // 8):
                 spread_kernel = "k_spread2d_cg"
-        if a.path == "type1":
+        if a.path == "type1" and breakdown:
             # lattice path: every (source, channel) pair is an entry with its own origin and 2 w
-            # weights; timed in the extra step (event records around the launch), not in the
-            # timed region
+            # weights; timed in the extra step (event records around the launch)
             spread_kernel = "k_t1_spread"
             tpol = 4 if pol else 1
             entries = st_all["source_visits"] / tpol
@@ -312,30 +315,51 @@ def main():
             tm = dict(tm, spread=tm_all["spread"])
             timed = launches
         ach = spread_bytes / spread_s / 1e9 if spread_s > 0 else 0.0
-        # HBM traffic of the spread kernel from the committed PMC run (rocprofv3 counters cannot be
-        # read from inside this process): only for the workload that run was taken on.
-        traffic = None
+        # HBM traffic of the spread kernel from the committed PMC passes over this same command (rocprofv3
+        # counters cannot be read from inside the process): only for the workload those passes ran.
+        traffic, traffic_src = None, None
         try:
-            if a.workload == "C2" and not (a.nsrc or a.nfreq or a.ntimes):
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
-                k = pm["counters"]["c2"][spread_kernel]
+            if a.workload in ("C2", "C3") and not (a.nsrc or a.nfreq or a.ntimes) and a.upsample == 2.0 and world == 1:
+                pm = json.load(open(os.path.join(ROOT, PMC_FILE)))
+                k = pm["counters"][a.workload.lower()][spread_kernel]
                 traffic = (2 * k["FETCH_SIZE_KB_avg_per_launch"] + k["WRITE_SIZE_KB_avg_per_launch"]) * 1024
+                traffic_src = PMC_FILE + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; 2*FETCH_SIZE+WRITE_SIZE per the gfx950 note)"
         except Exception:
             traffic = None
-        l2 = max(st_all["spread_launches"], 1.0)
-        fft_bytes = st_all["fft_cells"] * 2 * R8
-        kern = {
-            "note": "per-family times from one extra single-stream step with event records around every launch",
-            "spread_ms_per_launch": (tm["spread"] / timed) if a.path == "type3" else tm_all["spread"] / l2,
-            "fft_ms_per_launch": tm_all["fft"] / l2,
-            "interp_ms_per_launch": tm_all["interp"] / l2,
-            "strengths_ms_per_launch": tm_all["strengths"] / l2,
-            "prep_ms_per_step": tm_all["prep"],
-            "launches_per_step": l2,
-            "fft_GBps": fft_bytes / max(tm_all["fft"] * 1e-3, 1e-12) / 1e9,
-            "grid": {"n2": [int(st["n2x"]), int(st["n2y"])], "active": [int(st["n2z"]) // 65536, int(st["n2z"]) % 65536]},
-            "kernel_width": int(st["w"]),
-        }
+        kern, fft = None, None
+        if breakdown:
+            l2 = max(st_all["spread_launches"], 1.0)
+            fft_bytes = st_all["fft_cells"] * 2 * R8
+            fam = ("spread", "fft", "interp", "strengths", "prep")
+            total = max(sum(tm_all[k] for k in fam), 1e-9)
+            kern = {
+                "note": "per-family times from one extra single-stream step with event records around every launch",
+                "spread_ms_per_launch": tm_all["spread"] / l2,
+                "fft_ms_per_launch": tm_all["fft"] / l2,
+                "interp_ms_per_launch": tm_all["interp"] / l2,
+                "strengths_ms_per_launch": tm_all["strengths"] / l2,
+                "prep_ms_per_step": tm_all["prep"],
+                "launches_per_step": l2,
+                "share_of_step": {k: tm_all[k] / total for k in fam},
+                "grid_top_channel": {"n2": [int(st["n2x"]), int(st["n2y"])],
+                                     "active": [int(st["n2z"]) // 65536, int(st["n2z"]) % 65536]},
+                "kernel_width": int(st["w"]),
+            }
+            if tm_all["fft"] > 0:
+                gbps = fft_bytes / (tm_all["fft"] * 1e-3) / 1e9
+                # the pruned row FFT is the largest share of the step; same accounting: algorithmic
+                # bytes of its passes over its summed pass durations (HIP events)
+                fft = {
+                    "kernel": "k_rowfft_st (x-pass + y-pass of the pruned 2-D FFT)",
+                    "bound": "hbm",
+                    "achieved": gbps,
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": gbps / HBM_PEAK_GBS,
+                    "share_of_step": tm_all["fft"] / total,
+                    "algorithmic_bytes_per_step": fft_bytes,
+                }
+        own_ms = [1e3 * t / a.steps for t in per_rank]
         res = {
             "metric": "simulated visibilities/sec (baselines x freqs x times) at eps="
                       + ("6e-8" if a.eps == 6e-8 else f"{a.eps:g}"),
@@ -344,22 +368,25 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "settle_steps": extra,  # untimed repeats beyond --warmup until 40 ms of work had run (see above)
+            "settle_steps": extra,  # untimed repeats beyond --warmup (small workloads only, see above)
             "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32" if precision == 1 else "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{a.workload}: {synth.CONFIGS[a.workload][0]}, {nsrc} sources, "
-                            f"{nfreq} freqs, {ntimes} times/GPU, {nbls} baselines, "
+                            f"{nfreq} freqs, {ntimes} times, {nbls} baselines, "
                             f"{('%d basis beams (eigenbeam path), polarized' % len(blist)) if 'beam_coefs' in cfg else 'polarized table beam' if pol else 'unpolarized Airy beam'}, "
                             f"{a.path} NUFFT eps={a.eps:g} upsampfac={st.get('upsample_used', a.upsample):g}"
                             + (" (chosen by the engine)" if a.upsample == 0 else ""),
                 "slices_per_step": nfreq * ntimes,
-                "lanes": a.lanes if a.lanes is not None else "engine default (2 pipelined lanes for small grids)",
-                "pipe": a.pipe if a.pipe is not None else 1,
+                "sharding": "one observation, (time x freq) blocks per rank: "
+                            + "; ".join(f"r{r}: t[{b[0][0].start}:{b[0][0].stop}) f[{b[0][1].start}:{b[0][1].stop})" if b else f"r{r}: -"
+                                        for r, b in enumerate(blocks)),
+                "per_rank_ms_per_step": own_ms,
+                "imbalance_max_over_mean": max(own_ms) / (sum(own_ms) / len(own_ms)),
                 "finite_output": finite,
             },
             "roofline": {
@@ -370,25 +397,16 @@ def main():
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)" if traffic else None,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": spread_bytes / launches,
                 "avg_launch_ms": tm["spread"] / timed,
                 "launches_timed": timed,
+                "launches_in_timed_region": launches,
             },
-            # the pruned row FFT is the largest share of the step; same accounting: algorithmic
-            # bytes of its passes over its summed pass durations (HIP events)
-            "roofline_fft": {
-                "kernel": "k_rowfft_st (x-pass + y-pass" + (" + k_transpose" if kern["grid"]["n2"][1] > 1024 else "") + ")",
-                "bound": "hbm",
-                "achieved": kern["fft_GBps"],
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": kern["fft_GBps"] / HBM_PEAK_GBS,
-                "share_of_step": tm_all["fft"] / max(sum(tm_all[k] for k in ("spread", "fft", "interp", "strengths", "prep")), 1e-12),
-            },
+            "roofline_fft": fft,
             "kernels": kern,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
         print(json.dumps(res))
     h.close()

@@ -28,6 +28,7 @@ SYMBOLS = {
     "fv_device_count": (c_int, [POINTER(c_int)]),
     "fv_last_error": (c_char_p, []),
     "fv_device_bytes": (c_int, [POINTER(c_int64)]),
+    "fv_device_mem_info": (c_int, [c_int, POINTER(c_int64), POINTER(c_int64)]),
     "fv_release_workspaces": (c_int, []),
     "fv_nufft3": (c_int, [c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_int, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_double,
@@ -53,6 +54,7 @@ SYMBOLS = {
     "fv_sim_set_beam_pairs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "fv_sim_set_basis": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fv_sim_set_chunking": (c_int, [c_void_p, c_int, c_double]),
     "fv_sim_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "fv_sim_sync": (c_int, [c_void_p]),
     "fv_sim_stats": (c_int, [c_void_p, c_void_p, c_int]),

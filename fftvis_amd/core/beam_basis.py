@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .beams import TabulatedBeam, describe_beam
+from .beams import TabulatedBeam, describe_beam, is_sampled_analytic, response_at
 
 _C = 299792458.0
 
@@ -71,6 +71,10 @@ def _table_on_grid(tab, za_max, az, za):
 
 def _sample_beam(beam, freq, polarized, az, za):
     """One beam on the common grid: (2, 2, nza, naz) complex Jones, or (nza, naz) real power."""
+    if is_sampled_analytic(beam):  # a third-party analytic beam answers for itself, exactly, on the grid
+        Z, A = np.meshgrid(za, az, indexing="ij")
+        r = response_at(beam, polarized, freq, A, Z)
+        return r.reshape((2, 2) + Z.shape) if polarized else r.reshape(Z.shape)
     kind = describe_beam(beam, polarized, None)
     if kind[0] == "airy":
         from scipy.special import j1

@@ -171,3 +171,48 @@ def prepare_beam_evaluation(antnums, baselines, beam_idx):
         idxs[p].append(k)
         flips[p].append(flipped)
     return pairs, idxs, flips
+
+
+def get_required_chunks(freemem: int, nax: int, nfeed: int, nant: int, nsrc: int, nbeam: int, nbeampix: int,
+                        precision: int, source_buffer: float = 1.0, nprocesses: int = 1, nfreq: int = 1) -> int:
+    """Source chunks needed to fit the per-time working set in ``freemem`` bytes of DEVICE memory.
+
+    Same contract as the reference's estimate (core/utils.py:213-285: grow ``ch`` until the sizes
+    fit, at most 100), with the arrays this engine actually allocates per time step and lane instead
+    of matvis' host arrays: compacted coordinates, the bin sort with its tabulated kernel weights
+    (16 cells wide at most) and the strengths of every transform of a frequency group; the catalog
+    (``flux`` for all ``nfreq`` channels) and the beam tables stay resident whatever ``ch`` is.
+    ``nprocesses`` counts lanes here (4 = the gang mode's two pairs, the worst case)."""
+    rsize = 4 * precision
+    csize = 2 * rsize
+    lanes = max(4, nprocesses)
+    sizes = {"a": freemem}
+    ch = 0
+    while sum(sizes.values()) >= freemem and ch < 100:
+        ch += 1
+        nchunk = int(nsrc // ch * source_buffer) + 1
+        sizes = {
+            "antpos": nant * 3 * rsize,
+            "crd_eq": 3 * nsrc * rsize,
+            "flux": nsrc * nfreq * rsize,
+            "beam": nbeampix * nfeed * nax * csize * nfreq,
+            "crd_chunk": lanes * nchunk * (5 * rsize + 4),
+            "sort_chunk": lanes * nchunk * (2 * (12 + 3 * rsize) + 8 + 3 * 16 * rsize),
+            "strengths_chunk": lanes * nchunk * nfeed * nfeed * nfreq * csize,
+        }
+    return ch
+
+
+def get_desired_chunks(freemem: int, min_chunks: int, beam_list, nax: int, nfeed: int, nant: int, nsrc: int,
+                       precision: int, source_buffer: float = 1.0, nfreq: int = 1):
+    """(nchunks, sources per chunk): reference core/utils.py:287-356 over the device estimate above."""
+    nbeampix = 0
+    for beam in beam_list:
+        inner = getattr(beam, "beam", beam)
+        data = getattr(inner, "data_array", getattr(inner, "data", None))
+        if data is not None:
+            nbeampix += int(np.shape(data)[-2]) * int(np.shape(data)[-1])
+    need = get_required_chunks(freemem, nax, nfeed, nant, nsrc, len(beam_list), nbeampix, precision,
+                               source_buffer, nfreq=nfreq)
+    nchunks = max(1, min(max(int(min_chunks), need), max(int(nsrc), 1)))
+    return nchunks, int(np.ceil(max(nsrc, 1) / nchunks))

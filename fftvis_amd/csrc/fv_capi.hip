@@ -4,6 +4,7 @@
 #include "../../include/fftvis_hip.h"
 #include "fv_sim.h"
 
+#include <algorithm>
 #include <mutex>
 
 namespace fv {
@@ -70,6 +71,44 @@ static NufftWorkspace<T> *&workspace_slot() {
     static thread_local NufftWorkspace<T> *ws = nullptr;
     return ws;
 }
+// Every live workspace, whichever thread made it, so that fv_release_workspaces() can free those of
+// threads that have exited (their thread_local pointer died with them, the device memory did not).
+// A thread's slot holds an index into this registry rather than ownership.
+template <typename T>
+struct WorkspaceRegistry {
+    std::mutex mu;
+    std::vector<NufftWorkspace<T> *> all;
+    static WorkspaceRegistry &get() {
+        static WorkspaceRegistry *r = new WorkspaceRegistry();  // never destroyed: see the note above
+        return *r;
+    }
+    void add(NufftWorkspace<T> *w) {
+        std::lock_guard<std::mutex> g(mu);
+        all.push_back(w);
+    }
+    bool remove(NufftWorkspace<T> *w) {  // true if it was still registered (i.e. nobody freed it yet)
+        std::lock_guard<std::mutex> g(mu);
+        auto it = std::find(all.begin(), all.end(), w);
+        if (it == all.end()) return false;
+        all.erase(it);
+        return true;
+    }
+    bool contains(NufftWorkspace<T> *w) {
+        std::lock_guard<std::mutex> g(mu);
+        return std::find(all.begin(), all.end(), w) != all.end();
+    }
+    void drain() {
+        std::vector<NufftWorkspace<T> *> take;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            take.swap(all);
+        }
+        for (NufftWorkspace<T> *w : take) {
+            (void)hipSetDevice(w->device);
+            delete w;
+        }
+    }
+};
 static size_t workspace_limit() {
     const char *e = std::getenv("FFTVIS_HIP_HANDLE_CACHE_BYTES");
     return e ? (size_t)std::atof(e) : ((size_t)2 << 30);
@@ -78,8 +117,10 @@ template <typename T>
 static void drop_workspace() {
     NufftWorkspace<T> *&ws = workspace_slot<T>();
     if (ws) {
-        (void)hipSetDevice(ws->device);
-        delete ws;
+        if (WorkspaceRegistry<T>::get().remove(ws)) {  // else another thread's fv_release_workspaces() freed it
+            (void)hipSetDevice(ws->device);
+            delete ws;
+        }
         ws = nullptr;
     }
 }
@@ -101,6 +142,7 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
         return;
     }
     NufftWorkspace<T> *&slot = workspace_slot<T>();
+    if (slot && !WorkspaceRegistry<T>::get().contains(slot)) slot = nullptr;  // freed by another thread's release
     if (slot && (slot->device != device || slot->dim != dim || slot->eps != eps || slot->sigma != upsampfac))
         drop_workspace<T>();
     if (!slot) {
@@ -110,6 +152,7 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
         slot->eps = eps;
         slot->sigma = upsampfac;
         FV_HIP(hipStreamCreateWithFlags(&slot->st, hipStreamNonBlocking));
+        WorkspaceRegistry<T>::get().add(slot);
     }
     struct DropOnError {  // an exception may leave the plan half configured
         bool armed = true;
@@ -163,6 +206,10 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
                               hipMemcpyDeviceToHost, st));
         FV_HIP(hipStreamSynchronize(st));
         FV_HIP(hipGetLastError());
+        // finufft rejects points it cannot place; here they were clamped to an edge cell and counted
+        const int noob = plan.out_of_box_count();
+        FV_REQUIRE(noob == 0, std::to_string(noob) + " source coordinates are NaN or outside the box of the "
+                                                       "finite ones: the transform is invalid");
         guard.armed = fv::dev_bytes_held().load() > workspace_limit();
         return;
     }
@@ -278,14 +325,27 @@ extern "C" {
 
 int fv_version(void) { return 100; /* 0.1.0 */ }
 int fv_release_workspaces(void) {
-    return guarded([&] {
-        drop_workspace<double>();
-        drop_workspace<float>();
+    return guarded([&] {  // every thread's: call while no fv_nufft3 / fv_nudft3_direct is in flight
+        workspace_slot<double>() = nullptr;
+        workspace_slot<float>() = nullptr;
+        WorkspaceRegistry<double>::get().drain();
+        WorkspaceRegistry<float>::get().drain();
     });
 }
 int fv_device_bytes(int64_t *bytes) {
     if (bytes) *bytes = (int64_t)fv::dev_bytes_held().load();
     return bytes ? 0 : 1;
+}
+
+int fv_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes) {
+    return guarded([&] {
+        FV_REQUIRE(free_bytes && total_bytes, "null output");
+        FV_HIP(hipSetDevice(device));
+        size_t f = 0, t = 0;
+        FV_HIP(hipMemGetInfo(&f, &t));
+        *free_bytes = (int64_t)f;
+        *total_bytes = (int64_t)t;
+    });
 }
 
 int fv_device_count(int *count) {
@@ -429,6 +489,9 @@ int fv_sim_set_beam_pairs(fv_sim *h, int npairs, const int *bi, const int *bj, c
 int fv_sim_set_basis(fv_sim *h, int nant, int nbasis, int nfreq, const void *coefs, const int *ant1,
                      const int *ant2) {
     FV_SIM_CALL(FV_REQUIRE(nant >= 1 && nbasis >= 1 && coefs && ant1 && ant2, "bad basis"); h->impl->set_basis(nant, nbasis, nfreq, coefs, ant1, ant2));
+}
+int fv_sim_set_chunking(fv_sim *h, int nchunks, double source_buffer) {
+    FV_SIM_CALL(h->impl->set_chunking(nchunks, source_buffer));
 }
 int fv_sim_run(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int out_on_device) {
     FV_SIM_CALL(FV_REQUIRE(out, "null output"); h->impl->run(t0, t1, f0, f1, out, out_on_device));

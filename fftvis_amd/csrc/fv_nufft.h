@@ -179,7 +179,7 @@ __global__ void k_bin_count(int64_t M, const int *__restrict__ Mp, const T *__re
                             int *__restrict__ counts, int *__restrict__ n_oob) {
     // M = capacity (array stride, launch bound); *Mp = live count when it is only known on device
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (Mp ? (int64_t)*Mp : M)) return;
+    if (j >= (Mp ? min((int64_t)*Mp, M) : M)) return;
     const T *src[3] = {x, y, z};
     int tl[3] = {0, 0, 0};
     bool oob = false;
@@ -262,7 +262,7 @@ __global__ void k_bin_scatter(int64_t M, const int *__restrict__ Mp, int dim,
                               int *__restrict__ cursor, int *__restrict__ i0s, T *__restrict__ fs,
                               int *__restrict__ perm, T *__restrict__ kw, int w, T beta, T c4) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (Mp ? (int64_t)*Mp : M)) return;
+    if (j >= (Mp ? min((int64_t)*Mp, M) : M)) return;
     int t = tile_of[j];
     int pos = bin_start[t] + atomicAdd(&cursor[t], 1);
     for (int d = 0; d < dim; ++d) {
@@ -305,7 +305,7 @@ __global__ void k_load_strengths(int64_t M, const int *__restrict__ Mp, int ntra
                                  double btc1, double btc2, const double *__restrict__ scale,
                                  cplx<T> *__restrict__ cs) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= (Mp ? (int64_t)*Mp : M)) return;
+    if (p >= (Mp ? min((int64_t)*Mp, M) : M)) return;
     const double h[3] = {h0, h1, h2}, btc[3] = {btc0, btc1, btc2};
     const int na[3] = {na0, na1, na2};
     double dot = 0.0;  // btc . x'
@@ -1593,6 +1593,7 @@ class Nufft3 {
     DevBuf i0u, fu, tile_of, binmeta, bin_start, i0s, fs, perm, kw, scan_tot, scan_off, scan_tot2, scan_off2;
     const int *Mp = nullptr;   // device-side live source count (optional)
     int *oob_ptr = nullptr;
+    int *err_oob = nullptr;    // owner's sticky counter of clamped / NaN sources (else the plan's own, reset per sort)
     DevBuf dec[3], tw[3];
     DevBuf buf0, buf1;  // ping-pong: A -> (x-pass) B -> (transpose) Bt -> (y-pass) Ct
     DevBuf strengths;   // [M][ntrans] sorted order
@@ -1713,6 +1714,7 @@ class Nufft3 {
         bin_start.reserve(sizeof(int) * (nb + 1));
         binmeta.reserve(sizeof(int) * (2 * (size_t)(nb + 1) + 1));  // counts | cursor | oob
         int *counts_p = binmeta.as<int>(), *cursor_p = counts_p + (nb + 1), *oob_p = cursor_p + (nb + 1);
+        if (err_oob) oob_p = err_oob;
         oob_ptr = oob_p;
         FV_HIP(hipMemsetAsync(binmeta.p, 0, sizeof(int) * (2 * (size_t)(nb + 1) + 1), stream));
         BinArgs a{};

@@ -34,14 +34,16 @@ struct Rot9 {
 
 // Pass 1: above-horizon flag count per 256-source block (select_chunk's up > 0,
 // cpu_simulate.py:940-946 via matvis).
+// The kernels work on the source range [off, off + n) of the catalog (eq is (3, stride) SoA): one
+// source chunk of the reference's `for chunk in range(nchunks)` loop (cpu_simulate.py:939).
 template <typename T>
-__global__ void k_horizon_count(int64_t nsrc, const T *__restrict__ eq, Rot9 rt,
+__global__ void k_horizon_count(int64_t n, int64_t stride, int64_t off, const T *__restrict__ eq, Rot9 rt,
                                 int *__restrict__ block_counts) {
     __shared__ int wsum[4];
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool up = false;
-    if (j < nsrc) {
-        double ex = eq[j], ey = eq[nsrc + j], ez = eq[2 * nsrc + j];
+    if (j < n) {
+        double ex = eq[off + j], ey = eq[stride + off + j], ez = eq[2 * stride + off + j];
         up = rt.m[6] * ex + rt.m[7] * ey + rt.m[8] * ez > 0.0;
     }
     unsigned long long b = __ballot(up);
@@ -53,16 +55,18 @@ __global__ void k_horizon_count(int64_t nsrc, const T *__restrict__ eq, Rot9 rt,
 // Pass 2: stable compaction + everything that depends only on (time, source):
 //   topo = R_t eq;  az, za in the UN-rotated ENU frame (cpu_simulate.py:957-959, matvis
 //   enu_to_az_za "uvbeam");  x = 2 pi R_plane topo (cpu_simulate.py:961-967).
+// cap = capacity of the compacted arrays (chunk size x source_buffer): sources beyond it are not
+// stored and counted in *overflow (matvis raises likewise when its above-horizon buffer is too small).
 template <typename T>
-__global__ void k_horizon_compact(int64_t nsrc, const T *__restrict__ eq, Rot9 rt, Rot9 rp,
-                                  const int *__restrict__ block_off, T *__restrict__ xyz,
+__global__ void k_horizon_compact(int64_t nsrc, int64_t stride, int64_t off, const T *__restrict__ eq, Rot9 rt,
+                                  Rot9 rp, const int *__restrict__ block_off, T *__restrict__ xyz,
                                   int64_t cap, T *__restrict__ az, T *__restrict__ za,
-                                  int *__restrict__ src_idx) {
+                                  int *__restrict__ src_idx, int *__restrict__ overflow) {
     __shared__ int wsum[4];
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double e = 0, n = 0, u = -1;
     if (j < nsrc) {
-        double ex = eq[j], ey = eq[nsrc + j], ez = eq[2 * nsrc + j];
+        double ex = eq[off + j], ey = eq[stride + off + j], ez = eq[2 * stride + off + j];
         e = rt.m[0] * ex + rt.m[1] * ey + rt.m[2] * ez;
         n = rt.m[3] * ex + rt.m[4] * ey + rt.m[5] * ez;
         u = rt.m[6] * ex + rt.m[7] * ey + rt.m[8] * ez;
@@ -76,6 +80,10 @@ __global__ void k_horizon_compact(int64_t nsrc, const T *__restrict__ eq, Rot9 r
     for (int i = 0; i < wv; ++i) base += wsum[i];
     if (!up) return;
     const int64_t pos = base + __popcll(b & ((1ull << lane) - 1ull));
+    if (pos >= cap) {
+        atomicAdd(overflow, 1);
+        return;
+    }
     const double lsqr = n * n + e * e;
     const double zeta = sqrt(fmax(0.0, 1.0 - lsqr));
     double azv = 0.5 * M_PI - atan2(e, n);
@@ -87,7 +95,7 @@ __global__ void k_horizon_compact(int64_t nsrc, const T *__restrict__ eq, Rot9 r
     xyz[pos] = (T)(twopi * (rp.m[0] * e + rp.m[1] * n + rp.m[2] * u));
     xyz[cap + pos] = (T)(twopi * (rp.m[3] * e + rp.m[4] * n + rp.m[5] * u));
     xyz[2 * cap + pos] = (T)(twopi * (rp.m[6] * e + rp.m[7] * n + rp.m[8] * u));
-    src_idx[pos] = (int)j;
+    src_idx[pos] = (int)(off + j);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,7 +480,7 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const in
                             const double *__restrict__ freqs, const int *__restrict__ i0s,
                             const T *__restrict__ fs, cplx<T> *__restrict__ cs) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)*Mp * a.nfg) return;
+    if (idx >= min((int64_t)*Mp, a.M) * a.nfg) return;
     const int64_t p = idx / a.nfg;
     const int fgi = (int)(idx % a.nfg);
     const int fidx = a.f_first + fgi;
@@ -537,7 +545,7 @@ __global__ void k_t1_bin(T1Args a, const int *__restrict__ Mp, const T *__restri
                          const int *__restrict__ bin_start, int *__restrict__ cursor,
                          unsigned char *__restrict__ recs, T beta, T c4, int *__restrict__ overflow) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)*Mp * a.nfg) return;
+    if (idx >= min((int64_t)*Mp, a.cap) * a.nfg) return;
     const int64_t p = idx / a.nfg;
     const int f = (int)(idx % a.nfg);
     int i0x, i0y;
@@ -570,13 +578,13 @@ __global__ void k_t1_bin(T1Args a, const int *__restrict__ Mp, const T *__restri
 }
 
 template <typename T, int ORD>
-__global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent,
+__global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent, int64_t ecap,
                                const unsigned char *__restrict__ recs, int rec, const int *__restrict__ src_idx,
                                const T *__restrict__ az, const T *__restrict__ za,
                                const void *__restrict__ flux, const double *__restrict__ freqs,
                                cplx<T> *__restrict__ cs) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= *nent) return;
+    if (e >= min((int64_t)*nent, ecap)) return;  // entries beyond the capacity were dropped (and flagged) by k_t1_bin
     const int id = reinterpret_cast<const int *>(recs + e * rec)[2];
     const int tp = a.polarized ? 4 : 1;
     strength_eval<T, ORD>(a, id / a.nfg, a.f_first + id % a.nfg, cplx<double>{1.0, 0.0}, src_idx, az, za,
@@ -606,7 +614,8 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
     const int byl = ((by << BINLOG) - w + 1 + T1_PAD) >> BINLOG, byh = ((by << BINLOG) + 7 + T1_PAD) >> BINLOG;
     for (int yb = byl; yb <= byh; ++yb) {
         const int rowb = (f * a.nb1 + yb) * a.nb1;
-        const int s0 = bin_start[rowb + bxl], s1 = bin_start[rowb + bxh + 1];
+        // (entries beyond the capacity were dropped and flagged by k_t1_bin: stay inside the buffers)
+        const int s0 = bin_start[rowb + bxl], s1 = (int)min((int64_t)bin_start[rowb + bxh + 1], a.ecap);
         for (int base = s0; base < s1; base += SPREAD_CHUNK) {
             const int n = min(SPREAD_CHUNK, s1 - base);
             for (int e = lane; e < n * TP; e += 64) s_str[wave][e / TP][e % TP] = cs[(int64_t)base * TP + e];
@@ -652,7 +661,7 @@ __global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int P, int cnt,
                           const int *__restrict__ blx, const int *__restrict__ bly, int64_t N,
                           const int *__restrict__ bl_idx, const signed char *__restrict__ flip,
                           const T *__restrict__ dec, cplx<T> *__restrict__ out,
-                          int64_t out_fg_stride, int64_t p0, int64_t p1, int64_t p2, int64_t p3) {
+                          int64_t out_fg_stride, int64_t p0, int64_t p1, int64_t p2, int64_t p3, bool accumulate) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * nfg) return;
     const int f = (int)(idx / N);
@@ -667,7 +676,8 @@ __global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int P, int cnt,
         // rows (lx) are stored residue-major (DimGeom::out_pos), the contiguous ly in natural order
         cplx<T> v = X[(((int64_t)f * tp + r) * ((int64_t)P * cnt) + out_pos(lx, P, cnt)) * no + ly];
         v = {v.re * d, fl ? -v.im * d : v.im * d};
-        out[(int64_t)f * out_fg_stride + pol[r] + k] = v;
+        cplx<T> &o = out[(int64_t)f * out_fg_stride + pol[r] + k];
+        o = accumulate ? cplx<T>{o.re + v.re, o.im + v.im} : v;
     }
 }
 
@@ -726,6 +736,7 @@ struct SimBase {
                                 const int *idx, const signed char *flipped) = 0;
     virtual void set_basis(int nant, int K, int nfreq, const void *coefs, const int *ant1,
                            const int *ant2) = 0;
+    virtual void set_chunking(int nchunks, double source_buffer) = 0;
     virtual void run(int t0, int t1, int f0, int f1, void *out, int out_on_device) = 0;
     virtual void sync() = 0;
     virtual void stats(double *v, int n) = 0;
@@ -780,6 +791,12 @@ class Sim : public SimBase {
         double btc[3], B[3];
     };
     std::vector<Pair> pairs;
+    // Source-axis chunking (reference cpu_simulate.py:939: `for chunk in range(nchunks)` inside the time
+    // loop, visibilities accumulate with +=): per-time scratch is sized by one chunk, the catalog stays
+    // resident.  source_buffer = fraction of a chunk the above-horizon arrays can hold (matvis sizes its
+    // buffers the same way and raises when a chunk has more sources above the horizon).
+    int src_chunks = 1;
+    double source_buffer = 1.0;
     int nbasis = 0;  // > 0: eigenbeam mode
     // type-1 (lattice) mode
     bool type1 = false;
@@ -808,11 +825,16 @@ class Sim : public SimBase {
     hipStream_t prep_stream = nullptr;  // low priority: per-time preparation of the next step
     hipEvent_t ev_start = nullptr;
     DevBuf d_out, d_mhist;
+    // sticky device-side error counters, read at every host synchronisation point (check_errors):
+    // [0] sources outside the planned box or with NaN coordinates (k_bin_count), [1] type-1 entries
+    // dropped because the entry buffers overflowed (k_t1_bin), [2] above-horizon sources that did not
+    // fit source_buffer x chunk size (k_horizon_compact)
+    DevBuf d_err;
     std::vector<std::pair<int, double>> mhist_log;  // (time index, transforms spread) per processed time
 
     // stats / timing
-    double st[11] = {0};
-    int timing_level = 0;  // 1: spread only (events ride on the dispatches), 2: every kernel family
+    double st[12] = {0};
+    int timing_level = 0;  // 1: spread only, sampled (events ride on the dispatches); 3: the same on every spread launch; 2: every kernel family
     int64_t targets_serial = 1;  // version of the device-side target data (baselines, frequencies, pair lists)
     struct Ev {
         hipEvent_t a, b;
@@ -842,7 +864,7 @@ class Sim : public SimBase {
         return ev_used++;
     }
     size_t ev_begin(int kind, hipStream_t st_) {
-        if (timing_level < 2) return (size_t)-1;
+        if (timing_level != 2) return (size_t)-1;
         if (ev_used == ev_pool.size()) {
             Ev e;
             FV_HIP(hipEventCreate(&e.a));
@@ -886,6 +908,8 @@ class Sim : public SimBase {
             FV_HIP(hipEventCreateWithFlags(&L.heavy_done, hipEventDisableTiming));
         }
         FV_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+        d_err.reserve(4 * sizeof(int));
+        FV_HIP(hipMemsetAsync(d_err.p, 0, 4 * sizeof(int), stream));
         for (int i = 0; i < 9; ++i) rplane.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
     }
     ~Sim() override {
@@ -927,6 +951,7 @@ class Sim : public SimBase {
         upload(d_flux, flux, (pol_sky ? sizeof(T) * 8 : sizeof(T)) * (size_t)n * nfreq, on_device);
     }
     void set_times(int ntimes, const double *rot) override {
+        mhist_log.clear();  // entries index the previous configuration's time axis
         ntimes_topo = 0;
         rots.resize(ntimes);
         for (int i = 0; i < ntimes; ++i) std::memcpy(rots[i].m, rot + 9 * i, 9 * sizeof(double));
@@ -934,6 +959,7 @@ class Sim : public SimBase {
     void set_topo(int ntimes, int64_t n, const void *topo, int on_device) override {
         FV_HIP(hipSetDevice(device));
         FV_REQUIRE(n == nsrc, "topo source count != catalog (set_sources first)");
+        mhist_log.clear();
         ntimes_topo = ntimes;
         rots.assign(ntimes, Rot9{{1, 0, 0, 0, 1, 0, 0, 0, 1}});
         upload(d_topo, topo, sizeof(T) * 3 * (size_t)n * ntimes, on_device);
@@ -1091,16 +1117,26 @@ class Sim : public SimBase {
         set_beam_pairs((int)bi.size(), bi.data(), bj.data(), off.data(), all.data(), fl.data());
     }
 
+    void set_chunking(int nchunks, double sb) override {
+        FV_REQUIRE(nchunks >= 1, "nchunks must be >= 1");
+        FV_REQUIRE(sb > 0.0 && sb <= 1.0, "source_buffer must be in (0, 1]");
+        src_chunks = nchunks;
+        source_buffer = sb;
+    }
+
     // rotate -> horizon cut -> az/za -> 2 pi R topo for time ti; returns the device address of the
     // live above-horizon count (it never visits the host inside the loop).
-    const int *horizon_step(Lane &L, int ti, int64_t cap, int nblk, hipStream_t on = nullptr) {
+    // The step works on the catalog range [s0, s0 + sn) (one source chunk); cap = capacity of the
+    // compacted arrays; hslot = where the live count is kept for stats().
+    const int *horizon_step(Lane &L, int ti, int64_t cap, int nblk, hipStream_t on, int64_t s0, int64_t sn,
+                            int64_t hslot) {
         hipStream_t stream = on ? on : L.stream;
         DevBuf &d_blockcnt = L.d_blockcnt, &d_blockoff = L.d_blockoff, &d_scan_tot = L.d_scan_tot,
                &d_scan_off = L.d_scan_off, &d_xyz = L.d_xyz, &d_az = L.d_az, &d_za = L.d_za,
                &d_srcidx = L.d_srcidx;
         // either R_t . eq on the fly, or topocentric vectors the caller computed
         const T *vec = ntimes_topo ? d_topo.as<T>() + (size_t)ti * 3 * nsrc : d_eq.as<T>();
-        hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
+        hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, sn, nsrc, s0, vec,
                            rots[ti], d_blockcnt.as<int>());
         if (nblk <= 4096) {
             hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream,
@@ -1116,11 +1152,11 @@ class Sim : public SimBase {
             hipLaunchKernelGGL(k_scan_add, dim3(nb2), dim3(1024), 0, stream,
                                d_blockoff.as<int>(), d_scan_off.as<int>(), nblk);
         }
-        hipLaunchKernelGGL(k_horizon_compact<T>, dim3(nblk), dim3(256), 0, stream, nsrc, vec,
+        hipLaunchKernelGGL(k_horizon_compact<T>, dim3(nblk), dim3(256), 0, stream, sn, nsrc, s0, vec,
                            rots[ti], rplane, d_blockoff.as<int>(), d_xyz.as<T>(), cap,
-                           d_az.as<T>(), d_za.as<T>(), d_srcidx.as<int>());
+                           d_az.as<T>(), d_za.as<T>(), d_srcidx.as<int>(), d_err.as<int>() + 2);
         const int *Mp = d_blockoff.as<int>() + nblk;
-        FV_HIP(hipMemcpyAsync(d_mhist.as<int>() + ti, Mp, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        FV_HIP(hipMemcpyAsync(d_mhist.as<int>() + hslot, Mp, sizeof(int), hipMemcpyDeviceToDevice, stream));
         return Mp;
     }
 
@@ -1157,8 +1193,10 @@ class Sim : public SimBase {
         if (polarized)
             for (int r = 0; r < 4; ++r) pol_off[r] = (int64_t)((r % 2) * 2 + r / 2) * nbls;
 
-        const int64_t cap = std::max<int64_t>(nsrc, 1);
-        const int nblk = (int)cdiv(cap, 256);
+        const int nch = (int)std::max<int64_t>(1, std::min<int64_t>(src_chunks, nsrc));
+        const int64_t csz = std::max<int64_t>(cdiv(nsrc, nch), 1);
+        const int64_t cap = std::max<int64_t>((int64_t)std::ceil(csz * source_buffer), 1);
+        const int nblk = (int)cdiv(csz, 256);
         for (Lane &Lr : lanes) {
             Lr.d_xyz.reserve(sizeof(T) * 3 * cap);
             Lr.d_az.reserve(sizeof(T) * cap);
@@ -1167,13 +1205,18 @@ class Sim : public SimBase {
             Lr.d_blockcnt.reserve(sizeof(int) * (nblk + 1));
             Lr.d_blockoff.reserve(sizeof(int) * (nblk + 1));
         }
-        d_mhist.reserve(sizeof(int) * rots.size());
+        d_mhist.reserve(sizeof(int) * rots.size() * std::max(1, src_chunks));
         // frequencies per batch: bounded by entries (~1.3 per (source, freq)) and by grid bytes
         const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
         const double budget = eb ? std::atof(eb) : 8.0 * 1024 * 1024 * 1024;
         const double plane_bytes = 2.0 * g.n2 * (double)g.n2 * tpol * sizeof(cplx<T>);
-        int nfb = (int)std::max(1.0, std::min({(double)nf, budget / plane_bytes, 24.0e6 / (1.3 * cap)}));
-        const int64_t ecap = (int64_t)(1.3 * cap * nfb) + 4096;
+        // entries per live (source, frequency) pair: 1 + the periodic images of footprints that cross an
+        // edge of the n2 x n2 plane -- (1 + (w + 1) / n2)^2 on average for uniformly placed sources (1.52
+        // at w = 16 on the smallest, 64-cell planes); 5 % head-room on top, and a catalog that still
+        // overflows (sources piled on a plane edge) fails the run (t1 overflow flag), never silently
+        const double img = (1.0 + (ker.w + 1.0) / g.n2) * (1.0 + (ker.w + 1.0) / g.n2) * 1.05;
+        int nfb = (int)std::max(1.0, std::min({(double)nf, budget / plane_bytes, 24.0e6 / (img * cap)}));
+        const int64_t ecap = (int64_t)(img * cap * nfb) + 4096;
         const int nbins = nfb * nb1 * nb1;
         const int rec = t1_record_bytes(ker.w, sizeof(T));
         // Pipelined like the type-3 loop: the entry sort of unit (time, batch) u+1 (three kernels over
@@ -1181,8 +1224,8 @@ class Sim : public SimBase {
         // strengths / spread / FFT / pick of unit u; two sets of sort buffers and two sets of
         // per-time source arrays alternate.
         const char *ep = std::getenv("FFTVIS_HIP_PIPE");
-        const int nunits = nt * (int)cdiv(nf, nfb);
-        const bool pipe = timing_level < 2 && nunits > 1 && !(ep && std::atoi(ep) == 0);
+        const int nunits = nt * nch * (int)cdiv(nf, nfb);
+        const bool pipe = timing_level != 2 && nunits > 1 && !(ep && std::atoi(ep) == 0);
         const hipStream_t ps = pipe ? prep_stream : stream;
         for (int sset = 0; sset < (pipe ? 2 : 1); ++sset) {
             t1_meta[sset].reserve(sizeof(int) * (2 * (size_t)(nbins + 1) + 2));
@@ -1198,16 +1241,18 @@ class Sim : public SimBase {
         }
         int unit = 0;
 
-        for (int ti = t0; ti < t1; ++ti) {
-            if (nsrc == 0) continue;
-            const int li = pipe ? (ti - t0) % 2 : 0;
+        for (int tc = 0; tc < nt * nch; ++tc) {  // (time, source chunk), chunks innermost (cpu_simulate.py:936-939)
+            const int ti = t0 + tc / nch, chunk = tc % nch;
+            const int64_t s0 = (int64_t)chunk * csz, sn = std::min<int64_t>(csz, nsrc - s0);
+            if (nsrc == 0 || sn <= 0) continue;
+            const int li = pipe ? tc % 2 : 0;
             Lane &L = lanes[li];
             DevBuf &d_xyz = L.d_xyz, &d_az = L.d_az, &d_za = L.d_za, &d_srcidx = L.d_srcidx;
             if (pipe && lane_pending[li]) FV_HIP(hipStreamWaitEvent(ps, L.done, 0));  // its strengths are done
             size_t e0 = ev_begin(TM_PREP, ps);
-            const int *Mp = horizon_step(L, ti, cap, nblk, ps);
+            const int *Mp = horizon_step(L, ti, cap, nblk, ps, s0, sn, (int64_t)ti * nch + chunk);
             ev_end(e0, ps);
-            mhist_log.push_back({ti, 0.0});
+            mhist_log.push_back({ti * nch + chunk, 0.0});
             const size_t hist_slot = mhist_log.size() - 1;
             for (int fa = f0; fa < f1; fa += nfb, ++unit) {
                 const int nfg = std::min(nfb, f1 - fa);
@@ -1223,7 +1268,7 @@ class Sim : public SimBase {
                 a.ecap = ecap;
                 a.rec = rec;
                 const int nbn = nfg * nb1 * nb1;
-                int *counts_p = meta.as<int>(), *cursor_p = counts_p + (nbins + 1), *ovf_p = cursor_p + (nbins + 1);
+                int *counts_p = meta.as<int>(), *cursor_p = counts_p + (nbins + 1), *ovf_p = d_err.as<int>() + 1;
                 if (pipe && set_pending[ss]) FV_HIP(hipStreamWaitEvent(ps, lanes[ss].heavy_done, 0));
                 size_t e1 = ev_begin(TM_PREP, ps);
                 FV_HIP(hipMemsetAsync(meta.p, 0, sizeof(int) * (2 * (size_t)(nbins + 1) + 2), ps));
@@ -1259,7 +1304,7 @@ class Sim : public SimBase {
                     sa.bj = desc(pr.bj);
                     hipLaunchKernelGGL((beam_order == 3 ? k_t1_strengths<T, 3> : k_t1_strengths<T, 1>),
                                        dim3(cdiv(ecap, 256)), dim3(256), 0, stream,
-                                       sa, nent, (const unsigned char *)recs.as<unsigned char>(), rec,
+                                       sa, nent, ecap, (const unsigned char *)recs.as<unsigned char>(), rec,
                                        d_srcidx.as<int>(),
                                        d_az.as<T>(), d_za.as<T>(), d_flux.p, d_freqs.as<double>(),
                                        t1_cs.as<cplx<T>>());
@@ -1296,7 +1341,7 @@ class Sim : public SimBase {
                                        pr.trivial ? (const signed char *)nullptr
                                                   : (const signed char *)pr.flip->template as<signed char>(),
                                        (const T *)t1_dec.as<T>(), obase, (int64_t)nt * per_tf, pol_off[0],
-                                       pol_off[1], pol_off[2], pol_off[3]);
+                                       pol_off[1], pol_off[2], pol_off[3], chunk > 0);
                     ev_end(e5, stream);
                     st[4] += (double)pr.n * nplanes;
                     st[6] = g.n2;
@@ -1318,6 +1363,7 @@ class Sim : public SimBase {
             FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
             FV_HIP(hipStreamSynchronize(stream));
             if (timing_level) ev_collect();
+            check_errors();
         }
     }
 
@@ -1374,6 +1420,7 @@ class Sim : public SimBase {
                    "engine not fully configured");
         FV_REQUIRE(0 <= t0 && t0 <= t1 && t1 <= (int)rots.size(), "time range");
         FV_REQUIRE(0 <= f0 && f0 <= f1 && f1 <= (int)freqs.size(), "freq range");
+        if (mhist_log.size() > 65536) mhist_log.clear();  // nobody asked for the statistics of those runs
         FV_REQUIRE((int)freqs.size() == nfreq_cat, "flux frequency axis != freqs");
         for (const Beam &b : beams) FV_REQUIRE(b.kind >= 0, "beam not set");
         if (type1) {
@@ -1393,7 +1440,7 @@ class Sim : public SimBase {
         }
         // Baselines not covered by any pair stay zero (reference zero-initialises, :909-911).
         FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
-        d_mhist.reserve(sizeof(int) * rots.size());
+        d_mhist.reserve(sizeof(int) * rots.size() * std::max(1, src_chunks));
 
         double xc[3], X[3];
         source_box(xc, X);
@@ -1401,8 +1448,12 @@ class Sim : public SimBase {
         if (polarized)
             for (int r = 0; r < 4; ++r) pol_off[r] = (int64_t)((r % 2) * 2 + r / 2) * nbls;
 
-        const int64_t cap = std::max<int64_t>(nsrc, 1);
-        const int nblk = (int)cdiv(cap, 256);
+        // source chunks: chunk c covers catalog sources [c csz, min(nsrc, (c + 1) csz)); the compacted
+        // per-time arrays hold source_buffer x csz sources
+        const int nch = (int)std::max<int64_t>(1, std::min<int64_t>(src_chunks, nsrc));
+        const int64_t csz = std::max<int64_t>(cdiv(nsrc, nch), 1);
+        const int64_t cap = std::max<int64_t>((int64_t)std::ceil(csz * source_buffer), 1);
+        const int nblk = (int)cdiv(csz, 256);
 
         // Upsampling factor "auto" (fv_sim_create upsampfac = 0): sigma = 1.25 shrinks the fine grid and
         // all FFT work by (2 / 1.25)^D at the price of a kernel 13-14 cells wide instead of 9 (every
@@ -1470,7 +1521,7 @@ class Sim : public SimBase {
         int nlanes = el ? std::atoi(el)
                         : (cells_top * sizeof(cplx<T>) * max_ntrans <= 1.5 * 1024 * 1024 * 1024 ? 2 : 1);
         nlanes = std::max(1, std::min(2, std::min(nlanes, nt)));
-        if (timing_level >= 2) nlanes = 1;  // per-family event brackets only make sense on one stream
+        if (timing_level == 2) nlanes = 1;  // per-family event brackets only make sense on one stream
         // Two lanes, pipelined (default): every big kernel runs on the main (high-priority) stream,
         // one time step after the other, so kernel durations stay uncontended; the dozen tiny
         // latency-bound preparation kernels of step t+1 (rotation, horizon cut, bin sort, weight
@@ -1484,7 +1535,7 @@ class Sim : public SimBase {
         // latency chains and tails.  Two pairs of lanes alternate, so that the preparation of the next
         // pair still runs beside this pair's big kernels.  FFTVIS_HIP_GANG=0 turns it off.
         const char *eg = std::getenv("FFTVIS_HIP_GANG");
-        const bool gang = pipe && D == 2 && nt >= 2 && timing_level < 2 && !(eg && std::atoi(eg) == 0);
+        const bool gang = pipe && D == 2 && nt >= 2 && timing_level != 2 && !(eg && std::atoi(eg) == 0);
         const int nlanes_used = gang ? 4 : nlanes;
         // Lane scratch outlives a run: with a device-side output buffer nothing synchronises between
         // two fv_sim_run calls, so the "last big kernels of this lane" events carry over (the next
@@ -1504,6 +1555,7 @@ class Sim : public SimBase {
             Lane &L = lanes[li];
             if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma)
                 L.nufft.reset(new Nufft3<T>(D, eps, sigma, li < 2 ? L.stream : stream));
+            L.nufft->err_oob = d_err.as<int>();
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
             L.d_az.reserve(sizeof(T) * cap);
             L.d_za.reserve(sizeof(T) * cap);
@@ -1527,11 +1579,18 @@ class Sim : public SimBase {
         for (const Pair &pr : pairs) active_pairs += pr.n > 0;
         const char *erh = std::getenv("FFTVIS_HIP_RIDE_EVENT");
         const bool ride_heavy_done = !(erh && std::atoi(erh) == 0) && groups.size() == 1 && active_pairs == 1;
-        for (int ti = t0; ti < t1;) {
-            const int nm = gang && ti + 1 < t1 ? 2 : 1;  // time steps in this unit
-            const int tu = ti;
-            ti += nm;
-            if (nsrc == 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
+        for (int tnext = t0, ch = 0; tnext < t1;) {
+            // units: (one or two time steps) x source chunk, chunks innermost (cpu_simulate.py:936-939)
+            const int nm = gang && tnext + 1 < t1 ? 2 : 1;  // time steps in this unit
+            const int tu = tnext;
+            const int64_t s0 = (int64_t)ch * csz, sn = std::min<int64_t>(csz, nsrc - s0);
+            const bool accumulate = ch > 0;  // later chunks add to the first one's visibilities (:1024,1069)
+            const int chunk = ch;
+            if (++ch == nch) {
+                ch = 0;
+                tnext += nm;
+            }
+            if (nsrc == 0 || sn <= 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
             const int64_t unit = lane_serial++;
             Lane *Ls[2];
             if (gang) {
@@ -1558,7 +1617,7 @@ class Sim : public SimBase {
                 Lane &L = *Ls[m];
                 Nufft3<T> *nufft = L.nufft.get();
                 nufft->stream = ps;
-                Mps[m] = horizon_step(L, tu + m, cap, nblk, ps);
+                Mps[m] = horizon_step(L, tu + m, cap, nblk, ps, s0, sn, (int64_t)(tu + m) * nch + chunk);
                 if (pipe) {  // the first (group, pair)'s bin sort belongs to the preparation as well
                     for (const Pair &pr : pairs) {
                         if (pr.n == 0 || groups.empty()) continue;
@@ -1568,7 +1627,7 @@ class Sim : public SimBase {
                         nufft->set_geometry(xc, X, pr.btc, pr.B, smax0);
                         nufft->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
                                            D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mps[m]);
-                        L.binned_ti = tu + m;
+                        L.binned_ti = (tu + m) * nch + chunk;
                         L.binned_serial = nufft->geom_serial;
                         // ... and so do its strengths (beam x coherency, pre-phase): they depend on this
                         // step's sources only, not on the previous step's big kernels
@@ -1579,7 +1638,7 @@ class Sim : public SimBase {
                     }
                 }
                 hist_slot[m] = mhist_log.size();
-                mhist_log.push_back({tu + m, 0.0});
+                mhist_log.push_back({(tu + m) * nch + chunk, 0.0});
             }
             ev_end(e0, ps);
             if (pipe) {
@@ -1602,10 +1661,10 @@ class Sim : public SimBase {
                         // ---- geometry + bin sort (skipped when unchanged since last set) -------
                         size_t e1 = ev_begin(TM_PREP, ls);
                         nf_->set_geometry(xc, X, pr.btc, pr.B, smax);
-                        if (L.binned_ti != tu + m || L.binned_serial != nf_->geom_serial || nf_->M != M) {
+                        if (L.binned_ti != (tu + m) * nch + chunk || L.binned_serial != nf_->geom_serial || nf_->M != M) {
                             nf_->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
                                              D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mps[m]);
-                            L.binned_ti = tu + m;
+                            L.binned_ti = (tu + m) * nch + chunk;
                             L.binned_serial = nf_->geom_serial;
                         }
                         ev_end(e1, ls);
@@ -1614,7 +1673,7 @@ class Sim : public SimBase {
                             launch_strengths(L, pr, fa, nfg, M, Mps[m], ls);
                     }
                     // ---- NUFFT ----------------------------------------------------------
-                    if (timing_level >= 2 || (timing_level == 1 && sampled)) {
+                    if (timing_level >= 2 || (timing_level == 1 && sampled)) {  // 2 and 3: every launch
                         const size_t e3 = ev_slot(TM_SPREAD);
                         nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b, mate);
                         spread_timed += 1;
@@ -1655,7 +1714,7 @@ class Sim : public SimBase {
                                   pr.trivial ? nullptr : pr.idx->template as<int>(),
                                   pr.trivial ? nullptr : pr.flip->template as<signed char>(),
                                   d_freqs.as<double>() + fa, nfg, tpol, obase + (int64_t)m * per_tf,
-                                  (int64_t)nt * per_tf, 1, pol_off, false, nbasis ? &bt : nullptr);
+                                  (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr);
                     ev_end(e5, ls);
                     st[4] += (double)pr.n * ntrans * nm;
                     st[6] = nufft->geo.d[0].n2;
@@ -1677,6 +1736,7 @@ class Sim : public SimBase {
             FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
             FV_HIP(hipStreamSynchronize(stream));
             if (timing_level) ev_collect();
+            check_errors();
         }
     }
 
@@ -1725,25 +1785,46 @@ class Sim : public SimBase {
         return d;
     }
 
+    // Called where the host has just synchronised with the main stream: a run that met bad input fails
+    // here instead of returning finite, wrong visibilities (finufft rejects such points up front).
+    void check_errors() {
+        int e[4] = {0, 0, 0, 0};
+        FV_HIP(hipMemcpyAsync(e, d_err.p, sizeof(e), hipMemcpyDeviceToHost, stream));
+        FV_HIP(hipStreamSynchronize(stream));
+        if (!e[0] && !e[1] && !e[2]) return;
+        FV_HIP(hipMemsetAsync(d_err.p, 0, sizeof(e), stream));
+        if (e[2])
+            throw Error(FV_ERR_ARG, "more sources above the horizon than source_buffer allows (" +
+                                        std::to_string(e[2]) + " did not fit): increase source_buffer");
+        if (e[1])
+            throw Error(FV_ERR_INTERNAL, "type-1 entry buffers overflowed (" + std::to_string(e[1]) +
+                                             " entries dropped): the visibilities of this run are invalid");
+        throw Error(FV_ERR_ARG, std::to_string(e[0]) +
+                                    " source positions were NaN or outside the unit sphere's box (non-unit "
+                                    "coord_mgr vectors?): the visibilities of this run are invalid");
+    }
     void sync() override {
         FV_HIP(hipSetDevice(device));
         FV_HIP(hipStreamSynchronize(stream));
         if (timing_level) ev_collect();
+        check_errors();
     }
     void stats(double *v, int n) override {
         // above-horizon counts were left on the device during run(); fold them in now
         if (!mhist_log.empty()) {
             FV_HIP(hipSetDevice(device));
-            std::vector<int> mh(rots.size());
+            std::vector<int> mh(d_mhist.cap / sizeof(int));
             FV_HIP(hipMemcpyAsync(mh.data(), d_mhist.p, sizeof(int) * mh.size(), hipMemcpyDeviceToHost, stream));
             FV_HIP(hipStreamSynchronize(stream));
             for (const auto &e : mhist_log) {
+                if (e.first < 0 || e.first >= (int)mh.size()) continue;
                 st[5] += mh[e.first];
                 st[2] += (double)mh[e.first] * e.second;
+                st[11] = std::max(st[11], (double)mh[e.first]);
             }
             mhist_log.clear();
         }
-        for (int i = 0; i < n && i < 11; ++i) v[i] = st[i];
+        for (int i = 0; i < n && i < 12; ++i) v[i] = st[i];
     }
     void reset_stats() override {
         for (double &x : st) x = 0;

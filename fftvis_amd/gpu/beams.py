@@ -8,7 +8,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import _lib
-from ..core.beams import BeamEvaluator, checked_spline_order, describe_beam
+from ..core.beams import BeamEvaluator, checked_spline_order, describe_beam, is_sampled_analytic
 from ..core.utils import prepare_beam_evaluation as _prepare_beam_evaluation
 
 
@@ -52,7 +52,11 @@ class GPUBeamEvaluator(BeamEvaluator):
         az = np.ascontiguousarray(az, dtype=rdt)
         za = np.ascontiguousarray(za, dtype=rdt)
         n = az.size
-        desc = describe_beam(beam, polarized, None)
+        if is_sampled_analytic(beam):  # third-party analytic beam: a one-frequency table of its own response
+            desc = describe_beam(beam, polarized, np.atleast_1d(float(freq)), order=3)
+            order, freq_index = 3, 0
+        else:
+            desc = describe_beam(beam, polarized, None)
         out = np.empty((2, 2, n) if polarized else (n,), dtype=cdt)
         L = _lib.lib()
         _lib.require_gpu()

@@ -21,7 +21,7 @@ import numpy as np
 from .. import _lib
 from ..core import utils
 from ..core.antenna_gridding import check_antpos_griddability
-from ..core.beams import checked_spline_order, describe_beam
+from ..core.beams import checked_spline_order, describe_beam, feed_index, is_sampled_analytic
 from ..core.coords import SiderealRotation, eq_unit_vectors, julian_dates
 from ..core.simulate import SimulationEngine, default_accuracy_dict
 
@@ -132,10 +132,12 @@ class SimHandle:
         _lib.check(self._L.fv_sim_set_array_type1(self._h, _lib.ptr(B), self.nbls, _lib.ptr(b),
                                                   int(n_modes)))
 
-    def set_beams(self, beam_list, freqs, order: int = 1):
+    def set_beams(self, beam_list, freqs, order: int = 1, use_feed: str = "x"):
         _lib.check(self._L.fv_sim_set_nbeams(self._h, len(beam_list)))
+        if beam_list and all(is_sampled_analytic(b) for b in beam_list):
+            order = 3  # only sampled analytic beams: their tables are ours to lay out (cubic, 0.5-degree nodes)
         for i, beam in enumerate(beam_list):
-            d = describe_beam(beam, self.polarized, np.asarray(freqs, dtype=float))
+            d = describe_beam(beam, self.polarized, np.asarray(freqs, dtype=float), use_feed, order)
             if d[0] == "airy":
                 _lib.check(self._L.fv_sim_set_beam_airy(self._h, i, d[1]))
             else:
@@ -160,6 +162,10 @@ class SimHandle:
             idx, flp = np.zeros(1, np.int32), np.zeros(1, np.int8)
         _lib.check(self._L.fv_sim_set_beam_pairs(self._h, len(pairs), _lib.ptr(bi), _lib.ptr(bj),
                                                  _lib.ptr(off), _lib.ptr(idx), _lib.ptr(flp)))
+
+    def set_chunking(self, nchunks: int = 1, source_buffer: float = 1.0):
+        """Source chunks per time step and the above-horizon buffer fraction (fv_sim_set_chunking)."""
+        _lib.check(self._L.fv_sim_set_chunking(self._h, int(nchunks), float(source_buffer)))
 
     def set_basis(self, beam_coefs, ant1_idxs, ant2_idxs):
         c = np.ascontiguousarray(beam_coefs, dtype=self.cdt)
@@ -186,10 +192,10 @@ class SimHandle:
         _lib.check(self._L.fv_sim_sync(self._h))
 
     def stats(self):
-        v = np.zeros(11)
-        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 11))
+        v = np.zeros(12)
+        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 12))
         keys = ["spread_launches", "spread_cells", "source_visits", "fft_cells", "interp_items",
-                "sources_above_horizon", "n2x", "n2y", "n2z", "w", "upsample_used"]
+                "sources_above_horizon", "n2x", "n2y", "n2z", "w", "upsample_used", "max_above_horizon"]
         return dict(zip(keys, v))
 
     def reset_stats(self):
@@ -246,7 +252,7 @@ class GPUSimulationEngine(SimulationEngine):
         interpolation_function: str = "az_za_map_coordinates",
         nprocesses: int | None = 1,
         nthreads: int | None = None,
-        coord_method: str = "SiderealRotation",
+        coord_method: str = "CoordinateRotationERFA",
         coord_method_params: dict | None = None,
         force_use_ray: bool = False,
         force_use_type3: bool = False,
@@ -258,6 +264,8 @@ class GPUSimulationEngine(SimulationEngine):
         coord_mgr=None,
         time_idx: slice = slice(None),
         freq_idx: slice = slice(None),
+        use_feed: str = "x",
+        catalog_device=None,
     ) -> np.ndarray:
         """Simulate visibilities on the GPU.
 
@@ -267,23 +275,55 @@ class GPUSimulationEngine(SimulationEngine):
         * like the reference, a flat array whose antennas sit on a lattice takes the type-1 path
           unless ``force_use_type3`` (cpu_simulate.py:634-637); eigenbeam runs always use type 3
           here;
-        * ``coord_method`` defaults to this package's ``SiderealRotation`` because matvis /
-          ERFA are not importable here; a caller holding a matvis coordinate manager can pass
-          it as ``coord_mgr`` and its per-time topocentric vectors are used verbatim;
-        * ``nprocesses/nthreads/force_use_ray/trace_mem/nchunks/source_buffer`` are CPU
-          scheduling / memory knobs with no effect on one GPU (``n_threads`` "not used in GPU
-          implementation", reference gpu/nufft.py:38);
+        * ``coord_method``: matvis / ERFA astrometry is not part of this backend.  A caller holding a
+          matvis coordinate manager passes it as ``coord_mgr`` and its per-time topocentric vectors
+          (``rotate(ti)`` -> ``all_coords_topo``) are used verbatim, streamed to the device one time
+          block at a time.  Without one, ``"CoordinateRotationERFA"`` (the reference's default, and
+          ours) and ``"CoordinateRotationAstropy"`` RAISE; the mean-sidereal rotation of
+          ``core/coords.py`` (no precession / nutation / aberration: ~0.35 deg off ICRS positions at
+          2025 epochs) runs only when asked for by name, ``coord_method="SiderealRotation"``;
+        * ``nchunks`` splits the source axis exactly like the reference's chunk loop
+          (cpu_simulate.py:939,1024,1069): every time step processes the catalog in ``nchunks`` pieces
+          whose visibilities accumulate on the device; ``source_buffer`` sizes the above-horizon
+          arrays of a piece and a piece that overflows them raises, as matvis does.  On top of that the
+          engine walks the time axis in blocks when the output block would not fit in free device
+          memory;
+        * ``nprocesses/nthreads/force_use_ray/trace_mem/enable_memory_monitor`` are CPU scheduling /
+          tracing knobs with no meaning on one GPU (``n_threads`` "not used in GPU implementation",
+          reference gpu/nufft.py:38): accepted, unused;
         * ``beam_coefs`` (eigenbeams): like the reference, the (l, k) term reuses V_kl transposed
           (exact for real-valued basis beams, reference cpu_simulate.py:464-468);
         * ``beam_spline_opts``: order 1 (bilinear, also when None) or 3 (cubic B-spline; ``kx/ky``
-          of ``az_za_simple`` are read the same way); other orders raise NotImplementedError;
+          of ``az_za_simple`` are read the same way -- both interpolation functions of the reference
+          are regular-grid splines of that order and map onto the same device interpolant); other
+          orders raise NotImplementedError;
+        * ``use_feed`` (extra; the reference's wrapper applies it before the engine,
+          wrapper.py:278-279): the feed whose power pattern an unpolarized run takes from an E-field beam;
         * ``upsample_factor``: 2 (default, as the reference) or 1.25 are used as given; ``None`` /
           ``"auto"`` (extra) lets the engine pick per run -- 1.25 when eps >= 1e-8 (fp32: 1e-4) and
           the fine grid is large (HERA-350 class arrays: ~2x faster), else 2;
         * ``time_idx`` / ``freq_idx`` (extra) restrict the run to a block, which is how ranks
-          shard a simulation across GPUs.
+          shard a simulation across GPUs; ``catalog_device`` (extra; ``parallel.DeviceCatalog``) is a
+          catalog already resident on this GPU -- e.g. received by an RCCL broadcast -- used instead
+          of ``ra / dec / fluxes`` (which may then be None).
         """
         beam_order = checked_spline_order(beam_spline_opts)
+        if interpolation_function not in ("az_za_map_coordinates", "az_za_simple"):
+            raise ValueError(f"unknown interpolation_function {interpolation_function!r}")
+        feed_index(use_feed)  # 'x' or 'y', else ValueError
+        nchunks = int(nchunks)
+        if nchunks < 1:
+            raise ValueError("nchunks must be >= 1")
+        if not 0.0 < float(source_buffer) <= 1.0:
+            raise ValueError("source_buffer must be in (0, 1]")
+        if coord_mgr is None and coord_method != "SiderealRotation":
+            if coord_method in ("CoordinateRotationERFA", "CoordinateRotationAstropy"):
+                raise ValueError(
+                    f"coord_method={coord_method!r} needs matvis / ERFA astrometry, which the gpu backend does "
+                    "not carry: pass the matvis coordinate manager as coord_mgr= (its per-time topocentric "
+                    "vectors are used verbatim), or ask for the mean-sidereal approximation by name with "
+                    "coord_method='SiderealRotation' (no precession / nutation / aberration)")
+            raise ValueError(f"unknown coord_method {coord_method!r}")
         freqs = np.asarray(freqs)
         nfreqs, ntimes, nbeam, nant = np.size(freqs), len(julian_dates(times)), len(beam_list), len(ants)
         real_dtype = np.float32 if precision == 1 else np.float64
@@ -297,17 +337,24 @@ class GPUSimulationEngine(SimulationEngine):
                 f"(eps={eps:g} was asked for); use upsample_factor=2 or 'auto' for tighter tolerances.",
                 RuntimeWarning, stacklevel=2)
         # precision = 1 rounds ra/dec/freqs to float32 first (reference cpu_simulate.py:601-606)
-        ra = np.asarray(ra).astype(real_dtype)
-        dec = np.asarray(dec).astype(real_dtype)
+        if catalog_device is None:
+            ra = np.asarray(ra).astype(real_dtype)
+            dec = np.asarray(dec).astype(real_dtype)
+            nsrc = int(ra.size)
+        else:
+            nsrc = int(catalog_device.nsrc)
         freqs = freqs.astype(real_dtype)
         ants = {k: np.asarray(v) for k, v in ants.items()}
 
         beam_idx = utils.validate_beam_idx(beam_idx, beam_coefs, nbeam, nant)
         if baselines is None:
             baselines = [red[0] for red in utils.get_pos_reds(ants, include_autos=True)]
-        coherency, polarized_sky = utils.prepare_source_catalog(np.asarray(fluxes), polarized)
-        if coherency.shape[0] != ra.size or coherency.shape[1] != nfreqs:
-            raise ValueError("fluxes must have shape (nsources, nfreqs[, 4])")
+        if catalog_device is None:
+            coherency, polarized_sky = utils.prepare_source_catalog(np.asarray(fluxes), polarized)
+            if coherency.shape[0] != nsrc or coherency.shape[1] != nfreqs:
+                raise ValueError("fluxes must have shape (nsources, nfreqs[, 4])")
+        elif catalog_device.nfreq != nfreqs or (catalog_device.polarized_sky and not polarized):
+            raise ValueError("catalog_device does not match freqs / polarized")
 
         # lattice arrays -> type 1 (reference cpu_simulate.py:634-637, 661-681)
         antvecs = np.array([ants[a] for a in ants], dtype=real_dtype)
@@ -341,33 +388,46 @@ class GPUSimulationEngine(SimulationEngine):
         key, h = _acquire_handle(self.device, precision, eps, upsample_factor, polarized)
         ok = False
         try:
-            h.set_sources(eq_unit_vectors(ra.astype(float), dec.astype(float)), coherency, polarized_sky)
-            if coord_mgr is not None:
-                h.set_topo(_topo_from_coord_mgr(coord_mgr, ntimes))
-            elif coord_method in ("SiderealRotation", "CoordinateRotationERFA", "CoordinateRotationAstropy"):
-                if coord_method != "SiderealRotation":
-                    logger.warning(
-                        "%s needs matvis/ERFA, which this build does not import; using the "
-                        "sidereal-rotation approximation (pass coord_mgr= for exact astrometry)",
-                        coord_method,
-                    )
-                h.set_times(SiderealRotation(times, telescope_loc).matrices())
+            if catalog_device is None:
+                h.set_sources(eq_unit_vectors(ra.astype(float), dec.astype(float)), coherency, polarized_sky)
             else:
-                raise ValueError(f"unknown coord_method {coord_method!r}")
+                h.set_sources_device(nsrc, nfreqs, catalog_device.eq.data_ptr(), catalog_device.flux.data_ptr(),
+                                     catalog_device.polarized_sky)
+            if coord_mgr is None:
+                h.set_times(SiderealRotation(times, telescope_loc).matrices())
             h.set_freqs(freqs.astype(float))
             if is_gridded:
                 logger.info("Using gridded coordinates for the array. Type 1 transform will be used.")
                 h.set_array_type1(basis_matrix.astype(float), bls_int, n_modes)
             else:
                 h.set_array(R.astype(float), bls.astype(float), is_coplanar)
-            h.set_beams(beam_list, freqs.astype(float), beam_order)
+            h.set_beams(beam_list, freqs.astype(float), beam_order, use_feed)
+            h.set_chunking(min(nchunks, max(nsrc, 1)), float(source_buffer))
             if use_basis:
                 h.set_basis(beam_coefs, ant1_idxs, ant2_idxs)
             else:
                 h.set_beam_pairs(pairs, pair_idx, pair_flip)
             t0, t1, _ = time_idx.indices(ntimes)
             f0, f1, _ = freq_idx.indices(nfreqs)
-            vis = h.run(t0, t1, f0, f1)
+            # Walk the time axis in blocks whose output fits comfortably in free device memory (the
+            # reference holds the whole (nt, nbls, nfeeds, nfeeds, nf) block in host RAM,
+            # cpu_simulate.py:909-911); a coordinate manager's vectors are streamed block by block
+            # instead of being stacked for all times on the host.
+            nblk_t = _time_block(self.device, t1 - t0, f1 - f0, len(baselines), polarized, precision,
+                                 nsrc if coord_mgr is not None else 0)
+            if coord_mgr is not None:
+                coord_mgr.setup()
+            if nblk_t >= t1 - t0 and coord_mgr is None:
+                vis = h.run(t0, t1, f0, f1)
+            else:
+                vis = np.empty(h.out_shape(t1 - t0, f1 - f0), dtype=complex_dtype)
+                for tb in range(t0, t1, max(nblk_t, 1)):
+                    te = min(t1, tb + max(nblk_t, 1))
+                    if coord_mgr is not None:
+                        h.set_topo(_topo_from_coord_mgr(coord_mgr, range(tb, te)))
+                        vis[:, tb - t0:te - t0] = h.run(0, te - tb, f0, f1)
+                    else:
+                        vis[:, tb - t0:te - t0] = h.run(tb, te, f0, f1)
             ok = True
         finally:
             if ok:
@@ -387,12 +447,24 @@ class GPUSimulationEngine(SimulationEngine):
         return np.moveaxis(final, 0, 2)[:, :, None, None, :]
 
 
-def _topo_from_coord_mgr(coord_mgr, ntimes):
-    """Per-time topocentric unit vectors of every source from a matvis-style manager
-    (``setup()``, ``rotate(ti)``, attribute ``all_coords_topo``)."""
-    coord_mgr.setup()
+def _topo_from_coord_mgr(coord_mgr, time_indices):
+    """Topocentric unit vectors (len(time_indices), 3, nsrc) of every source at the given time indices
+    from a matvis-style manager (``rotate(ti)``, attribute ``all_coords_topo``; ``setup()`` was called)."""
     out = []
-    for ti in range(ntimes):
+    for ti in time_indices:
         coord_mgr.rotate(ti)
         out.append(np.array(coord_mgr.all_coords_topo, dtype=float))
     return np.stack(out)
+
+
+def _time_block(device, nt, nf, nbls, polarized, precision, nsrc_topo=0):
+    """Time steps per fv_sim_run: as many as keep the output block under 45 % of free device memory
+    (and, with a coordinate manager, the staged vectors of a block under 2 GiB)."""
+    free = ctypes.c_int64(0)
+    total = ctypes.c_int64(0)
+    _lib.check(_lib.lib().fv_device_mem_info(int(device), ctypes.byref(free), ctypes.byref(total)))
+    per_time = max(1, nf * nbls * (4 if polarized else 1) * 8 * precision)
+    n = max(1, int(0.45 * free.value // per_time))
+    if nsrc_topo:
+        n = min(n, max(1, int(2**31 // (3 * nsrc_topo * 4 * precision))))
+    return min(n, max(nt, 1))

@@ -3,8 +3,9 @@
 The reference shards the same way over Ray workers (src/fftvis/cpu/cpu_simulate.py:711-713,
 800-847 with ``get_task_chunks``, core/utils.py:122-187): blocks are disjoint, so there is no
 data-path collective.  Communication here is (1) one broadcast of the source catalog from rank 0
-(``torch.distributed`` -- RCCL over xGMI with the "nccl" backend, gloo on CPU) and (2) an optional
-gather of the finished blocks to rank 0.
+(``torch.distributed`` -- RCCL over xGMI with the "nccl" backend, gloo on CPU), received straight
+into device memory and handed to the engine as device pointers, and (2) an optional gather of the
+finished blocks to rank 0.
 """
 
 from __future__ import annotations
@@ -18,12 +19,13 @@ def shard_blocks(world: int, nfreqs: int, ntimes: int):
     """Per rank, the list of (time_slice, freq_slice) blocks it owns; together they cover the
     (ntimes, nfreqs) plane exactly once.
 
-    Follows the reference's chunker.  When it decides the job is too small to split
-    (ntasks < 2 * world) rank 0 takes everything, like the reference falling back to one process
-    (core/utils.py:160-162).  For awkward shapes the chunker can emit more chunks than workers
+    Follows the reference's chunker (equal COUNTS of slices).  When it decides the job is too small to
+    split (ntasks < 2 * world) rank 0 takes everything, like the reference falling back to one
+    process (core/utils.py:160-162).  For awkward shapes the chunker can emit more chunks than workers
     (e.g. 3 workers, 7 channels, 5 times -> 7 chunks); the reference's ``zip`` over workers
     (cpu_simulate.py:800) would silently drop the surplus, here they are dealt round-robin so
-    nothing is left uncomputed."""
+    nothing is left uncomputed.  The GPU engine's cost per slice grows like nu^2, so GPU runs use
+    ``shard_blocks_weighted`` instead."""
     _, fchunks, tchunks, _, _ = get_task_chunks(world, nfreqs, ntimes)
     blocks = [[] for _ in range(world)]
     for i, (fc, tc) in enumerate(zip(fchunks, tchunks)):
@@ -34,10 +36,69 @@ def shard_blocks(world: int, nfreqs: int, ntimes: int):
     return blocks
 
 
+def slice_cost(freqs, fixed: float = 0.1) -> np.ndarray:
+    """Relative cost of one (time, channel) slice on the GPU engine: the fine grid has
+    ~(2 sigma b_max nu / c)^2 cells, and spread output, FFT passes and gather input all scale with
+    it, so cost ~ nu^2 (HERA's 100-200 MHz band: the top channel costs 4x the bottom one); ``fixed``
+    (in units of the top channel's grid cost) stands for the per-slice work that does not.  Measured
+    on C3: 3.06 s per 128-channel step, of which the top 64 channels take ~66 %."""
+    f = np.abs(np.asarray(freqs, dtype=float))
+    return (f / f.max()) ** 2 + fixed
+
+
+def _cut_by_weight(w: np.ndarray, parts: int):
+    """Cut range(len(w)) into ``parts`` consecutive non-empty runs of (nearly) equal total weight."""
+    n = len(w)
+    parts = max(1, min(parts, n))
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    edges = [0]
+    for k in range(1, parts):
+        target = c[-1] * k / parts
+        e = int(np.searchsorted(c, target))
+        if e > 0 and abs(c[e - 1] - target) <= abs(c[min(e, n)] - target):
+            e -= 1
+        e = max(edges[-1] + 1, min(e, n - (parts - k)))  # every run keeps at least one element
+        edges.append(e)
+    edges.append(n)
+    return [(edges[i], edges[i + 1]) for i in range(parts)]
+
+
+def shard_blocks_weighted(world: int, freqs, ntimes: int):
+    """One (time_slice, freq_slice) block per rank (empty list for surplus ranks), TIME-MAJOR and
+    balanced by ``slice_cost``: the ranks form an (a x b) grid, a time parts x b frequency parts
+    with a b <= world; time parts have (nearly) equal length -- rotation, horizon cut and az/za are
+    per-time work that then amortises over a rank's whole frequency range -- and
+    the frequency cuts equalise the summed nu^2 cost, not the channel count.  Among the factorisations
+    the one with the smallest largest block wins; ties go to more time parts."""
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=float))
+    nf = len(freqs)
+    w = slice_cost(freqs)
+    best = None
+    for a in range(1, min(world, max(ntimes, 1)) + 1):
+        b = min(world // a, nf)
+        if b < 1:
+            continue
+        tparts = _cut_by_weight(np.ones(max(ntimes, 1)), a)
+        fparts = _cut_by_weight(w, b)
+        worst = max(t1 - t0 for t0, t1 in tparts) * max(w[f0:f1].sum() for f0, f1 in fparts)
+        key = (worst, -a)
+        if best is None or key < best[0]:
+            best = (key, tparts, fparts)
+    _, tparts, fparts = best
+    blocks = [[] for _ in range(world)]
+    r = 0
+    for t0, t1 in tparts:
+        for f0, f1 in fparts:
+            if ntimes > 0 and t1 > t0 and f1 > f0:
+                blocks[r].append((slice(t0, t1), slice(f0, f1)))
+            r += 1
+    return blocks
+
+
 def broadcast_catalog(ra, dec, fluxes, src: int = 0, device=None):
     """Broadcast (ra, dec, fluxes) from ``src`` to every rank; non-source ranks pass None.
-    Returns numpy arrays (CPU group) -- for device-resident hand-over use bench.py's pattern of
-    broadcasting device tensors and ``SimHandle.set_sources_device``."""
+    Returns numpy arrays (host copies; for the device-resident hand-over see
+    ``broadcast_catalog_device``)."""
     import torch
     import torch.distributed as dist
 
@@ -60,17 +121,71 @@ def broadcast_catalog(ra, dec, fluxes, src: int = 0, device=None):
     return tuple(out)
 
 
-def simulate_sharded(compute_block, nfreqs: int, ntimes: int, gather_to: int | None = 0):
+class DeviceCatalog:
+    """A source catalog resident on this rank's GPU in the engine's layout: ``eq`` (3, nsrc) equatorial
+    unit vectors and ``flux`` (nsrc, nfreq) real / (nsrc, nfreq, 2, 2) complex coherency (already x0.5,
+    reference cpu/utils.py:26-80), as torch tensors of the run's precision.  ``GPUSimulationEngine.simulate``
+    takes it as ``catalog_device=`` and hands the pointers to ``fv_sim_set_sources(on_device=1)``."""
+
+    def __init__(self, eq, flux, polarized_sky: bool):
+        self.eq, self.flux, self.polarized_sky = eq, flux, bool(polarized_sky)
+        self.nsrc, self.nfreq = int(eq.shape[1]), int(flux.shape[1])
+
+
+def broadcast_catalog_device(ra, dec, fluxes, polarized: bool, precision: int, device, src: int = 0,
+                             via_host: bool = False) -> DeviceCatalog:
+    """Rank ``src`` prepares the catalog (``prepare_source_catalog``, unit vectors), every rank receives
+    it INTO DEVICE MEMORY with one broadcast per array -- RCCL over xGMI under the "nccl" backend; with a
+    CPU group (gloo rehearsal on a one-GPU box, ``via_host=True``) through a host staging copy.  The only
+    collective of a sharded run (24 B/source + 8 nf B/source, 2 GB at C4)."""
+    import torch
+    import torch.distributed as dist
+
+    from .core.coords import eq_unit_vectors
+    from .core.utils import prepare_source_catalog
+
+    rank = dist.get_rank()
+    rdt = torch.float32 if precision == 1 else torch.float64
+    cdt = torch.complex64 if precision == 1 else torch.complex128
+    meta = [None]
+    if rank == src:
+        coh, pol_sky = prepare_source_catalog(np.asarray(fluxes), polarized)
+        meta = [(int(len(ra)), tuple(coh.shape), bool(pol_sky))]
+    dist.broadcast_object_list(meta, src=src)
+    nsrc, fshape, pol_sky = meta[0]
+    fdt = cdt if pol_sky else rdt
+    if rank == src:
+        rr = np.asarray(ra).astype(np.float32 if precision == 1 else np.float64).astype(float)
+        dd = np.asarray(dec).astype(np.float32 if precision == 1 else np.float64).astype(float)
+        eq = torch.from_numpy(eq_unit_vectors(rr, dd)).to(device, rdt)
+        flux = torch.from_numpy(np.ascontiguousarray(coh)).to(device, fdt)
+    else:
+        eq = torch.empty((3, nsrc), dtype=rdt, device=device)
+        flux = torch.empty(fshape, dtype=fdt, device=device)
+    for t in (eq, flux):
+        if via_host:
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    return DeviceCatalog(eq, flux, pol_sky)
+
+
+def simulate_sharded(compute_block, nfreqs: int, ntimes: int, gather_to: int | None = 0, blocks=None):
     """Run ``compute_block(time_slice, freq_slice) -> ndarray`` (final layout, leading axes
     (nf_here, nt_here)) on each of this rank's blocks; optionally gather and assemble on
-    ``gather_to``.
+    ``gather_to``.  ``blocks`` = per-rank block lists (default: the reference's count-based chunker).
 
     Returns the assembled (nfreqs, ntimes, ...) array on ``gather_to`` (or this rank's
     [(block, array), ...] list when ``gather_to`` is None), None elsewhere."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    blocks = shard_blocks(world, nfreqs, ntimes)
+    if blocks is None:
+        blocks = shard_blocks(world, nfreqs, ntimes)
     parts = [(blk, compute_block(*blk)) for blk in blocks[rank]]
     if gather_to is None:
         return parts
@@ -84,3 +199,35 @@ def simulate_sharded(compute_block, nfreqs: int, ntimes: int, gather_to: int | N
         for (tsl, fsl), p in plist:
             vis[fsl, tsl] = p  # reference: vis[tc][..., fc] = future (cpu_simulate.py:846-847)
     return vis
+
+
+def simulate_vis_sharded(device, gather_to: int | None = 0, via_host: bool = False, **kw):
+    """``simulate_vis`` across the ranks of the initialised process group, one GPU per rank.
+
+    Rank 0's ``ra / dec / fluxes`` are broadcast into every rank's device memory
+    (``broadcast_catalog_device``); every other argument must be the same on all ranks (they are small:
+    array, beams, frequencies, times).  Each rank simulates its cost-balanced block
+    (``shard_blocks_weighted``) through ``GPUSimulationEngine.simulate(time_idx=, freq_idx=)`` on
+    ``device`` (its local GPU index); blocks are disjoint, so nothing is reduced -- rank ``gather_to``
+    assembles them like the reference's ``vis[tc][..., fc] = future`` (cpu_simulate.py:843-847)."""
+    import torch
+
+    from .core.coords import julian_dates
+    from .wrapper import create_simulation_engine
+
+    beam = kw.pop("beam")
+    kw["beam_list"] = list(beam) if isinstance(beam, (list, tuple)) else [beam]
+    polarized, precision = bool(kw.get("polarized", False)), int(kw.get("precision", 2))
+    cat = broadcast_catalog_device(kw.pop("ra", None), kw.pop("dec", None), kw.pop("fluxes", None), polarized,
+                                   precision, torch.device("cuda", int(device)), via_host=via_host)
+    freqs = np.asarray(kw["freqs"])
+    ntimes = len(julian_dates(kw["times"]))
+    engine = create_simulation_engine("gpu", device=int(device))
+
+    def compute_block(tsl, fsl):
+        return engine.simulate(ra=None, dec=None, fluxes=None, catalog_device=cat, time_idx=tsl, freq_idx=fsl, **kw)
+
+    import torch.distributed as dist
+
+    return simulate_sharded(compute_block, len(freqs), ntimes, gather_to,
+                            blocks=shard_blocks_weighted(dist.get_world_size(), freqs, ntimes))

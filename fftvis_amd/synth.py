@@ -144,6 +144,8 @@ def make_config(name: str, seed: int = 0, nsrc=None, nfreq=None, ntimes=None):
         ants=ants, fluxes=flux, ra=ra, dec=dec, freqs=freqs, times=times, beam=beam,
         telescope_loc=(HERA_LAT, HERA_LON), baselines=all_cross_baselines(ants), polarized=pol,
         precision=2, eps=6e-8, force_use_type3=True,  # the benchmark path is the type-3 NUFFT
+        # the documented stand-in for matvis/ERFA astrometry, by name (the engine refuses to fall back silently)
+        coord_method="SiderealRotation",
     )
     cfg.update(extra)
     return cfg

@@ -11,7 +11,8 @@ from __future__ import annotations
 import numpy as np
 
 from .core.simulate import SimulationEngine, default_accuracy_dict
-from .core.utils import validate_beam_idx
+from .core.beams import feed_index
+from .core.utils import get_desired_chunks, validate_beam_idx
 
 
 def create_beam_evaluator(backend: str = "gpu", **kwargs):
@@ -60,7 +61,7 @@ def simulate_vis(
     interpolation_function: str = "az_za_map_coordinates",
     nprocesses: int | None = 1,
     nthreads: int | None = None,
-    coord_method: str = "SiderealRotation",
+    coord_method: str = "CoordinateRotationERFA",
     coord_method_params: dict | None = None,
     force_use_type3: bool = False,
     force_use_ray: bool = False,
@@ -74,7 +75,14 @@ def simulate_vis(
     coord_mgr=None,
 ) -> np.ndarray:
     """Visibilities (nfreqs, ntimes, nbls) or (nfreqs, ntimes, 2, 2, nbls); arguments as the
-    reference's ``simulate_vis`` (wrapper.py:85-238)."""
+    reference's ``simulate_vis`` (wrapper.py:85-238).
+
+    ``max_memory`` / ``min_chunks`` / ``source_buffer`` act as in the reference (wrapper.py:292-302),
+    against DEVICE memory: the source axis is cut into at least ``min_chunks`` pieces, more if the
+    per-time working set would not fit in min(max_memory, free device memory).  ``use_feed`` picks the
+    feed of an E-field beam whose power an unpolarized run uses (wrapper.py:278-279).  ``coord_method``
+    defaults to the reference's "CoordinateRotationERFA", which this backend only honours through
+    ``coord_mgr=``; see ``GPUSimulationEngine.simulate``."""
     if eps is None:
         eps = default_accuracy_dict[precision]  # wrapper.py:241-242
     ants = {k: np.array(v) for k, v in ants.items()}
@@ -84,7 +92,18 @@ def simulate_vis(
         raise ValueError(
             "Basis decomposition is not compatible with unpolarized simulations. Set polarized=True to use beam_coefs."
         )
+    feed_index(use_feed)  # 'x' or 'y'
+    nax = nfeed = 2 if polarized else 1
     engine = create_simulation_engine(backend=backend, device=device)
+    # wrapper.py:292-302 with device memory in place of host RAM
+    from . import _lib
+    import ctypes
+
+    free, total = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().fv_device_mem_info(int(device), ctypes.byref(free), ctypes.byref(total)))
+    nchunks, _ = get_desired_chunks(min(max_memory, free.value), min_chunks, beam_list, nax, nfeed, len(ants),
+                                    len(np.atleast_1d(ra)), precision, source_buffer=source_buffer,
+                                    nfreq=int(np.size(freqs)))
     return engine.simulate(
         ants=ants, freqs=np.asarray(freqs), fluxes=fluxes, beam_list=beam_list, beam_idx=beam_idx,
         ra=ra, dec=dec, times=times, telescope_loc=telescope_loc, baselines=baselines,
@@ -93,6 +112,6 @@ def simulate_vis(
         interpolation_function=interpolation_function, nprocesses=nprocesses, nthreads=nthreads,
         coord_method=coord_method, coord_method_params=coord_method_params,
         force_use_type3=force_use_type3, force_use_ray=force_use_ray, trace_mem=trace_mem,
-        nchunks=min_chunks, source_buffer=source_buffer, beam_coefs=beam_coefs,
-        coord_mgr=coord_mgr,
+        nchunks=nchunks, source_buffer=source_buffer, beam_coefs=beam_coefs,
+        coord_mgr=coord_mgr, use_feed=use_feed,
     )

@@ -29,9 +29,13 @@ extern "C" {
 int fv_version(void);                 /* 10000*major + 100*minor + patch */
 int fv_device_count(int *count);      /* number of visible HIP devices (0 on a CPU-only box) */
 int fv_device_bytes(int64_t *bytes);  /* device memory this process's handles hold right now (all devices) */
+/* Free / total device memory of `device` (hipMemGetInfo): what the host side sizes its (time, frequency)
+ * output blocks and source chunks against -- the device counterpart of the reference's
+ * psutil.virtual_memory().available in simulate_vis (src/fftvis/wrapper.py:292-302).                 */
+int fv_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes);
 /* fv_nufft3 / fv_nudft3_direct keep a stream, device buffers and a plan per host thread between calls
  * (while the process holds < FFTVIS_HIP_HANDLE_CACHE_BYTES, default 2 GiB, of device memory): this frees
- * the calling thread's; call it before a thread that used them exits.                              */
+ * them all, including those of threads that have exited.  Call it while no transform is in flight. */
 int fv_release_workspaces(void);
 const char *fv_last_error(void);
 
@@ -44,7 +48,8 @@ const char *fv_last_error(void);
  * out: (ntrans, N) complex, caller-allocated.  upsampfac in {2.0, 1.25}
  * (cpu/nufft.py:19 "upsample_factor"); 1.25 reaches ~1e-8 at best in fp64 (kernel one cell wider
  * than finufft's formula, capped at 15: beyond that amplified rounding at band-edge targets
- * outweighs the truncation gain).  Host pointers.                                            */
+ * outweighs the truncation gain).  Host pointers.  NaN / infinite source coordinates are refused
+ * (FV_ERR_ARG), as finufft refuses them.                                                      */
 int fv_nufft3(int device, int precision, int dim, int64_t M, const void *x, const void *y,
               const void *z, const void *c, int ntrans, int64_t N, const void *s, const void *t,
               const void *u, double eps, double upsampfac, void *out);
@@ -160,11 +165,27 @@ int fv_sim_set_beam_pairs(fv_sim *h, int npairs, const int *bi, const int *bj, c
 int fv_sim_set_basis(fv_sim *h, int nant, int nbasis, int nfreq, const void *coefs, const int *ant1,
                      const int *ant2);
 
+/* Source-axis chunking: the `for chunk in range(nchunks)` loop inside the reference's time loop
+ * (cpu_simulate.py:939-946; visibilities accumulate with += over chunks, :1024,1069) and matvis'
+ * source_buffer (cpu_simulate.py:693-704: the above-horizon arrays of a chunk hold
+ * source_buffer x chunk size sources).  Every time step then processes the catalog in nchunks
+ * consecutive pieces whose per-time device scratch (coordinates, bin sort, kernel weights, strengths)
+ * is sized by one piece; the catalog itself stays resident.  A chunk with more sources above the
+ * horizon than source_buffer allows fails the run (FV_ERR_ARG at the next synchronisation), as matvis
+ * raises.  Defaults: nchunks = 1, source_buffer = 1.                                           */
+int fv_sim_set_chunking(fv_sim *h, int nchunks, double source_buffer);
+
 /* Run times [t0, t1) x freqs [f0, f1).  Result layout is the reference's FINAL layout
  * (cpu_simulate.py:850-854): polarized (nf_here, nt_here, 2, 2, nbls), else (nf_here, nt_here,
  * nbls), complex of the handle's precision.  out_on_device = 0: `out` is a host buffer (the
  * call synchronises); != 0: `out` is a device buffer and the call only enqueues work on the
- * handle's stream -- use fv_sim_sync().                                                      */
+ * handle's stream -- use fv_sim_sync().  A device `out` must be ordinary (coarse-grained) hipMalloc
+ * memory on the handle's GPU: small 2-D grids are gathered with fp64 atomics compiled with
+ * -munsafe-fp-atomics, which fine-grained or managed memory does not honour.
+ * Bad input met on the device (source vectors that are NaN or not unit length, so that they fall
+ * outside the planned grid; a type-1 entry overflow) fails the run at the next host
+ * synchronisation -- this call for a host `out`, fv_sim_sync() otherwise -- with FV_ERR_ARG /
+ * FV_ERR_INTERNAL; the output of that run is invalid.                                          */
 int fv_sim_run(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int out_on_device);
 int fv_sim_sync(fv_sim *h);
 
@@ -173,7 +194,7 @@ int fv_sim_sync(fv_sim *h);
  * [2] source x trans visits, [3] cells moved through HBM by the pruned FFT passes,
  * [4] interp targets x trans, [5] above-horizon sources summed over times, [6] last n2x,
  * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w, [10] upsampling factor the
- * last run used.                                                                             */
+ * last run used, [11] largest above-horizon source count of any time step since the reset.   */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,
@@ -181,7 +202,8 @@ int fv_sim_reset_stats(fv_sim *h);
  * behind [0].  level 0: off; 1: spread only, events attached to the dispatches themselves (no extra
  * queue packets) for the spread launches of one time step in 16 of a run (the 9th: steady state) -- sampled because even
  * attached events idle the queue for a few us around a launch; cheap enough for a timed region; 2: every launch of every
- * family, bracketed by event records (adds ~10 us bubbles each; runs on a single stream). */
+ * family, bracketed by event records (adds ~10 us bubbles each; runs on a single stream); 3: as 1 but on
+ * every spread launch (large grids, where a launch is hundreds of us and the bubble does not matter). */
 int fv_sim_enable_timing(fv_sim *h, int level);
 int fv_sim_timing(fv_sim *h, double *ms, int n);
 

@@ -42,10 +42,18 @@ def _vp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _ncores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def _nthreads(work: int) -> int:
-    """OpenMP threads for a spread/interp call: one per ~2e6 kernel-cell updates (forking a team
-    for less costs more than it saves), capped at the host's cores."""
-    return int(max(1, min(os.cpu_count() or 1, work // 2_000_000)))
+    """OpenMP threads for a spread/interp call: every core this process may run on once each gets
+    >= 2.5e4 kernel-cell updates (a team costs ~10 us to fork; below that the call is over sooner on
+    fewer threads) -- all cores for every BASELINE configuration from C2 up."""
+    return int(max(1, min(_ncores(), work // 25_000)))
 
 
 def next235even(n: int) -> int:

@@ -343,7 +343,7 @@ def test_sim_c1_against_committed_fixture(gpu):
     kw = dict(ants=ants, fluxes=z["fluxes"], ra=z["ra"], dec=z["dec"], freqs=z["freqs"],
               times=z["times"], beam=fftvis_amd.AiryBeam(float(z["airy_diameter"])),
               telescope_loc=tuple(z["telescope_loc"]), baselines=[tuple(b) for b in z["baselines"]],
-              precision=2, eps=6e-8)
+              precision=2, eps=6e-8, coord_method="SiderealRotation")
     v = fftvis_amd.simulate_vis(**kw, polarized=False)
     assert v.shape == (8, 2, 21) and v.dtype == np.complex128
     assert rel_l2(v, z["vis_unpolarized"]) < TOL
@@ -468,7 +468,7 @@ def test_sim_blocks_and_chunk_layout(gpu):
     cfg = synth.make_config("C2", nsrc=1500, nfreq=12, ntimes=4)
     cfg["polarized"] = True
     kw = {k: cfg[k] for k in ("ants", "freqs", "fluxes", "ra", "dec", "times", "telescope_loc",
-                              "baselines", "polarized", "eps")}
+                              "baselines", "polarized", "eps", "coord_method")}
     kw["beam_list"] = [cfg["beam"]]
     eng = fftvis_amd.create_simulation_engine("gpu")
     full = eng.simulate(**kw)
@@ -861,7 +861,8 @@ def _random_sim_config(rng, lattice=False):
     return dict(ants=ants, fluxes=flux, ra=ra, dec=dec, freqs=freqs, times=times,
                 beam=beams if nbeam > 1 else beams[0], beam_idx=rng.integers(0, nbeam, nant) if nbeam > 1 else None,
                 telescope_loc=(synth.HERA_LAT, synth.HERA_LON), baselines=[allb[k] for k in sel], polarized=pol,
-                precision=2, eps=float(10 ** rng.uniform(-11, -4)), force_use_type3=not lattice)
+                precision=2, eps=float(10 ** rng.uniform(-11, -4)), force_use_type3=not lattice,
+                coord_method="SiderealRotation")
 
 
 def test_sim_fuzz_random_configurations(gpu):

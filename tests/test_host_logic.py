@@ -213,7 +213,7 @@ def test_spline_opts_orders():
         with pytest.raises(NotImplementedError, match="spline orders 1 and 3"):
             eng.simulate(ants=cfg["ants"], freqs=cfg["freqs"], fluxes=cfg["fluxes"], beam_list=[cfg["beam"]],
                          ra=cfg["ra"], dec=cfg["dec"], times=cfg["times"], telescope_loc=cfg["telescope_loc"],
-                         beam_spline_opts=opts)
+                         beam_spline_opts=opts, coord_method="SiderealRotation")
 
 
 def test_upsample_1p25_below_its_floor_warns():
@@ -223,7 +223,8 @@ def test_upsample_1p25_below_its_floor_warns():
 
     cfg = synth.make_config("C1", nsrc=5, nfreq=2, ntimes=1)
     kw = dict(ants=cfg["ants"], freqs=cfg["freqs"], fluxes=cfg["fluxes"], beam_list=[cfg["beam"]], ra=cfg["ra"],
-              dec=cfg["dec"], times=cfg["times"], telescope_loc=cfg["telescope_loc"], upsample_factor=1.25)
+              dec=cfg["dec"], times=cfg["times"], telescope_loc=cfg["telescope_loc"], upsample_factor=1.25,
+              coord_method="SiderealRotation")
     for prec, eps in ((2, 1e-10), (1, 1e-6)):
         with pytest.warns(RuntimeWarning, match="upsample_factor=1.25 delivers about"):
             try:
