@@ -75,3 +75,29 @@ def test_shard_blocks_cover_plane_once(world, nf, nt):
         for b in mine:
             cover[b[0], b[1]] += 1
     assert (cover == 1).all()
+
+
+@pytest.mark.parametrize("world,nf,nt", [(1, 128, 20), (2, 128, 20), (3, 128, 20), (4, 128, 20), (8, 128, 20),
+                                         (8, 256, 60), (8, 4, 3), (3, 7, 5), (7, 64, 2), (8, 3, 1), (5, 1, 1)])
+def test_weighted_shards_cover_plane_once_and_balance(world, nf, nt):
+    """GPU runs shard by cost (nu^2 grid size), time-major: one block per rank, the plane covered once, and
+    no rank more than a few per cent over the mean once the job has a few dozen slices per rank."""
+    freqs = np.linspace(100e6, 200e6, nf)
+    blocks = parallel.shard_blocks_weighted(world, freqs, nt)
+    assert len(blocks) == world and all(len(b) <= 1 for b in blocks)
+    cover = np.zeros((nt, nf), int)
+    cost = parallel.slice_cost(freqs)
+    loads = []
+    for mine in blocks:
+        for tsl, fsl in mine:
+            cover[tsl, fsl] += 1
+            loads.append((tsl.stop - tsl.start) * cost[fsl].sum())
+    assert (cover == 1).all()
+    if nt * nf >= 64 * world:
+        assert max(loads) / (nt * cost.sum() / world) < 1.06
+    # by count the top half of the band would cost ~1.9x the bottom half
+    if (world, nf, nt) == (2, 128, 20):
+        assert blocks[0][0][0] == slice(0, 10) and blocks[0][0][1] == slice(0, 128)  # time-major split
+    if (world, nf, nt) == (8, 128, 20):
+        f_cut = blocks[0][0][1].stop
+        assert 75 <= f_cut <= 85  # 4 time parts x 2 frequency parts; the cut sits above the middle channel

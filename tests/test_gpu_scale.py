@@ -1,0 +1,278 @@
+"""GPU parity at the sizes of BASELINE.json configs[3] and [4] (C4: 1e6 sources; C5: HERA-350 eigenbeams in
+fp32), the source-chunk / memory knobs, the lattice path's entry buffers, run-to-run determinism and the
+sharded multi-rank path with the GPU engine.  Every call goes through the C ABI; checks are against the CPU
+oracle's exact sums on baseline subsets, the device-side brute-force sum, and size-independent properties
+(linearity, chunking invariance, basis == per-antenna beams)."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import fftvis_amd
+from fftvis_amd import synth
+from fftvis_amd._lib import FftvisHipError
+from fftvis_amd.gpu import gpu_nufft2d
+from fftvis_amd.gpu.nufft import gpu_nudft_direct
+from oracle import fftvis_oracle as orc
+from tests.helpers import oracle_simulate, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 5 * 6e-8
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sim_c4_million_sources(gpu, monkeypatch):
+    """configs[3] at its full catalog and baseline set: HERA-350, 1e6 sources, polarized table beam, all
+    61 075 baselines, 2 channels (band edges) x 1 time, fp64 eps 6e-8.  A random 64-baseline subset against
+    the device-side brute-force sum (O(M N), independent of spread / FFT / gather) fed with the oracle's
+    strengths, a 16-baseline subset against the CPU oracle end to end, and linearity in the flux."""
+    cfg = synth.make_config("C4", nfreq=2, ntimes=1)
+    assert len(cfg["ra"]) == 1_000_000 and len(cfg["baselines"]) == 61075
+    v = fftvis_amd.simulate_vis(**cfg)
+    assert v.shape == (2, 1, 2, 2, 61075) and np.isfinite(v).all()
+    rng = np.random.default_rng(11)
+    sub = sorted(rng.choice(61075, 64, replace=False))
+    # the CPU oracle, exact sums, on the first 16 of them
+    s16 = sub[:16]
+    exact = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in s16]))
+    assert rel_l2(v[..., s16], exact) < TOL
+    # the oracle's per-source strengths summed by brute force on the GPU for all 64
+    monkeypatch.setattr(orc, "nudft_type3", lambda coords, c, targets, **kw: gpu_nudft_direct(coords, c, targets))
+    brute = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
+    monkeypatch.undo()
+    assert rel_l2(v[..., sub], brute) < TOL
+    assert rel_l2(brute[..., :16], exact) < 1e-10  # the two checkers agree with each other
+    # linearity at full size: V(a - 2 b) = V(a) - 2 V(b)
+    _, _, fl2 = synth.catalog(1_000_000, cfg["freqs"], 9)
+    vb = fftvis_amd.simulate_vis(**dict(cfg, fluxes=fl2))
+    vab = fftvis_amd.simulate_vis(**dict(cfg, fluxes=cfg["fluxes"] - 2.0 * fl2))
+    assert rel_l2(vab, v - 2.0 * vb) < 1e-9
+    # the reference's source-chunk loop at this size: 4 chunks of 250 000 sources accumulate to the same block
+    v4 = fftvis_amd.simulate_vis(**dict(cfg, min_chunks=4))
+    assert rel_l2(v4, v) < 1e-9
+
+
+def test_sim_c5_eigenbeams_fp32(gpu):
+    """configs[4]'s shape: HERA-350, 1e5 sources, K = 4 tabulated basis beams with per-antenna coefficients,
+    precision 1, eps 1e-4, all 61 075 baselines, 2 channels x 1 time.  (a) a random subset of baselines
+    against the oracle's eigenbeam path (cpu_simulate.py:303-470 restated) at the fp32 tolerance the
+    reference's own eigenbeam test uses in spirit (tests/test_beam_basis.py:344-396); (b) on the 15
+    baselines among 6 antennas (3 of them outriggers, so the grid stays HERA-350's): the basis run equals
+    the run that gives every antenna its own beam sum_k c[a, k] B_k."""
+    cfg = synth.make_config("C5", nfreq=2, ntimes=1)
+    assert cfg["precision"] == 1 and cfg["eps"] == 1e-4 and len(cfg["beam"]) == 4
+    v = fftvis_amd.simulate_vis(**cfg)
+    assert v.dtype == np.complex64 and v.shape == (2, 1, 2, 2, 61075) and np.isfinite(v).all()
+    rng = np.random.default_rng(5)
+    sub = sorted(rng.choice(61075, 24, replace=False))
+    exact = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
+    assert rel_l2(v[..., sub], exact) < 2e-3
+    # (b) basis == per-antenna beams
+    antnums = list(cfg["ants"])
+    chosen = [0, 57, 211, 325, 337, 349]  # core antennas and outriggers
+    bl = [(a, b) for i, a in enumerate(chosen) for b in chosen[i + 1:]]
+    coefs = cfg["beam_coefs"]
+    freqs = cfg["freqs"]
+    per_ant = []
+    for a in chosen:
+        tab = sum(coefs[antnums.index(a), k, :, None, None, None, None] * cfg["beam"][k].data for k in range(4))
+        per_ant.append(fftvis_amd.TabulatedBeam(tab, freqs))
+    beam_idx = np.zeros(len(antnums), dtype=int)
+    for i, a in enumerate(chosen):
+        beam_idx[antnums.index(a)] = i
+    base = dict(cfg, baselines=bl)
+    vb = fftvis_amd.simulate_vis(**base)
+    pa = {k: base[k] for k in base if k != "beam_coefs"}
+    vp = fftvis_amd.simulate_vis(**dict(pa, beam=per_ant, beam_idx=beam_idx))
+    assert vb.shape == vp.shape == (2, 1, 2, 2, 15)
+    assert rel_l2(vb, vp) < 2e-3
+    # the same identity in fp64 at a tight tolerance pins it far below fp32 rounding
+    vb64 = fftvis_amd.simulate_vis(**dict(base, precision=2, eps=1e-9))
+    vp64 = fftvis_amd.simulate_vis(**dict(pa, beam=per_ant, beam_idx=beam_idx, precision=2, eps=1e-9))
+    assert rel_l2(vb64, vp64) < 1e-7 and rel_l2(vb, vb64) < 2e-3
+
+
+def test_sim_source_chunks_and_memory_knobs(gpu):
+    """nchunks (wrapper: min_chunks / max_memory) cuts the source axis like the reference's chunk loop
+    (cpu_simulate.py:939, += at :1024,1069): the result does not depend on it.  C1 in full, the C2 geometry
+    (fused-gather path, gang launches), a polarized two-beam case through the stand-alone gather, the
+    lattice path, the eigenbeam path; source_buffer too small raises like matvis."""
+    c1 = synth.make_config("C1")
+    ref = fftvis_amd.simulate_vis(**c1)
+    for n in (2, 3, 100, 1000):  # more chunks than sources is clipped (wrapper.py: min(..., nsrc))
+        assert rel_l2(fftvis_amd.simulate_vis(**dict(c1, min_chunks=n)), ref) < 1e-12, n
+    assert rel_l2(ref, oracle_simulate(c1)) < TOL
+    c2 = synth.make_config("C2", nsrc=3000, nfreq=16, ntimes=5)
+    r2 = fftvis_amd.simulate_vis(**c2)
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(c2, min_chunks=3)), r2) < 1e-12
+    # a device-memory budget too small for the whole catalog's per-time scratch forces chunks by itself
+    from fftvis_amd.core.utils import get_desired_chunks
+
+    n_auto, _ = get_desired_chunks(6_000_000, 1, [c2["beam"]], 1, 1, 37, 3000, 2, nfreq=16)
+    assert n_auto > 1
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(c2, max_memory=6_000_000)), r2) < 1e-12
+    # polarized, two table beams, flipped baselines, polarized sky (k_interp accumulate path on a big grid)
+    freqs = c1["freqs"]
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=46, naz=90), freqs)
+    tab2 = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, diameter=12.0, nza=46, naz=90), freqs)
+    _, _, fl4 = synth.catalog(100, freqs, 0, polarized_sky=True)
+    pol = dict(c1, polarized=True, beam=[tab, tab2], beam_idx=np.array([0, 1, 0, 1, 1, 0, 1]), fluxes=fl4,
+               baselines=c1["baselines"] + [(3, 0), (6, 1), (2, 2)])
+    rp = fftvis_amd.simulate_vis(**pol)
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(pol, min_chunks=4)), rp) < 1e-12
+    big = synth.make_config("C3", nsrc=5000, nfreq=2, ntimes=2)
+    big["baselines"] = big["baselines"][::97]
+    rb = fftvis_amd.simulate_vis(**big)
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(big, min_chunks=3)), rb) < 1e-11
+    # lattice (type-1) path and eigenbeam path
+    lat = {k: v for k, v in c1.items() if k != "force_use_type3"}
+    rl = fftvis_amd.simulate_vis(**lat)
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(lat, min_chunks=3)), rl) < 1e-12
+    rng = np.random.default_rng(2)
+    coefs = 0.1 * (rng.normal(size=(7, 2, 8)) + 1j * rng.normal(size=(7, 2, 8)))
+    coefs[:, 0] += 1.0
+    rtab = [fftvis_amd.TabulatedBeam(b.data.real.astype(complex), freqs) for b in (tab, tab2)]
+    bas = dict(c1, polarized=True, beam=rtab, beam_coefs=coefs)
+    rbas = fftvis_amd.simulate_vis(**bas)
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(bas, min_chunks=3)), rbas) < 1e-12
+    # source_buffer: roughly half of an isotropic catalog is up; a buffer of 10 % must raise, 0.9 must not
+    with pytest.raises(FftvisHipError, match="increase source_buffer"):
+        fftvis_amd.simulate_vis(**dict(c2, source_buffer=0.1))
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(c2, source_buffer=0.9)), r2) < 1e-12
+    assert rel_l2(fftvis_amd.simulate_vis(**c2), r2) < 1e-12  # the handle recovered after the error
+    with pytest.raises(ValueError, match="source_buffer"):
+        fftvis_amd.simulate_vis(**dict(c2, source_buffer=1.5))
+    with pytest.raises(ValueError, match="use_feed"):
+        fftvis_amd.simulate_vis(**dict(c2, use_feed="z"))
+    with pytest.raises(ValueError, match="coord_mgr"):
+        fftvis_amd.simulate_vis(**dict(c2, coord_method="CoordinateRotationERFA"))
+    with pytest.raises(ValueError, match="unknown coord_method"):
+        fftvis_amd.simulate_vis(**dict(c2, coord_method="Nope"))
+
+
+def test_sim_time_blocks_and_streamed_coord_mgr(gpu, monkeypatch):
+    """The engine walks the time axis in blocks when the output would not fit (here: forced), and a
+    coordinate manager's vectors are streamed block by block: same visibilities either way."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    cfg = synth.make_config("C2", nsrc=1200, nfreq=6, ntimes=7)
+    ref = fftvis_amd.simulate_vis(**cfg)
+
+    class Mgr:
+        def __init__(self):
+            self.o = orc.SimpleCoordinateRotation(None, cfg["times"], cfg["telescope_loc"], cfg["ra"], cfg["dec"])
+            self.rotated = []
+
+        def setup(self):
+            pass
+
+        def rotate(self, ti):
+            self.rotated.append(ti)
+            self.o.rotate(ti)
+            self.all_coords_topo = self.o._topo
+
+    monkeypatch.setattr(gpu_simulate, "_time_block", lambda *a, **k: 3)
+    assert rel_l2(fftvis_amd.simulate_vis(**cfg), ref) < 1e-12
+    m = Mgr()
+    got = fftvis_amd.simulate_vis(**dict(cfg, coord_method="CoordinateRotationERFA"), coord_mgr=m)
+    assert m.rotated == list(range(7)) and rel_l2(got, ref) < 1e-12
+
+
+def test_type1_entry_buffers_hold_a_sky_that_is_all_up(gpu):
+    """on small lattices (n2 = 64) every (source, frequency) pair needs ~1.5 entries at
+    the default fp64 tolerance (periodic images of 14-16 cell footprints), and a catalog that is entirely
+    above the horizon used to overflow entry buffers sized at 1.3 per pair.  2.4e4 sources within 50
+    degrees of the zenith, HERA-37 lattice, default eps: type 1 equals type 3."""
+    cfg = synth.make_config("C2", nsrc=24_000, nfreq=4, ntimes=1)
+    from fftvis_amd.core.coords import gmst_rad
+
+    rng = np.random.default_rng(4)
+    lst = gmst_rad(cfg["times"][0]) + synth.HERA_LON
+    th = np.deg2rad(50.0) * np.sqrt(rng.uniform(0, 1, 24_000))
+    ph = rng.uniform(0, 2 * np.pi, 24_000)
+    cfg["dec"] = np.clip(synth.HERA_LAT + th * np.sin(ph), -np.pi / 2, np.pi / 2)
+    cfg["ra"] = lst + th * np.cos(ph) / np.cos(synth.HERA_LAT)
+    cfg.update(eps=None)
+    cfg.pop("force_use_type3")
+    t1 = fftvis_amd.simulate_vis(**cfg)
+    t3 = fftvis_amd.simulate_vis(**cfg, force_use_type3=True)
+    assert np.isfinite(t1).all() and rel_l2(t1, t3) < 1e-11
+    sub = cfg["baselines"][::40]
+    assert rel_l2(fftvis_amd.simulate_vis(**dict(cfg, baselines=sub)), oracle_simulate(dict(cfg, baselines=sub, force_use_type3=False))) < 1e-11
+
+
+def test_bad_coordinates_fail_loudly(gpu):
+    """NaN source coordinates are refused by the stand-alone transform (finufft refuses them too) and
+    non-unit coord_mgr vectors fail the run instead of producing finite wrong numbers."""
+    rng = np.random.default_rng(0)
+    x, y = rng.uniform(-3, 3, (2, 500))
+    c = rng.normal(size=500) + 0j
+    s, t = rng.uniform(-50, 50, (2, 40))
+    gpu_nufft2d(x, y, c, s, t, 1e-6)
+    xb = x.copy()
+    xb[17] = np.nan
+    with pytest.raises(FftvisHipError, match="NaN"):
+        gpu_nufft2d(xb, y, c, s, t, 1e-6)
+    assert np.isfinite(gpu_nufft2d(x, y, c, s, t, 1e-6)).all()  # the workspace survived
+    cfg = synth.make_config("C1")
+
+    class Mgr:  # vectors three times too long: outside the unit sphere's box
+        def __init__(self):
+            self.o = orc.SimpleCoordinateRotation(None, cfg["times"], cfg["telescope_loc"], cfg["ra"], cfg["dec"])
+
+        def setup(self):
+            pass
+
+        def rotate(self, ti):
+            self.o.rotate(ti)
+            self.all_coords_topo = 3.0 * self.o._topo
+
+    with pytest.raises(FftvisHipError, match="outside"):
+        fftvis_amd.simulate_vis(**cfg, coord_mgr=Mgr())
+    assert rel_l2(fftvis_amd.simulate_vis(**cfg), oracle_simulate(cfg)) < TOL
+
+
+def test_runs_are_bitwise_reproducible_without_the_fused_gather(gpu):
+    """The spread is a gather (every cell written once, no atomics), the FFT passes and the stand-alone
+    gather have a fixed summation order: two runs of the same transform / simulation are BIT-identical.
+    Only the fused gather of small 2-D grids adds partial sums with fp64 atomics (compiled with
+    -munsafe-fp-atomics) and is reproducible to rounding, not bitwise."""
+    rng = np.random.default_rng(1)
+    x, y = rng.uniform(-3, 3, (2, 20_000))
+    c = rng.normal(size=(8, 20_000)) + 1j * rng.normal(size=(8, 20_000))
+    s, t = rng.uniform(-300, 300, (2, 3000))
+    a = gpu_nufft2d(x, y, c, s, t, 6e-8)
+    b = gpu_nufft2d(x, y, c, s, t, 6e-8)
+    assert np.array_equal(a, b)
+    big = synth.make_config("C3", nsrc=30_000, nfreq=3, ntimes=2)  # 8192^2-class grid: stand-alone gather
+    big["baselines"] = big["baselines"][::13]
+    assert np.array_equal(fftvis_amd.simulate_vis(**big), fftvis_amd.simulate_vis(**big))
+    c2 = synth.make_config("C2", nsrc=3000, nfreq=16, ntimes=4)  # fused gather: atomics
+    u, v = fftvis_amd.simulate_vis(**c2), fftvis_amd.simulate_vis(**c2)
+    assert rel_l2(u, v) < 1e-13
+
+
+def test_sharded_run_two_ranks_on_the_gpu(gpu, tmp_path):
+    """Two ranks (gloo rendezvous, both on device 0 -- a one-GPU box cannot host two RCCL ranks) run
+    parallel.simulate_vis_sharded through the GPU engine: catalog broadcast into device memory, one
+    cost-balanced (time x freq) block per rank via GPUSimulationEngine(time_idx, freq_idx), blocks
+    assembled on rank 0 (reference cpu_simulate.py:800-847) == the single-process GPU result."""
+    out = tmp_path / "sharded.npz"
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29731",
+           os.path.join(ROOT, "tests", "sharded_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    cfg = synth.make_config("C2", nsrc=2500, nfreq=12, ntimes=6)
+    cfg["polarized"] = True
+    freqs = cfg["freqs"]
+    cfg["beam"] = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=46, naz=90), freqs)
+    single = fftvis_amd.simulate_vis(**cfg)
+    assert z["vis"].shape == single.shape == (12, 6, 2, 2, 666)
+    assert rel_l2(z["vis"], single) < 1e-12
+    assert [tuple(b) for b in z["blocks"]] == [(0, 3, 0, 12), (3, 6, 0, 12)]
