@@ -253,18 +253,40 @@ __global__ void k_scan_add(int *__restrict__ out, const int *__restrict__ block_
     if (i == n - 1 || (n == 0 && i == 0)) out[n] = block_off[gridDim.x];
 }
 
-// Scatter into bin order and tabulate each source's kernel weights:
-//   kw[(d * M + pos) * w + k] = psi(f_d + k),  k < w.
-template <typename T>
-__global__ void k_bin_scatter(int64_t M, const int *__restrict__ Mp, int dim,
-                              const int *__restrict__ i0u, const T *__restrict__ fu,
-                              const int *__restrict__ tile_of, const int *__restrict__ bin_start,
-                              int *__restrict__ cursor, int *__restrict__ i0s, T *__restrict__ fs,
-                              int *__restrict__ perm, T *__restrict__ kw, int w, T beta, T c4) {
+// Counting sort, second half, in two kernels so that the order INSIDE a bin does not depend on the order in
+// which atomics retire: (1) every source takes a slot of its bin (atomic cursor) and leaves its id there;
+// (2) every slot's source finds its rank among the ids of its bin and moves to that position, where its
+// footprint origin, offsets and tabulated kernel weights  kw[(d * M + pos) * w + k] = psi(f_d + k), k < w,
+// are written.  The spread sums a cell's contributions in bin-walk order, so with (2) two runs of the same
+// transform are bit-identical.  Bins beyond RANK_SORT_MAX sources keep the atomic order (a clustered
+// catalog would make the rank search quadratic).
+constexpr int RANK_SORT_MAX = 8192;
+__global__ void k_bin_scatter_ids(int64_t M, const int *__restrict__ Mp, const int *__restrict__ tile_of,
+                                  const int *__restrict__ bin_start, int *__restrict__ cursor,
+                                  int *__restrict__ slot_id) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (Mp ? min((int64_t)*Mp, M) : M)) return;
-    int t = tile_of[j];
-    int pos = bin_start[t] + atomicAdd(&cursor[t], 1);
+    const int t = tile_of[j];
+    slot_id[bin_start[t] + atomicAdd(&cursor[t], 1)] = (int)j;
+}
+
+template <typename T>
+__global__ void k_bin_fill(int64_t M, const int *__restrict__ Mp, int dim, const int *__restrict__ i0u,
+                           const T *__restrict__ fu, const int *__restrict__ tile_of,
+                           const int *__restrict__ bin_start, const int *__restrict__ slot_id,
+                           int *__restrict__ i0s, T *__restrict__ fs, int *__restrict__ perm,
+                           T *__restrict__ kw, int w, T beta, T c4) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (Mp ? min((int64_t)*Mp, M) : M)) return;
+    const int j = slot_id[q];
+    const int t = tile_of[j];
+    const int s0 = bin_start[t], s1 = bin_start[t + 1];
+    int rank = (int)q - s0;
+    if (s1 - s0 > 1 && s1 - s0 <= RANK_SORT_MAX) {
+        rank = 0;
+        for (int k = s0; k < s1; ++k) rank += slot_id[k] < j;
+    }
+    const int64_t pos = s0 + rank;
     for (int d = 0; d < dim; ++d) {
         const T f = fu[(int64_t)d * M + j];
         i0s[(int64_t)d * M + pos] = i0u[(int64_t)d * M + j];
@@ -272,7 +294,7 @@ __global__ void k_bin_scatter(int64_t M, const int *__restrict__ Mp, int dim,
         T *row = kw + ((int64_t)d * M + pos) * w;
         for (int k = 0; k < w; ++k) row[k] = es_eval<T>(f + (T)k, beta, c4);
     }
-    perm[pos] = (int)j;
+    perm[pos] = j;
 }
 
 // Inner-kernel deconvolution table of one dimension in buffer-A coordinates:
@@ -1590,7 +1612,7 @@ class Nufft3 {
     int64_t geom_serial = 0;  // bumps whenever the source->cell mapping changes
 
     // device state
-    DevBuf i0u, fu, tile_of, binmeta, bin_start, i0s, fs, perm, kw, scan_tot, scan_off, scan_tot2, scan_off2;
+    DevBuf i0u, fu, tile_of, binmeta, bin_start, i0s, fs, perm, slot_id, kw, scan_tot, scan_off, scan_tot2, scan_off2;
     const int *Mp = nullptr;   // device-side live source count (optional)
     int *oob_ptr = nullptr;
     int *err_oob = nullptr;    // owner's sticky counter of clamped / NaN sources (else the plan's own, reset per sort)
@@ -1711,6 +1733,7 @@ class Nufft3 {
         kw.reserve(sizeof(T) * 3 * M1 * ker.w);
         tile_of.reserve(sizeof(int) * M1);
         perm.reserve(sizeof(int) * M1);
+        slot_id.reserve(sizeof(int) * M1);
         bin_start.reserve(sizeof(int) * (nb + 1));
         binmeta.reserve(sizeof(int) * (2 * (size_t)(nb + 1) + 1));  // counts | cursor | oob
         int *counts_p = binmeta.as<int>(), *cursor_p = counts_p + (nb + 1), *oob_p = cursor_p + (nb + 1);
@@ -1733,9 +1756,12 @@ class Nufft3 {
         }
         exclusive_scan(counts_p, bin_start.as<int>(), nb);
         if (M > 0) {
-            hipLaunchKernelGGL(k_bin_scatter<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, Mp,
+            hipLaunchKernelGGL(k_bin_scatter_ids, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, Mp,
+                               (const int *)tile_of.as<int>(), (const int *)bin_start.as<int>(), cursor_p,
+                               slot_id.as<int>());
+            hipLaunchKernelGGL(k_bin_fill<T>, dim3(cdiv(M, 256)), dim3(256), 0, stream, M, Mp,
                                dim, i0u.as<int>(), fu.as<T>(), tile_of.as<int>(),
-                               bin_start.as<int>(), cursor_p, i0s.as<int>(), fs.as<T>(),
+                               bin_start.as<int>(), (const int *)slot_id.as<int>(), i0s.as<int>(), fs.as<T>(),
                                perm.as<int>(), kw.as<T>(), ker.w, (T)ker.beta, (T)ker.c);
         }
     }
@@ -1918,7 +1944,9 @@ int64_t Nufft3<T>::b_pitch() const {
     const DimGeom &x = geo.d[0], &y = geo.d[1];
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
-    return rpw >= 4 ? (x.nos() + rpw - 1) / rpw * rpw : x.nos();  // whole 64-/128-B segments per workgroup
+    // whole 128-B lines per workgroup (8 columns) or per pair of neighbouring workgroups (4 columns each;
+    // giving such pairs consecutive slots on one XCD was measured to change nothing: 1.836 vs 1.833 ms)
+    return rpw >= 4 ? (x.nos() + 7) / 8 * 8 : x.nos();
 }
 
 template <typename T>
