@@ -1430,7 +1430,14 @@ struct InterpArgs {
     int basis, kk, ll, nbasis, ncoef_freq, f_first;
 };
 
-template <typename T, int DIM>
+// HERM (Hermitian strengths): the grid holds two transforms per frequency instead of four --
+//   T1 = F[c_00 + i c_11]  (both real),   T2 = F[c_01]   (c_10 = conj(c_01)) --
+// and the four products are rebuilt from their values at the target s and at its mirror image -s:
+//   V_00(s) = (T1(s) + conj(T1(-s))) / 2,   V_11(s) = (T1(s) - conj(T1(-s))) / 2i,
+//   V_01(s) = T2(s),                        V_10(s) = conj(T2(-s)),
+// exact identities of the non-uniform DFT of real / conjugate-paired strengths.  The caller plans a box
+// that is symmetric about s = 0, so that -s is a target like any other.
+template <typename T, int DIM, bool HERM>
 __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ bt0,
     const T *__restrict__ bt1, const T *__restrict__ bt2, const int *__restrict__ bl_idx,
@@ -1451,23 +1458,13 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const T beta = (T)ker.beta, c4 = (T)ker.c;
     const T *bt[3] = {bt0, bt1, bt2};
     double sv[DIM], th[DIM];
-    int j0[DIM];
-    T kv[DIM];  // this lane's kernel value along each dimension (lane = footprint offset)
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
         sv[d] = sc * sg * (double)bt[d][k];                     // actual target coordinate
         th[d] = a.h[d] * (sv[d] - sc * a.btc[d]);               // theta = h (s - s_c)
-        const double e = th[d] * a.n2[d] * (0.5 / M_PI) + 0.5 * a.no[d];
-        int j = (int)ceil(e - 0.5 * w);
-        j = max(0, min(a.no[d] - w, j));
-        j0[d] = j;
-        kv[d] = g < w ? es_eval<T>((T)((double)(j + g) - e), beta, c4) : T(0);
     }
-    T k1[MAX_W];
-#pragma unroll
-    for (int r = 0; r < MAX_W; ++r) k1[r] = __shfl(kv[1], lane_base + r, 64);
-
-    // psi_1_hat at every theta: quadrature nodes split over the 16 lanes
+    // psi_1_hat at every theta (an even function: the mirror target shares it): quadrature nodes split
+    // over the 16 lanes
     double hh[DIM];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) hh[d] = 0.0;
@@ -1497,40 +1494,66 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const int64_t row_sz = (int64_t)a.P[0] * a.cnt[0];
     const int64_t slab_sz = row_sz * a.P[1] * a.cnt[1];
     const int64_t plane_sz = DIM == 3 ? slab_sz * a.P[2] * a.cnt[2] : slab_sz;
-    const int gcol = out_pos(min(j0[0] + g, a.no[0] - 1), a.P[0], a.cnt[0]);
     const int nouter = DIM == 3 ? w : 1;
-    for (int r = 0; r < a.tpol; ++r) {
-        const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * plane_sz + gcol;
-        T sr = T(0), si = T(0);
-        for (int ro = 0; ro < nouter; ++ro) {
-            T k2 = T(1);
-            const cplx<T> *slab = plane;
-            if (DIM == 3) {
-                k2 = __shfl(kv[DIM - 1], lane_base + ro, 64);
-                slab += (int64_t)out_pos(j0[DIM - 1] + ro, a.P[DIM - 1], a.cnt[DIM - 1]) * slab_sz;
-            }
-            T tr = T(0), ti = T(0);
+    constexpr int NSIDE = HERM ? 2 : 1;   // the target and (HERM) its mirror image
+    constexpr int NVAL = HERM ? 2 : 16;   // transforms per frequency held at once (non-HERM: streamed)
+    double vre[NSIDE][HERM ? NVAL : 1], vim[NSIDE][HERM ? NVAL : 1];
+    for (int side = 0; side < NSIDE; ++side) {
+        const double sgn = side ? -1.0 : 1.0;
+        int j0[DIM];
+        T kv[DIM];  // this lane's kernel value along each dimension (lane = footprint offset)
 #pragma unroll
-            for (int rr = 0; rr < MAX_W; ++rr) {
-                if (rr < w) {
-                    const cplx<T> v = slab[(int64_t)out_pos(j0[1] + rr, a.P[1], a.cnt[1]) * row_sz];
-                    tr += v.re * k1[rr];
-                    ti += v.im * k1[rr];
+        for (int d = 0; d < DIM; ++d) {
+            const double e = sgn * th[d] * a.n2[d] * (0.5 / M_PI) + 0.5 * a.no[d];
+            int j = (int)ceil(e - 0.5 * w);
+            j = max(0, min(a.no[d] - w, j));
+            j0[d] = j;
+            kv[d] = g < w ? es_eval<T>((T)((double)(j + g) - e), beta, c4) : T(0);
+        }
+        T k1[MAX_W];
+#pragma unroll
+        for (int r = 0; r < MAX_W; ++r) k1[r] = __shfl(kv[1], lane_base + r, 64);
+        const int gcol = out_pos(min(j0[0] + g, a.no[0] - 1), a.P[0], a.cnt[0]);
+        const double pis = side ? -pi_ : pi_;  // exp(i (-s) . x_c) = conj
+        for (int r = 0; r < a.tpol; ++r) {
+            const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * plane_sz + gcol;
+            T sr = T(0), si = T(0);
+            for (int ro = 0; ro < nouter; ++ro) {
+                T k2 = T(1);
+                const cplx<T> *slab = plane;
+                if (DIM == 3) {
+                    k2 = __shfl(kv[DIM - 1], lane_base + ro, 64);
+                    slab += (int64_t)out_pos(j0[DIM - 1] + ro, a.P[DIM - 1], a.cnt[DIM - 1]) * slab_sz;
                 }
-            }
-            sr += tr * k2;
-            si += ti * k2;
-        }
-        sr *= kv[0];
-        si *= kv[0];
+                T tr = T(0), ti = T(0);
 #pragma unroll
-        for (int off = GROUP / 2; off > 0; off >>= 1) {
-            sr += __shfl_xor(sr, off, 64);
-            si += __shfl_xor(si, off, 64);
-        }
-        if (g == 0) {
-            double vr = (double)sr * pr - (double)si * pi_;
-            double vi = (double)sr * pi_ + (double)si * pr;
+                for (int rr = 0; rr < MAX_W; ++rr) {
+                    if (rr < w) {
+                        const cplx<T> v = slab[(int64_t)out_pos(j0[1] + rr, a.P[1], a.cnt[1]) * row_sz];
+                        tr += v.re * k1[rr];
+                        ti += v.im * k1[rr];
+                    }
+                }
+                sr += tr * k2;
+                si += ti * k2;
+            }
+            sr *= kv[0];
+            si *= kv[0];
+#pragma unroll
+            for (int off = GROUP / 2; off > 0; off >>= 1) {
+                sr += __shfl_xor(sr, off, 64);
+                si += __shfl_xor(si, off, 64);
+            }
+            double vr = (double)sr * pr - (double)si * pis;
+            double vi = (double)sr * pis + (double)si * pr;
+            if constexpr (HERM) {
+                if (r < NVAL) {
+                    vre[side][r] = vr;
+                    vim[side][r] = vi;
+                }
+                continue;
+            }
+            if (g != 0) continue;
             if (sg < 0) vi = -vi;  // conj for flipped baselines (cpu_simulate.py:298)
             const int64_t po = r < 16 ? a.out_pol_off[r] : (int64_t)r * a.out_pol_off[1];
             cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + k * a.out_k_stride;
@@ -1557,6 +1580,32 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                     o2->im += (T)v2.im;
                 }
             } else if (a.accumulate) {
+                o->re += (T)vr;
+                o->im += (T)vi;
+            } else {
+                *o = {(T)vr, (T)vi};
+            }
+        }
+    }
+    if constexpr (HERM) {
+        if (g != 0) return;
+        // P = T1(s), M = T1(-s), C = T2(s), D = T2(-s)
+        const double Pr = vre[0][0], Pi = vim[0][0], Mr = vre[1][0], Mi = vim[1][0];
+        double o_re[4], o_im[4];
+        o_re[0] = 0.5 * (Pr + Mr);   // (P + conj M) / 2
+        o_im[0] = 0.5 * (Pi - Mi);
+        o_re[3] = 0.5 * (Pi + Mi);   // (P - conj M) / 2i = -i/2 ((Pr - Mr) + i (Pi + Mi))
+        o_im[3] = -0.5 * (Pr - Mr);
+        o_re[1] = vre[0][1];         // C
+        o_im[1] = vim[0][1];
+        o_re[2] = vre[1][1];         // conj D
+        o_im[2] = -vim[1][1];
+        cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + k * a.out_k_stride;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double vr = o_re[r], vi = sg < 0 ? -o_im[r] : o_im[r];  // conj for flipped baselines
+            cplx<T> *o = ob + a.out_pol_off[r];
+            if (a.accumulate) {
                 o->re += (T)vr;
                 o->im += (T)vi;
             } else {
@@ -1861,7 +1910,8 @@ class Nufft3 {
     void interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
                 const signed char *flip, const double *scale_dev, int nfg, int tpol,
                 cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
-                const int64_t *out_pol_off, bool accumulate, const struct BasisTerm *basis = nullptr);
+                const int64_t *out_pol_off, bool accumulate, const struct BasisTerm *basis = nullptr,
+                bool herm = false);
 
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
@@ -2221,8 +2271,9 @@ template <typename T>
 void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
                        const signed char *flip, const double *scale_dev, int nfg, int tpol,
                        cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
-                       const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis) {
+                       const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis, bool herm) {
     if (N == 0 || nfg == 0) return;
+    FV_REQUIRE(!herm || (tpol == 2 && !basis), "Hermitian gather: two transforms per frequency, no eigenbeams");
     InterpArgs a{};
     const cplx<T> *coef = nullptr;
     const int *ant1 = nullptr, *ant2 = nullptr;
@@ -2263,12 +2314,10 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.accumulate = accumulate ? 1 : 0;
     const int64_t items = N * nfg;
     const dim3 grid((unsigned)cdiv(items, INTERP_THREADS / GROUP));
-    if (dim == 2)
-        hipLaunchKernelGGL((k_interp<T, 2>), grid, dim3(INTERP_THREADS), 0, stream, grid_out, N,
-                           bt[0], bt[1], bt[2], bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2);
-    else
-        hipLaunchKernelGGL((k_interp<T, 3>), grid, dim3(INTERP_THREADS), 0, stream, grid_out, N,
-                           bt[0], bt[1], bt[2], bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2);
+    auto kern = dim == 2 ? (herm ? k_interp<T, 2, true> : k_interp<T, 2, false>)
+                         : (herm ? k_interp<T, 3, true> : k_interp<T, 3, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(INTERP_THREADS), 0, stream, (const cplx<T> *)grid_out, N, bt[0], bt[1], bt[2],
+                       bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2);
 }
 
 }  // namespace fv

@@ -419,6 +419,7 @@ struct StrengthArgs {
     int f_first;        // catalog index of the group's first frequency
     int nfreq;          // catalog frequency count (flux row length)
     int polarized, pol_sky, same_beam;
+    int herm;           // Hermitian strengths packed as two transforms: c_00 + i c_11 and c_01 (see k_interp)
     int dim, w;
     double h[3], btc[3];
     int na[3];
@@ -465,6 +466,11 @@ __device__ inline void strength_eval(const StrengthArgs &a, int jc, int fidx, cp
         const cplx<double> Fj[4] = {Aj[2], Aj[3], Aj[0], Aj[1]};
         coh_AhCB(Fi, C, Fj, o);
     }
+    if (a.herm) {  // same beam on both sides: o is Hermitian (o_00, o_11 real, o_10 = conj o_01); pre = 1
+        dst[0] = {(T)o[0].re, (T)o[3].re};
+        dst[1] = {(T)o[1].re, (T)o[1].im};
+        return;
+    }
     for (int r = 0; r < 4; ++r) {
         const cplx<double> v = cmul(o[r], pre);
         dst[r] = {(T)v.re, (T)v.im};
@@ -492,7 +498,7 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const in
     }
     cplx<double> pre = {1.0, 0.0};
     if (dot != 0.0) sincos(freqs[fidx] * dot, &pre.im, &pre.re);
-    const int tp = a.polarized ? 4 : 1;
+    const int tp = a.herm ? 2 : a.polarized ? 4 : 1;
     strength_eval<T, ORD>(a, perm[p], fidx, pre, src_idx, az, za, flux, freqs, cs + (p * a.nfg + fgi) * tp);
 }
 
@@ -788,8 +794,13 @@ class Sim : public SimBase {
         int64_t n;
         bool trivial;  // all baselines in order, nothing flipped
         std::unique_ptr<DevBuf> idx, flip;
-        double btc[3], B[3];
+        double btc[3], B[3];   // tight box of its (sign-adjusted) baselines: centre, half-width [s]
+        double Bs[3];          // half-width of the box made symmetric about 0
+        bool herm = false;     // this run packs its Hermitian strengths into two transforms (decided per run)
+        const double *box_c() const { return herm ? zero3 : btc; }
+        const double *box_B() const { return herm ? Bs : B; }
     };
+    static constexpr double zero3[3] = {0.0, 0.0, 0.0};
     std::vector<Pair> pairs;
     // Source-axis chunking (reference cpu_simulate.py:939: `for chunk in range(nchunks)` inside the time
     // loop, visibilities accumulate with +=): per-time scratch is sized by one chunk, the catalog stays
@@ -1075,6 +1086,7 @@ class Sim : public SimBase {
             for (int d = 0; d < 3; ++d) {
                 pr.btc[d] = pr.n ? 0.5 * (lo[d] + hi[d]) : 0.0;
                 pr.B[d] = pr.n ? 0.5 * (hi[d] - lo[d]) * (1.0 + 1e-12) : 0.0;
+                pr.Bs[d] = pr.n ? std::max(std::fabs(lo[d]), std::fabs(hi[d])) * (1.0 + 1e-12) : 0.0;
             }
             if (!pr.trivial && pr.n) {
                 pr.idx.reset(new DevBuf());
@@ -1382,7 +1394,7 @@ class Sim : public SimBase {
     // for the group's top frequency).  Small grids are launch-bound, so they tolerate a wide
     // frequency ratio (more wasted cells, far fewer launches); large grids are HBM-bound and get
     // a narrow one.  cells_top = fine-grid cells per transform at the highest frequency.
-    std::vector<std::pair<int, int>> freq_groups(int f0, int f1, double cells_top) const {
+    std::vector<std::pair<int, int>> freq_groups(int f0, int f1, double cells_top, int tg) const {
         const char *er = std::getenv("FFTVIS_HIP_GROUP_RATIO");
         const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
         // 4 GiB of grid per launch measured best on C3 (3-4 GiB: 350 ms per two time steps, 8 GiB:
@@ -1402,7 +1414,7 @@ class Sim : public SimBase {
                 const double nlo = std::min(lo, std::fabs(freqs[b])), nhi = std::max(hi, std::fabs(freqs[b]));
                 if (nlo < ratio * nhi) break;
                 const double sc = nhi / fmax;
-                const double bytes = cells_top * sc * sc * (b + 1 - a) * tpol * sizeof(cplx<T>);
+                const double bytes = cells_top * sc * sc * (b + 1 - a) * tg * sizeof(cplx<T>);
                 if (bytes > budget) break;
                 lo = nlo;
                 hi = nhi;
@@ -1460,6 +1472,38 @@ class Sim : public SimBase {
         // source and target costs ~2x in 2-D), with NUFFT errors at or below sigma = 2's down to
         // eps ~ 1e-8 (fv_eskernel.h).  It pays when the FFT dominates: C3 (8192^2 cells, 1.1e5 points
         // per transform) 3.06 -> 1.57 s per step; C2 (1024 x 512, 5.7e3) would lose, 1.38 -> 1.58 ms.
+        // Hermitian packing (k_interp<.., HERM>): a pair whose two beams are the same has Hermitian
+        // strengths -- c_00, c_11 real, c_10 = conj(c_01) -- so two transforms per frequency (c_00 + i c_11,
+        // c_01) evaluated at the baseline and at its mirror image give all four products: half the
+        // spread, FFT and grid traffic of a polarized run.  The mirror targets need a box that is
+        // symmetric about 0; taken when that box costs at most 1.5x the cells of the tight one and
+        // the grid is large (small grids keep four transforms and the fused gather).
+        // FFTVIS_HIP_NO_HERMITIAN=1 turns it off.
+        {
+            const bool herm_off = std::getenv("FFTVIS_HIP_NO_HERMITIAN") != nullptr;  // read per run: tests flip it
+            const KerParams k2 = make_kernel(eps, 2.0);
+            double fmax = 0;
+            for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
+            for (Pair &p : pairs) {
+                p.herm = false;
+                if (!polarized || nbasis || herm_off || p.bi != p.bj || p.n == 0) continue;
+                double cs = 1.0, ct = 1.0;
+                for (int d = 0; d < D; ++d) {
+                    DimGeom gs, gt;
+                    gs.X = gt.X = X[d];
+                    gs.B = p.Bs[d];
+                    gt.B = p.B[d];
+                    set_dim_geom(gs, 2.0, k2.w, fmax);
+                    set_dim_geom(gt, 2.0, k2.w, fmax);
+                    cs *= gs.n2;
+                    ct *= gt.n2;
+                }
+                p.herm = cs >= 4.0e6 && cs <= 1.5 * ct;
+            }
+        }
+        int tg_max = 1;  // transforms per frequency on the grid, largest over the pairs
+        for (const Pair &p : pairs)
+            if (p.n) tg_max = std::max(tg_max, p.herm ? 2 : tpol);
         double sigma = this->sigma;
         if (sigma == 0.0) {
             const KerParams k2 = make_kernel(eps, 2.0);
@@ -1471,7 +1515,7 @@ class Sim : public SimBase {
                 DimGeom g;
                 g.X = X[d];
                 double Bm = 0;
-                for (const Pair &p : pairs) Bm = std::max(Bm, p.B[d]);
+                for (const Pair &p : pairs) Bm = std::max(Bm, p.box_B()[d]);
                 g.B = Bm;
                 set_dim_geom(g, 2.0, k2.w, fmax);
                 cells2 *= g.n2;
@@ -1503,7 +1547,7 @@ class Sim : public SimBase {
                 DimGeom g;
                 g.X = X[d];
                 double Bm = 0;
-                for (const Pair &p : pairs) Bm = std::max(Bm, p.B[d]);
+                for (const Pair &p : pairs) Bm = std::max(Bm, p.box_B()[d]);
                 g.B = Bm;
                 set_dim_geom(g, sigma, k.w, fmax);
                 na[d] = g.na;
@@ -1512,11 +1556,11 @@ class Sim : public SimBase {
             cells_top = 2.0 * std::max({na[2] * na[1] * na[0], na[2] * na[1] * no[0], na[2] * no[0] * no[1],
                                          no[2] * no[0] * no[1]});
         }
-        const auto groups = freq_groups(f0, f1, cells_top);
+        const auto groups = freq_groups(f0, f1, cells_top, tg_max);
 
         // two lanes while a group's grid buffers are small (launch-bound regime), else one
         int max_ntrans = 1;
-        for (const auto &grp : groups) max_ntrans = std::max(max_ntrans, (grp.second - grp.first) * tpol);
+        for (const auto &grp : groups) max_ntrans = std::max(max_ntrans, (grp.second - grp.first) * tg_max);
         const char *el = std::getenv("FFTVIS_HIP_LANES");
         int nlanes = el ? std::atoi(el)
                         : (cells_top * sizeof(cplx<T>) * max_ntrans <= 1.5 * 1024 * 1024 * 1024 ? 2 : 1);
@@ -1624,7 +1668,7 @@ class Sim : public SimBase {
                         double smax0 = 0;
                         for (int f = groups[0].first; f < groups[0].second; ++f)
                             smax0 = std::max(smax0, std::fabs(freqs[f]));
-                        nufft->set_geometry(xc, X, pr.btc, pr.B, smax0);
+                        nufft->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax0);
                         nufft->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
                                            D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mps[m]);
                         L.binned_ti = (tu + m) * nch + chunk;
@@ -1650,17 +1694,18 @@ class Sim : public SimBase {
 
             for (const auto &grp : groups) {
                 const int fa = grp.first, fb = grp.second, nfg = fb - fa;
-                const int ntrans = nfg * tpol;
                 double smax = 0;
                 for (int f = fa; f < fb; ++f) smax = std::max(smax, std::fabs(freqs[f]));
                 for (const Pair &pr : pairs) {
                     if (pr.n == 0) continue;
+                    const int tg = pr.herm ? 2 : tpol;  // transforms per frequency on the grid
+                    const int ntrans = nfg * tg;
                     for (int m = 0; m < nm; ++m) {
                         Lane &L = *Ls[m];
                         Nufft3<T> *nf_ = L.nufft.get();
                         // ---- geometry + bin sort (skipped when unchanged since last set) -------
                         size_t e1 = ev_begin(TM_PREP, ls);
-                        nf_->set_geometry(xc, X, pr.btc, pr.B, smax);
+                        nf_->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
                         if (L.binned_ti != (tu + m) * nch + chunk || L.binned_serial != nf_->geom_serial || nf_->M != M) {
                             nf_->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
                                              D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mps[m]);
@@ -1693,7 +1738,7 @@ class Sim : public SimBase {
                     // small 2-D grids: the last FFT pass serves the targets from its LDS tiles (no C
                     // buffer, no gather kernel); the output block was zeroed at the start of the run
                     const bool fused =
-                        !nbasis &&
+                        !nbasis && !pr.herm &&
                         nufft->prepare_fused_gather(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
                                                     pr.trivial ? nullptr : pr.idx->template as<int>(),
                                                     pr.trivial ? nullptr : pr.flip->template as<signed char>(),
@@ -1713,8 +1758,8 @@ class Sim : public SimBase {
                                   D > 2 ? d_bls.as<T>() + 2 * nbls : nullptr,
                                   pr.trivial ? nullptr : pr.idx->template as<int>(),
                                   pr.trivial ? nullptr : pr.flip->template as<signed char>(),
-                                  d_freqs.as<double>() + fa, nfg, tpol, obase + (int64_t)m * per_tf,
-                                  (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr);
+                                  d_freqs.as<double>() + fa, nfg, tg, obase + (int64_t)m * per_tf,
+                                  (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr, pr.herm);
                     ev_end(e5, ls);
                     st[4] += (double)pr.n * ntrans * nm;
                     st[6] = nufft->geo.d[0].n2;
@@ -1753,16 +1798,17 @@ class Sim : public SimBase {
         sa.polarized = polarized;
         sa.pol_sky = pol_sky;
         sa.same_beam = pr.bi == pr.bj;
+        sa.herm = pr.herm;
         sa.dim = D;
         sa.w = nufft->ker.w;
         for (int d = 0; d < 3; ++d) {
             sa.h[d] = nufft->geo.d[d].h;
-            sa.btc[d] = d < D ? pr.btc[d] : 0.0;
+            sa.btc[d] = d < D ? pr.box_c()[d] : 0.0;
             sa.na[d] = d < D ? nufft->geo.d[d].na : 1;
         }
         sa.bi = desc(pr.bi);
         sa.bj = desc(pr.bj);
-        cplx<T> *cs = nufft->strengths_buffer(nfg * tpol);
+        cplx<T> *cs = nufft->strengths_buffer(nfg * (pr.herm ? 2 : tpol));
         hipLaunchKernelGGL((beam_order == 3 ? k_strengths<T, 3> : k_strengths<T, 1>),
                            dim3(cdiv((int64_t)M * nfg, 256)), dim3(256), 0, on, sa, Mp,
                            nufft->perm.template as<int>(), L.d_srcidx.template as<int>(),

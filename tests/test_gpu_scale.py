@@ -276,3 +276,36 @@ def test_sharded_run_two_ranks_on_the_gpu(gpu, tmp_path):
     assert z["vis"].shape == single.shape == (12, 6, 2, 2, 666)
     assert rel_l2(z["vis"], single) < 1e-12
     assert [tuple(b) for b in z["blocks"]] == [(0, 3, 0, 12), (3, 6, 0, 12)]
+
+
+def test_hermitian_packing_matches_four_transforms(gpu, monkeypatch):
+    """Single-beam polarized runs on large grids pack their Hermitian strengths into two transforms per
+    frequency (c_00 + i c_11, c_01) and rebuild the four products from the baseline and its mirror image
+    (k_interp<.., HERM>).  Against the plain four-transform run (FFTVIS_HIP_NO_HERMITIAN=1) and the oracle:
+    unpolarized sky, polarized sky (complex c_01), a table beam with complex leakage, flipped baselines and
+    autos, a non-coplanar array (3-D transform), source chunks, fp32."""
+    cfg = synth.make_config("C3", nsrc=20_000, nfreq=3, ntimes=2)
+    bl = cfg["baselines"][::23] + [(5, 5), (340, 2), (349, 17)]   # autos, and pairs given "backwards"
+    cfg["baselines"] = bl
+    _, _, fl4 = synth.catalog(20_000, cfg["freqs"], 3, polarized_sky=True)
+    tilted = {k: v + np.array([0.0, 0.0, 0.02 * v[0] + 0.3 * np.sin(0.01 * v[1])]) for k, v in cfg["ants"].items()}
+    cases = {"unpolarized sky": cfg, "polarized sky": dict(cfg, fluxes=fl4),
+             "non-coplanar": dict(cfg, ants=tilted, baselines=bl[::9]),
+             "chunks": dict(cfg, min_chunks=3), "fp32": dict(cfg, precision=1, eps=1e-4)}
+    sub = list(range(0, len(bl), 40)) + [len(bl) - 3, len(bl) - 2, len(bl) - 1]
+    for name, c in cases.items():
+        monkeypatch.delenv("FFTVIS_HIP_NO_HERMITIAN", raising=False)
+        packed = fftvis_amd.simulate_vis(**c)
+        monkeypatch.setenv("FFTVIS_HIP_NO_HERMITIAN", "1")
+        plain = fftvis_amd.simulate_vis(**c)
+        tol = 2e-3 if name == "fp32" else TOL
+        d = rel_l2(packed, plain)
+        assert 0 < d < tol, (name, d)   # two different computations (not the same path twice), same answer
+        # every one of the four products separately, not just the block as a whole
+        for a in range(2):
+            for b in range(2):
+                assert rel_l2(packed[:, :, a, b], plain[:, :, a, b]) < 4 * tol, (name, a, b)
+        if name in ("unpolarized sky", "polarized sky"):
+            cs = dict(c, baselines=[c["baselines"][i] for i in sub])
+            assert rel_l2(packed[..., sub], oracle_simulate(cs)) < TOL, name
+    monkeypatch.delenv("FFTVIS_HIP_NO_HERMITIAN", raising=False)
