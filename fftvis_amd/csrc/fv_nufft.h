@@ -994,6 +994,17 @@ constexpr int ST_THREADS = 256;      // row mode
 constexpr int ST_THREADS_COL = 512;  // column mode
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v / 2); }
 
+// A pointer every lane of the wave holds the same value of, moved to scalar registers: global loads /
+// stores through it take the scalar-base + 32-bit-offset form (one VALU op per address instead of a
+// 64-bit multiply-add chain, and no address pairs kept in vector registers).
+template <typename P>
+__device__ inline P *wave_uniform_ptr(P *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<P *>(((uint64_t)hi << 32) | lo);
+}
+
 template <bool WAVE>
 __device__ inline void st_sync() {
     if constexpr (WAVE) {  // the row lives in one wavefront: LDS is in order, only the compiler must not reorder
@@ -1112,11 +1123,16 @@ __global__ void k_fg_build(int64_t N, int nfg, const T *__restrict__ btx, const 
 #ifndef FV_ST_DUAL
 #define FV_ST_DUAL 1
 #endif
-template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false>
+// FOLD: rows longer than Q (n_in > Q; NLD = R1).  Slot q of the length-Q row then holds
+//     w^{q p} sum_m x[q + m Q] c^m,      c = w^{Q p} = exp(2 pi i p / P)  (uniform),
+// over the m with -n_in/2 <= q + m Q < n_in - n_in/2: ceil(n_in / Q) + 1 sweeps of coalesced loads, one
+// uniform complex factor per sweep (none for p = 0), one per-slot twiddle at the end.
+template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false, bool FOLD = false>
 __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_ST_MINW12 : 4) void k_rowfft_st(
     const cplx<T> *__restrict__ in0, cplx<T> *__restrict__ out0, const cplx<T> *__restrict__ tw, RowDifArgs a,
     FusedArgs fz) {
     static_assert(!FUSED || COL, "the fused gather rides on the column-mode last pass");
+    static_assert(!FOLD || (!FUSED && NLD == (1 << (LOGQ == 9 ? 3 : 4))), "folding runs on full pass-1 operands");
     // gang launch: blockIdx.y = 1 runs the same transform on a second pair of buffers
     const cplx<T> *__restrict__ in = blockIdx.y ? static_cast<const cplx<T> *>(a.in1) : in0;
     cplx<T> *__restrict__ out = blockIdx.y ? static_cast<cplx<T> *>(a.out1) : out0;
@@ -1179,10 +1195,64 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     // elements with s = q (mod Q): one of them when n_in <= Q, else the extras are folded on top.
     cplx<T> va[R1];
     const int hshift = a.n_in / 2;
-    {
+    if constexpr (FOLD) {
+        const cplx<T> *rin = in + (ok ? rplane * a.in_plane + rk * a.in_row : 0);
+        if constexpr (!COL) rin = wave_uniform_ptr(rin);  // row mode: a row belongs to whole waves
+        const int qmax = a.n_in - 1;
+        const int nlo = a.n_in - hshift;                      // elements with s >= 0
+        const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
+        const int mmax = (nlo - 1) / Q;
+        constexpr int CH = 4;  // slots per sweep: 4 accumulators + 4 operands in flight beside va
+#pragma unroll
+        for (int h = 0; h < R1; h += CH) {
+            cplx<T> acc[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[j] = {T(0), T(0)};
+            for (int m = mmin; m <= mmax; ++m) {
+                // c^m = w^{(m Q p) mod n2}: m Q p is a multiple of Q, so the index is ((m p) mod P) Q
+                int mp = (m * p) % a.P;
+                if (mp < 0) mp += a.P;
+                const cplx<T> cm = tw[mp * Q];
+                const int off = m * Q + hshift;
+                cplx<T> x[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int ia = u + (h + j) * S1 + off;
+                    const bool live = ok && ia >= 0 && ia <= qmax;
+                    const int iac = min(max(ia, 0), qmax);
+                    x[j] = COL ? rin[(int64_t)iac * a.in_elem] : rin[(uint32_t)iac];
+                    if (!live) x[j] = {T(0), T(0)};
+                }
+                if (mp) {  // uniform
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        acc[j].re += x[j].re * cm.re - x[j].im * cm.im;
+                        acc[j].im += x[j].re * cm.im + x[j].im * cm.re;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        acc[j].re += x[j].re;
+                        acc[j].im += x[j].im;
+                    }
+                }
+            }
+            if (p) {
+                cplx<T> w[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) w[j] = tw[(u + (h + j) * S1) * p];  // q p < Q P = n2
+#pragma unroll
+                for (int j = 0; j < CH; ++j) acc[j] = cmul(acc[j], w[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) va[h + j] = acc[j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
         // branch-free loads (clamped index, masked afterwards) so that a chunk's requests issue
         // back to back; chunks of 8 bound the registers held by data + residue twiddles in flight
         const cplx<T> *rin = in + (ok ? rplane * a.in_plane + rk * a.in_row : 0);
+        if constexpr (!COL) rin = wave_uniform_ptr(rin);  // row mode: a row belongs to whole waves
         const int qmax = a.n_in - 1;
         const int nlo = a.n_in - hshift;  // elements with s >= 0
         constexpr int CH = NLD < 8 ? NLD : 8;
@@ -1202,7 +1272,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
                 live[j] = ok && ia >= 0 && ia <= qmax;
                 widx[j] = hi ? n2 - (Q - q) * p : q * p;  // (s p) mod n2; (Q - q) p < Q P = n2
                 const int iac = min(max(ia, 0), qmax);
-                x[j] = rin[COL ? (int64_t)iac * a.in_elem : (int64_t)iac];
+                x[j] = COL ? rin[(int64_t)iac * a.in_elem] : rin[(uint32_t)iac];
             }
             if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
                 cplx<T> w[CH];
@@ -1221,27 +1291,6 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         if constexpr (NLD < R1) {
 #pragma unroll
             for (int n1 = NH; n1 < R1 - NH; ++n1) va[n1] = {T(0), T(0)};
-        }
-        if (NLD == R1 && a.n_in > Q && ok) {
-            // fold: the elements the slots above did not take, as ranges of s (thread u owns the slots
-            // q = u mod S1, and S1 divides Q, so it walks each range in steps of S1)
-            auto fold = [&](int s_lo, int s_hi) {
-                if (s_lo >= s_hi) return;
-                for (int sv = s_lo + (((u - s_lo) % S1) + S1) % S1; sv < s_hi; sv += S1) {
-                    const int ia = sv + hshift;
-                    const int q = sv & (Q - 1);
-                    int64_t e = ((int64_t)sv * p) % n2;
-                    if (e < 0) e += n2;
-                    const cplx<T> xv = cmul(rin[COL ? (int64_t)ia * a.in_elem : (int64_t)ia], tw[e]);
-                    const int n1 = q / S1;
-#pragma unroll
-                    for (int j = 0; j < R1; ++j)
-                        if (j == n1) va[j] = {va[j].re + xv.re, va[j].im + xv.im};
-                }
-            };
-            fold(max(-hshift, -Q), min(0, nlo - Q));  // wrapped elements whose slot a direct one took
-            fold(Q, nlo);                              // direct elements beyond one period
-            fold(-hshift, -Q);                         // wrapped elements beyond one period
         }
     }
     dif_regs<T, R1>(va);
@@ -1336,6 +1385,9 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         rout = reinterpret_cast<cplx<T> *>(smem) + (int64_t)r * a.n_out + half_n;
         ostep = 1;
     }
+    // row mode: scalar base at the lowest address a thread can write (ks = -Q/2) + unsigned 32-bit offsets
+    cplx<T> *rlow = rout - (Q / 2) * ostep;
+    if constexpr (!COL) rlow = wave_uniform_ptr(rlow);
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
         const int v = u + i * TPR;
@@ -1345,7 +1397,12 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
             const int kk = v + k * (Q / R3);
             const int ks = kk < Q / 2 ? kk : kk - Q;
             const int l = a.P * ks + p;
-            if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
+            if (l >= -half_n && l < a.n_out - half_n) {
+                if constexpr (COL)
+                    rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
+                else
+                    rlow[(uint32_t)((ks + Q / 2) * ostep)] = vc[i][bitrev_small(k, L3)];
+            }
         }
     }
     if constexpr (FUSED) {
@@ -1497,7 +1554,8 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const int nouter = DIM == 3 ? w : 1;
     constexpr int NSIDE = HERM ? 2 : 1;   // the target and (HERM) its mirror image
     constexpr int NVAL = HERM ? 2 : 16;   // transforms per frequency held at once (non-HERM: streamed)
-    double vre[NSIDE][HERM ? NVAL : 1], vim[NSIDE][HERM ? NVAL : 1];
+    double vre[NSIDE][HERM ? NVAL : 1], vim[NSIDE][HERM ? NVAL : 1];  // compile-time indexed: registers
+#pragma unroll
     for (int side = 0; side < NSIDE; ++side) {
         const double sgn = side ? -1.0 : 1.0;
         int j0[DIM];
@@ -1515,7 +1573,9 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
         for (int r = 0; r < MAX_W; ++r) k1[r] = __shfl(kv[1], lane_base + r, 64);
         const int gcol = out_pos(min(j0[0] + g, a.no[0] - 1), a.P[0], a.cnt[0]);
         const double pis = side ? -pi_ : pi_;  // exp(i (-s) . x_c) = conj
-        for (int r = 0; r < a.tpol; ++r) {
+#pragma unroll
+        for (int r = 0; r < (HERM ? NVAL : 64); ++r) {
+            if (!HERM && r >= a.tpol) break;
             const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * plane_sz + gcol;
             T sr = T(0), si = T(0);
             for (int ro = 0; ro < nouter; ++ro) {
@@ -1547,10 +1607,8 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
             double vr = (double)sr * pr - (double)si * pis;
             double vi = (double)sr * pis + (double)si * pr;
             if constexpr (HERM) {
-                if (r < NVAL) {
-                    vre[side][r] = vr;
-                    vim[side][r] = vi;
-                }
+                vre[side][r] = vr;
+                vim[side][r] = vi;
                 continue;
             }
             if (g != 0) continue;
@@ -2080,7 +2138,10 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;
         const bool col = a.colmode != 0;
 #define FV_ST_GO(LQ, COLM, NLD)                                                                        \
-    if (COLM && fused)                                                                                 \
+    if (a.n_in > g.Q && NLD == (LQ == 9 ? 8 : 16))                                                     \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, (LQ == 9 ? 8 : 16), false, true>), jobs,          \
+                           dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, FusedArgs{}); \
+    else if (COLM && fused)                                                                            \
         hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, COLM>), jobs,                                \
                            dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, *fused); \
     else                                                                                               \
