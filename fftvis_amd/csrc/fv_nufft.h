@@ -116,9 +116,10 @@ inline void choose_pq(int nmin, DimGeom &g) {
             pp /= 2;
             ++bb;
         }
-        // every extra residue re-reads the row (from L2) and re-applies the input twiddles: measured
-        // on C3's mix of grid sizes, 0.15-0.4 per extra residue beats 0.03-0.1 by 4-5 % and >= 0.7
-        static const double pen = std::getenv("FFTVIS_HIP_PQ_PENALTY") ? std::atof(std::getenv("FFTVIS_HIP_PQ_PENALTY")) : 0.25;
+        // every extra residue re-reads the row (from L2) and re-applies the input twiddles: measured on C3's
+        // mix of grid sizes with the sweep-wise fold of k_rowfft_st<.., FOLD>: 0.05-0.12 per extra residue
+        // beats 0.25 by 2 % (10240 = 5 x 2048 instead of 12288 = 3 x 4096 for the widest grids)
+        static const double pen = std::getenv("FFTVIS_HIP_PQ_PENALTY") ? std::atof(std::getenv("FFTVIS_HIP_PQ_PENALTY")) : 0.12;
         const double cost = (double)p * q * (1.0 + pen * (pp - 1));
         if (best == 0 || cost < best) {
             best = cost;
@@ -1390,8 +1391,12 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     if constexpr (!COL) rlow = wave_uniform_ptr(rlow);
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
-        const int v = u + i * TPR;
+        int v = u + i * TPR;
+        // opaque to the optimiser: the output indices v + k Q/R3 are the same numbers as pass 1's slot indices,
+        // and kept alive from there they cost 16 registers for three passes (recomputing is one add each)
+        asm volatile("" : "+v"(v));
         dif_regs<T, R3>(vc[i]);
+        __builtin_amdgcn_sched_barrier(0);  // the outputs' index arithmetic stays behind the butterflies
 #pragma unroll
         for (int k = 0; k < R3; ++k) {
             const int kk = v + k * (Q / R3);
@@ -1799,6 +1804,7 @@ class Nufft3 {
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
             set_dim_geom(geo.d[d], sigma, ker.w, scale_max);
+            // (residue-major storage of the last dimension as well: C3's FFT passes -2.5 %, its gather +41 %)
             geo.d[d].rm = d != dim - 1 && !debug_switch_natural_order();
             geo.nbin[d] = geo.d[d].na >> BINLOG;
         for (int d = dim; d < 3; ++d) geo.nbin[d] = 1;
