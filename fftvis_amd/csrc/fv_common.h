@@ -5,11 +5,14 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
 
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -93,6 +96,33 @@ __host__ __device__ inline cplx<T> cscale(cplx<T> a, T s) {
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// roctx ranges around the launches of each kernel family ("prep", "strengths", "spread", "fft", "gather"), so
+// that a rocprofv3 --marker-trace / --kernel-trace run groups the kernels by family without parsing names.
+// Off unless FFTVIS_HIP_ROCTX=1: the library is looked up at run time (librocprofiler-sdk-roctx, else
+// libroctx64), nothing is linked.
+struct Roctx {
+    using push_t = int (*)(const char *);
+    using pop_t = int (*)();
+    push_t push = nullptr;
+    pop_t pop = nullptr;
+    Roctx();
+    static Roctx &get() {
+        static Roctx r;
+        return r;
+    }
+};
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(Roctx::get().push != nullptr) {
+        if (on) Roctx::get().push(name);
+    }
+    ~RoctxRange() {
+        if (on) Roctx::get().pop();
+    }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
+
 // Smallest even integer >= n whose only prime factors are 2, 3, 5 (the usual FFT-friendly sizes).
 inline int next235even(int n) {
     if (n <= 2) return 2;
@@ -103,6 +133,20 @@ inline int next235even(int n) {
         while (m % 3 == 0) m /= 3;
         while (m % 5 == 0) m /= 5;
         if (m == 1) return n;
+    }
+}
+
+inline Roctx::Roctx() {
+    const char *e = std::getenv("FFTVIS_HIP_ROCTX");
+    if (!e || !std::atoi(e)) return;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+        if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+            push = reinterpret_cast<push_t>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<pop_t>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
     }
 }
 

@@ -1396,7 +1396,6 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         // and kept alive from there they cost 16 registers for three passes (recomputing is one add each)
         asm volatile("" : "+v"(v));
         dif_regs<T, R3>(vc[i]);
-        __builtin_amdgcn_sched_barrier(0);  // the outputs' index arithmetic stays behind the butterflies
 #pragma unroll
         for (int k = 0; k < R3; ++k) {
             const int kk = v + k * (Q / R3);
@@ -1578,9 +1577,9 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
         for (int r = 0; r < MAX_W; ++r) k1[r] = __shfl(kv[1], lane_base + r, 64);
         const int gcol = out_pos(min(j0[0] + g, a.no[0] - 1), a.P[0], a.cnt[0]);
         const double pis = side ? -pi_ : pi_;  // exp(i (-s) . x_c) = conj
-#pragma unroll
-        for (int r = 0; r < (HERM ? NVAL : 64); ++r) {
-            if (!HERM && r >= a.tpol) break;
+        constexpr int RUNROLL = HERM ? NVAL : 1;  // HERM: two transforms, compile-time indexed results
+#pragma unroll RUNROLL
+        for (int r = 0; r < (HERM ? NVAL : a.tpol); ++r) {
             const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * plane_sz + gcol;
             T sr = T(0), si = T(0);
             for (int ro = 0; ro < nouter; ++ro) {

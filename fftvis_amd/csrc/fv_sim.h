@@ -1658,6 +1658,7 @@ class Sim : public SimBase {
             size_t hist_slot[2] = {0, 0};
             size_t e0 = ev_begin(TM_PREP, ps);
             for (int m = 0; m < nm; ++m) {
+                RoctxRange rr("prep");
                 Lane &L = *Ls[m];
                 Nufft3<T> *nufft = L.nufft.get();
                 nufft->stream = ps;
@@ -1704,6 +1705,7 @@ class Sim : public SimBase {
                         Lane &L = *Ls[m];
                         Nufft3<T> *nf_ = L.nufft.get();
                         // ---- geometry + bin sort (skipped when unchanged since last set) -------
+                        RoctxRange rr("prep");
                         size_t e1 = ev_begin(TM_PREP, ls);
                         nf_->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
                         if (L.binned_ti != (tu + m) * nch + chunk || L.binned_serial != nf_->geom_serial || nf_->M != M) {
@@ -1718,6 +1720,8 @@ class Sim : public SimBase {
                             launch_strengths(L, pr, fa, nfg, M, Mps[m], ls);
                     }
                     // ---- NUFFT ----------------------------------------------------------
+                    {
+                    RoctxRange rr("spread");
                     if (timing_level >= 2 || (timing_level == 1 && sampled)) {  // 2 and 3: every launch
                         const size_t e3 = ev_slot(TM_SPREAD);
                         nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b, mate);
@@ -1730,6 +1734,7 @@ class Sim : public SimBase {
                         heavy_recorded = true;
                     } else {
                         nufft->spread(ntrans, nullptr, nullptr, mate);
+                    }
                     }
                     st[0] += 1;
                     st[1] += (double)nufft->geo.cells_a() * ntrans * nm;
@@ -1746,9 +1751,13 @@ class Sim : public SimBase {
                                                     (int64_t)nt * per_tf, 1, pol_off, targets_serial,
                                                     mate ? obase + per_tf : nullptr);
                     size_t e4 = ev_begin(TM_FFT, ls);
-                    nufft->fft(ntrans, mate);
+                    {
+                        RoctxRange rr("fft");
+                        nufft->fft(ntrans, mate);
+                    }
                     ev_end(e4, ls);
                     st[3] += nufft->fft_traffic_cells() * ntrans * nm;
+                    RoctxRange rg("gather");
                     size_t e5 = ev_begin(TM_INTERP, ls);
                     BasisTerm bt{d_coefs.p, d_ant1.as<int>(), d_ant2.as<int>(), pr.bi, pr.bj, nbasis,
                                  (int)freqs.size(), fa};
@@ -1789,6 +1798,7 @@ class Sim : public SimBase {
     void launch_strengths(Lane &L, const Pair &pr, int fa, int nfg, int64_t M, const int *Mp, hipStream_t on) {
         Nufft3<T> *nufft = L.nufft.get();
         const int D = dim();
+        RoctxRange rr("strengths");
         size_t e2 = ev_begin(TM_STRENGTHS, on);
         StrengthArgs sa{};
         sa.M = M;

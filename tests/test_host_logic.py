@@ -359,3 +359,16 @@ def test_memory_and_coordinate_knobs_are_honoured_or_refused():
         eng.simulate(coord_method="SiderealRotation", source_buffer=0.0, **kw)
     with pytest.raises(ValueError, match="interpolation_function"):
         eng.simulate(coord_method="SiderealRotation", interpolation_function="healpix", **kw)
+
+
+def test_sanitizer_builds_of_the_cpu_code_are_clean():
+    """SURVEY section 5 / VERDICT r1 #8: AddressSanitizer + UBSan on the CPU builds -- the oracle's C files and
+    the HOST side of libfftvis_hip (argument checking and error reporting of every C-ABI entry point, driven by
+    tools/abi_sanitize_check.cpp; device code is not instrumented).  `make -C oracle sanitize` builds and runs
+    both and fails on any sanitizer report; neither needs a GPU."""
+    import subprocess
+
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "sanitize_check: ok" in r.stdout and "abi_sanitize_check: ok" in r.stdout

@@ -1,20 +1,33 @@
-# Collects what profiles/ holds for a round: bench lines, rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE
-# passes (run on the GPU box: gpurun -- bash tools/collect_profiles.sh; outputs under gpurun_out/final).
+# Collects what profiles/ holds for a round: bench lines, rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE passes
+# (run on the GPU box: gpurun -- bash tools/collect_profiles.sh; outputs under gpurun_out/final, then
+# python tools/refresh_profiles.py rNN copies the summaries into profiles/).
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
-python3 $R/bench.py > $O/bench_c2.json 2>$O/bench_c2.err &&
-python3 $R/bench.py --lanes 1 --no-cpu-baseline > $O/bench_c2_lanes1.json 2>/dev/null &&
-python3 $R/bench.py --lanes 2 --pipe 0 --no-cpu-baseline > $O/bench_c2_free.json 2>/dev/null &&
-python3 $R/bench.py --workload C3 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2>/dev/null &&
-python3 $R/bench.py --workload C3 --upsample 0 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c3_auto.json 2>/dev/null &&
-python3 $R/bench.py --workload C3 --path type1 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c3_type1.json 2>/dev/null &&
-python3 $R/bench.py --workload C5 --ntimes 2 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null &&
-python3 $R/bench.py --workload C5 --ntimes 2 --upsample 0 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_c5_auto.json 2>/dev/null &&
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -- python3 $R/bench.py --no-cpu-baseline --no-breakdown > $O/prof_c2.log 2>&1 &&
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python3 $R/bench.py --workload C3 --ntimes 2 --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_c3.log 2>&1 &&
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $O/pmc_fetch_c2.log 2>&1 &&
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_c2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $O/pmc_write_c2.log 2>&1 &&
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c3 -- python3 $R/bench.py --workload C3 --ntimes 1 --nfreq 16 --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_c3.log 2>&1 &&
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_c3 -- python3 $R/bench.py --workload C3 --ntimes 1 --nfreq 16 --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write_c3.log 2>&1
-echo rc=$?
-cut -c1-400 $O/bench_c2.json; echo; cut -c1-260 $O/bench_c2_free.json; echo; cut -c1-260 $O/bench_c3.json; echo; cut -c1-260 $O/bench_c3_type1.json; echo; cut -c1-300 $O/bench_c5.json
+B="python3 $R/bench.py"
+# ---- bench lines: the default (driver) workload C3, then the others, clearly named -----------------------
+$B > $O/bench_c3.json 2>$O/bench_c3.err &&
+$B --upsample 0 --no-cpu-baseline > $O/bench_c3_auto.json 2>/dev/null &&
+$B --path type1 --no-cpu-baseline > $O/bench_c3_type1.json 2>/dev/null &&
+FFTVIS_HIP_NO_HERMITIAN=1 $B --steps 2 --no-cpu-baseline > $O/bench_c3_four_transforms.json 2>/dev/null &&
+$B --workload C2 > $O/bench_c2.json 2>/dev/null &&
+$B --workload C5 --ntimes 2 --steps 2 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null &&
+$B --workload C4 --nfreq 32 --ntimes 2 --steps 2 --no-cpu-baseline > $O/bench_c4slice.json 2>/dev/null
+echo bench rc=$?
+# ---- rocprofv3 kernel stats of the same commands (no breakdown step: only launches shaped like the timed region) --
+prof() { # tag, bench args...
+  t=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$t -- python3 $R/bench.py "$@" --no-cpu-baseline --no-breakdown > $O/prof_$t.log 2>&1
+}
+prof c3 --steps 2 --warmup 1 && prof c2 --workload C2 && prof c4slice --workload C4 --nfreq 32 --ntimes 2 --steps 1 --warmup 1 &&
+prof c3type1 --path type1 --steps 1 --warmup 1
+echo prof rc=$?
+# ---- HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (kernel trace only), full-size launches ----
+pmc() { # tag, counter, bench args...
+  t=$1; c=$2; shift; shift
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_$t -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $O/pmc_${c}_$t.log 2>&1
+}
+for c in FETCH_SIZE WRITE_SIZE; do
+  pmc c3 $c --ntimes 1 && pmc c2 $c --workload C2 && pmc c4slice $c --workload C4 --nfreq 32 --ntimes 1 && pmc c3type1 $c --path type1 --ntimes 1
+done
+echo pmc rc=$?
+cut -c1-300 $O/bench_c3.json; echo; cut -c1-200 $O/bench_c2.json; echo; cut -c1-200 $O/bench_c3_type1.json; echo; cut -c1-200 $O/bench_c5.json; echo; cut -c1-200 $O/bench_c4slice.json
