@@ -1725,7 +1725,7 @@ class Sim : public SimBase {
                     if (timing_level >= 2 || (timing_level == 1 && sampled)) {  // 2 and 3: every launch
                         const size_t e3 = ev_slot(TM_SPREAD);
                         nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b, mate);
-                        spread_timed += 1;
+                        spread_timed += nm;  // a gang launch serves nm time steps: counted per time step
                     } else if (ride_heavy_done && pipe && &grp == &groups.back() && &pr == last_pair) {
                         // the unit's last spread is the last reader of the lanes' per-time arrays (the FFT
                         // passes and the gather work on the grids): its dispatch carries the "lane scratch
@@ -1736,7 +1736,7 @@ class Sim : public SimBase {
                         nufft->spread(ntrans, nullptr, nullptr, mate);
                     }
                     }
-                    st[0] += 1;
+                    st[0] += nm;  // launches are counted per (time, frequency group, beam pair)
                     st[1] += (double)nufft->geo.cells_a() * ntrans * nm;
                     for (int m = 0; m < nm; ++m) mhist_log[hist_slot[m]].second += ntrans;
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (tu - t0)) * per_tf;

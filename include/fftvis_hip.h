@@ -190,7 +190,8 @@ int fv_sim_run(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int out_on_
 int fv_sim_sync(fv_sim *h);
 
 /* Introspection for bench/roofline: fills up to n doubles:
- * [0] spread kernel launches, [1] fine-grid cells written by spread (all trans, summed),
+ * [0] spread launches, counted per (time, frequency group, beam pair) -- a gang launch that serves two
+ * time steps counts twice, and a launch's transforms may run as several kernel launches --, [1] fine-grid cells written by spread (all trans, summed),
  * [2] source x trans visits, [3] cells moved through HBM by the pruned FFT passes,
  * [4] interp targets x trans, [5] above-horizon sources summed over times, [6] last n2x,
  * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w, [10] upsampling factor the
