@@ -1397,9 +1397,10 @@ class Sim : public SimBase {
     std::vector<std::pair<int, int>> freq_groups(int f0, int f1, double cells_top, int tg) const {
         const char *er = std::getenv("FFTVIS_HIP_GROUP_RATIO");
         const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
-        // 4 GiB of grid per launch measured best on C3 (3-4 GiB: 350 ms per two time steps, 8 GiB:
-        // 362, 2 GiB: 364, 1 GiB: 369)
-        const double budget = eb ? std::atof(eb) : 4.0 * 1024 * 1024 * 1024;
+        // grid bytes per launch, measured on C3: round 1 (four transforms per frequency) 3-4 GiB 350 ms per two
+        // time steps, 8 GiB 362, 2 GiB 364, 1 GiB 369; round 2 (two per frequency, groups of whole eights):
+        // 6 GiB 416.7 ms per four time steps (spread at 0.64 of the HBM roofline), 4 GiB 421.7 (0.54), 3 GiB 422.7
+        const double budget = eb ? std::atof(eb) : 6.0 * 1024 * 1024 * 1024;
         double fmax = 1.0;
         for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
         const double mb = cells_top * sizeof(cplx<T>) / (1024.0 * 1024.0);
@@ -1420,6 +1421,12 @@ class Sim : public SimBase {
                 hi = nhi;
                 ++b;
             }
+            // whole spread chunks: a launch's transforms run as kernel launches of 16 / 8 / 4 / 2 / 1, and the
+            // small ones re-walk the sources for few cells' worth of stores (14 transforms = 8 + 4 + 2: 0.52 of
+            // the HBM roofline against 0.58 for 8 or 16); large grids therefore take groups of whole eights
+            static const int quant = std::getenv("FFTVIS_HIP_GROUP_QUANT") ? std::atoi(std::getenv("FFTVIS_HIP_GROUP_QUANT")) : 8;
+            const int cq = std::max(1, quant / std::max(tg, 1));  // channels per `quant` transforms
+            if (quant > 1 && mb >= 64.0 && b - a > cq && b < f1) b = a + (b - a) / cq * cq;
             g.emplace_back(a, b);
             a = b;
         }
