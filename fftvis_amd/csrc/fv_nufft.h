@@ -1663,11 +1663,22 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
         o_re[2] = vre[1][1];         // conj D
         o_im[2] = -vim[1][1];
         cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + k * a.out_k_stride;
+        cplx<double> w1 = {1.0, 0.0};
+        if (a.basis) {  // eigenbeam term (k, k): vis += conj(C[a1,k]) C[a2,k] V   (cpu_simulate.py:461-468)
+            const int f = a.f_first + fg;
+            const cplx<T> c1k = coef[((int64_t)ant1[k] * a.nbasis + a.kk) * a.ncoef_freq + f];
+            const cplx<T> c2l = coef[((int64_t)ant2[k] * a.nbasis + a.ll) * a.ncoef_freq + f];
+            w1 = cmul(cplx<double>{(double)c1k.re, -(double)c1k.im}, cplx<double>{(double)c2l.re, (double)c2l.im});
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double vr = o_re[r], vi = sg < 0 ? -o_im[r] : o_im[r];  // conj for flipped baselines
+            double vr = o_re[r], vi = sg < 0 ? -o_im[r] : o_im[r];  // conj for flipped baselines
             cplx<T> *o = ob + a.out_pol_off[r];
-            if (a.accumulate) {
+            if (a.basis) {
+                const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
+                o->re += (T)v1.re;
+                o->im += (T)v1.im;
+            } else if (a.accumulate) {
                 o->re += (T)vr;
                 o->im += (T)vi;
             } else {
@@ -2339,7 +2350,8 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
                        cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                        const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis, bool herm) {
     if (N == 0 || nfg == 0) return;
-    FV_REQUIRE(!herm || (tpol == 2 && !basis), "Hermitian gather: two transforms per frequency, no eigenbeams");
+    FV_REQUIRE(!herm || (tpol == 2 && (!basis || basis->kk == basis->ll)),
+               "Hermitian gather: two transforms per frequency; eigenbeam terms only on the diagonal");
     InterpArgs a{};
     const cplx<T> *coef = nullptr;
     const int *ant1 = nullptr, *ant2 = nullptr;

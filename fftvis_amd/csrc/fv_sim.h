@@ -1484,8 +1484,8 @@ class Sim : public SimBase {
         // c_01) evaluated at the baseline and at its mirror image give all four products: half the
         // spread, FFT and grid traffic of a polarized run.  The mirror targets need a box that is
         // symmetric about 0; taken when that box costs at most 1.5x the cells of the tight one and
-        // the grid is large (small grids keep four transforms and the fused gather).
-        // FFTVIS_HIP_NO_HERMITIAN=1 turns it off.
+        // the grid is large (small grids keep four transforms and the fused gather).  In eigenbeam mode the
+        // diagonal (k, k) terms qualify.  FFTVIS_HIP_NO_HERMITIAN=1 turns it off.
         {
             const bool herm_off = std::getenv("FFTVIS_HIP_NO_HERMITIAN") != nullptr;  // read per run: tests flip it
             const KerParams k2 = make_kernel(eps, 2.0);
@@ -1493,7 +1493,7 @@ class Sim : public SimBase {
             for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
             for (Pair &p : pairs) {
                 p.herm = false;
-                if (!polarized || nbasis || herm_off || p.bi != p.bj || p.n == 0) continue;
+                if (!polarized || herm_off || p.bi != p.bj || p.n == 0) continue;  // eigenbeams: the (k, k) terms
                 double cs = 1.0, ct = 1.0;
                 for (int d = 0; d < D; ++d) {
                     DimGeom gs, gt;

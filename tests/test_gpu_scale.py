@@ -55,7 +55,7 @@ def test_sim_c4_million_sources(gpu, monkeypatch):
     assert rel_l2(v4, v) < 1e-9
 
 
-def test_sim_c5_eigenbeams_fp32(gpu):
+def test_sim_c5_eigenbeams_fp32(gpu, monkeypatch):
     """configs[4]'s shape: HERA-350, 1e5 sources, K = 4 tabulated basis beams with per-antenna coefficients,
     precision 1, eps 1e-4, all 61 075 baselines, 2 channels x 1 time.  (a) a random subset of baselines
     against the oracle's eigenbeam path (cpu_simulate.py:303-470 restated) at the fp32 tolerance the
@@ -70,6 +70,11 @@ def test_sim_c5_eigenbeams_fp32(gpu):
     sub = sorted(rng.choice(61075, 24, replace=False))
     exact = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
     assert rel_l2(v[..., sub], exact) < 2e-3
+    # the diagonal (k, k) terms ride the Hermitian packing (two transforms instead of four): same answer without it
+    monkeypatch.setenv("FFTVIS_HIP_NO_HERMITIAN", "1")
+    plain = fftvis_amd.simulate_vis(**cfg)
+    monkeypatch.delenv("FFTVIS_HIP_NO_HERMITIAN")
+    assert 0 < rel_l2(v, plain) < 2e-3
     # (b) basis == per-antenna beams
     antnums = list(cfg["ants"])
     chosen = [0, 57, 211, 325, 337, 349]  # core antennas and outriggers
