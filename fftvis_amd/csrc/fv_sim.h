@@ -592,7 +592,7 @@ __global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent, int
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= min((int64_t)*nent, ecap)) return;  // entries beyond the capacity were dropped (and flagged) by k_t1_bin
     const int id = reinterpret_cast<const int *>(recs + e * rec)[2];
-    const int tp = a.polarized ? 4 : 1;
+    const int tp = a.herm ? 2 : a.polarized ? 4 : 1;
     strength_eval<T, ORD>(a, id / a.nfg, a.f_first + id % a.nfg, cplx<double>{1.0, 0.0}, src_idx, az, za,
                      flux, freqs, cs + e * tp);
 }
@@ -667,7 +667,8 @@ __global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int P, int cnt,
                           const int *__restrict__ blx, const int *__restrict__ bly, int64_t N,
                           const int *__restrict__ bl_idx, const signed char *__restrict__ flip,
                           const T *__restrict__ dec, cplx<T> *__restrict__ out,
-                          int64_t out_fg_stride, int64_t p0, int64_t p1, int64_t p2, int64_t p3, bool accumulate) {
+                          int64_t out_fg_stride, int64_t p0, int64_t p1, int64_t p2, int64_t p3, bool accumulate,
+                          bool herm) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * nfg) return;
     const int f = (int)(idx / N);
@@ -678,6 +679,27 @@ __global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int P, int cnt,
     const int lx = mx + no / 2, ly = my + no / 2;
     const T d = dec[lx] * dec[ly];
     const int64_t pol[4] = {p0, p1, p2, p3};
+    if (herm) {
+        // Hermitian packing (see k_interp): planes T1 = F[c_00 + i c_11], T2 = F[c_01]; the mirror mode
+        // (-mx, -my) is on the grid too and shares the deconvolution factor (psi_hat is even)
+        const int lxm = -mx + no / 2, lym = -my + no / 2;
+        const int64_t rows = (int64_t)P * cnt;
+        const cplx<T> *X1 = X + ((int64_t)f * 2) * rows * no, *X2 = X1 + rows * no;
+        const cplx<T> Pp = X1[(int64_t)out_pos(lx, P, cnt) * no + ly], Mm = X1[(int64_t)out_pos(lxm, P, cnt) * no + lym];
+        const cplx<T> C = X2[(int64_t)out_pos(lx, P, cnt) * no + ly], D = X2[(int64_t)out_pos(lxm, P, cnt) * no + lym];
+        const T h = T(0.5) * d;
+        cplx<T> v[4];
+        v[0] = {h * (Pp.re + Mm.re), h * (Pp.im - Mm.im)};   // (P + conj M) / 2
+        v[3] = {h * (Pp.im + Mm.im), -h * (Pp.re - Mm.re)};  // (P - conj M) / 2i
+        v[1] = {d * C.re, d * C.im};
+        v[2] = {d * D.re, -d * D.im};                        // conj D
+        for (int r = 0; r < 4; ++r) {
+            if (fl) v[r].im = -v[r].im;
+            cplx<T> &o = out[(int64_t)f * out_fg_stride + pol[r] + k];
+            o = accumulate ? cplx<T>{o.re + v[r].re, o.im + v[r].im} : v[r];
+        }
+        return;
+    }
     for (int r = 0; r < tp; ++r) {
         // rows (lx) are stored residue-major (DimGeom::out_pos), the contiguous ly in natural order
         cplx<T> v = X[(((int64_t)f * tp + r) * ((int64_t)P * cnt) + out_pos(lx, P, cnt)) * no + ly];
@@ -1311,6 +1333,10 @@ class Sim : public SimBase {
                     sa.polarized = polarized;
                     sa.pol_sky = pol_sky;
                     sa.same_beam = pr.bi == pr.bj;
+                    // Hermitian packing: two planes per frequency instead of four for a single-beam pair
+                    const bool herm1 = polarized && pr.bi == pr.bj && std::getenv("FFTVIS_HIP_NO_HERMITIAN") == nullptr;
+                    const int tg = herm1 ? 2 : tpol;
+                    sa.herm = herm1;
                     sa.dim = 2;
                     sa.bi = desc(pr.bi);
                     sa.bj = desc(pr.bj);
@@ -1321,11 +1347,16 @@ class Sim : public SimBase {
                                        d_az.as<T>(), d_za.as<T>(), d_flux.p, d_freqs.as<double>(),
                                        t1_cs.as<cplx<T>>());
                     ev_end(e2, stream);
-                    const int nplanes = nfg * tpol;
+                    const int nplanes = nfg * tg;
                     cplx<T> *A = t1fft->fft_input(nplanes);
                     size_t e3 = ev_begin(TM_SPREAD, stream);
                     const dim3 gs((unsigned)cdiv(g.n2 >> BINLOG, 4), (unsigned)(g.n2 >> BINLOG), (unsigned)nfg);
-                    if (polarized)
+                    if (herm1)
+                        hipLaunchKernelGGL((k_t1_spread<T, 2>), gs, dim3(SPREAD_THREADS), 0, stream, a,
+                                           (const unsigned char *)recs.as<unsigned char>(),
+                                           (const int *)binstart.as<int>(),
+                                           (const cplx<T> *)t1_cs.as<cplx<T>>(), A);
+                    else if (polarized)
                         hipLaunchKernelGGL((k_t1_spread<T, 4>), gs, dim3(SPREAD_THREADS), 0, stream, a,
                                            (const unsigned char *)recs.as<unsigned char>(),
                                            (const int *)binstart.as<int>(),
@@ -1346,14 +1377,14 @@ class Sim : public SimBase {
                     size_t e5 = ev_begin(TM_INTERP, stream);
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (ti - t0)) * per_tf;
                     hipLaunchKernelGGL(k_t1_pick<T>, dim3(cdiv(pr.n * nfg, 256)), dim3(256), 0, stream,
-                                       t1fft->fft_output(), g.no, g.P, g.cnt(), nfg, tpol,
+                                       t1fft->fft_output(), g.no, g.P, g.cnt(), nfg, tg,
                                        (const int *)d_blint.as<int>(),
                                        (const int *)d_blint.as<int>() + nbls, pr.n,
                                        pr.trivial ? (const int *)nullptr : (const int *)pr.idx->template as<int>(),
                                        pr.trivial ? (const signed char *)nullptr
                                                   : (const signed char *)pr.flip->template as<signed char>(),
                                        (const T *)t1_dec.as<T>(), obase, (int64_t)nt * per_tf, pol_off[0],
-                                       pol_off[1], pol_off[2], pol_off[3], chunk > 0);
+                                       pol_off[1], pol_off[2], pol_off[3], chunk > 0, herm1);
                     ev_end(e5, stream);
                     st[4] += (double)pr.n * nplanes;
                     st[6] = g.n2;
