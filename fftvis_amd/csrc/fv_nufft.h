@@ -1006,6 +1006,45 @@ __device__ inline P *wave_uniform_ptr(P *p) {
     return reinterpret_cast<P *>(((uint64_t)hi << 32) | lo);
 }
 
+// Buffer-descriptor access to one row of complex elements (row mode: the row belongs to whole waves, so base
+// and extent are wave-uniform).  The hardware range check replaces the clamp / compare / select per element:
+// a load at an element index outside [0, n) -- negative indices wrap to huge unsigned offsets -- returns
+// zero, a store there is dropped.  n = 0 switches the row off altogether.
+template <typename T>
+struct RowBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ RowBuf(const cplx<T> *base, int64_t n_elems) {
+        const cplx<T> *b = wave_uniform_ptr(base);
+        const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(n_elems * (int64_t)sizeof(cplx<T>)));
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx<T> *>(b), 0, bytes, 0x00020000);
+    }
+    __device__ cplx<T> load(int idx) const {
+        const uint32_t off = (uint32_t)idx * (uint32_t)sizeof(cplx<T>);
+        if constexpr (sizeof(T) == 8) {
+            using v4 = unsigned int __attribute__((ext_vector_type(4)));
+            const v4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            return __builtin_bit_cast(cplx<T>, r);
+        } else {
+            using v2 = unsigned int __attribute__((ext_vector_type(2)));
+            const v2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+            return __builtin_bit_cast(cplx<T>, r);
+        }
+    }
+    __device__ void store(int idx, cplx<T> v) const {
+        const uint32_t off = (uint32_t)idx * (uint32_t)sizeof(cplx<T>);
+        if constexpr (sizeof(T) == 8) {
+            using v4 = unsigned int __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4, v), rsrc, off, 0, 0);
+        } else {
+            using v2 = unsigned int __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2, v), rsrc, off, 0, 0);
+        }
+    }
+};
+__host__ __device__ inline int ceil_div_signed(int a, int b) {  // ceil(a / b), b > 0
+    return a >= 0 ? (a + b - 1) / b : -((-a) / b);
+}
+
 template <bool WAVE>
 __device__ inline void st_sync() {
     if constexpr (WAVE) {  // the row lives in one wavefront: LDS is in order, only the compiler must not reorder
@@ -1198,7 +1237,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     const int hshift = a.n_in / 2;
     if constexpr (FOLD) {
         const cplx<T> *rin = in + (ok ? rplane * a.in_plane + rk * a.in_row : 0);
-        if constexpr (!COL) rin = wave_uniform_ptr(rin);  // row mode: a row belongs to whole waves
+        const RowBuf<T> rowin(rin, COL || !ok ? 0 : a.n_in);  // row mode: a row belongs to whole waves
         const int qmax = a.n_in - 1;
         const int nlo = a.n_in - hshift;                      // elements with s >= 0
         const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
@@ -1219,10 +1258,14 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const int ia = u + (h + j) * S1 + off;
-                    const bool live = ok && ia >= 0 && ia <= qmax;
-                    const int iac = min(max(ia, 0), qmax);
-                    x[j] = COL ? rin[(int64_t)iac * a.in_elem] : rin[(uint32_t)iac];
-                    if (!live) x[j] = {T(0), T(0)};
+                    if constexpr (COL) {
+                        const bool live = ok && ia >= 0 && ia <= qmax;
+                        const int iac = min(max(ia, 0), qmax);
+                        x[j] = rin[(int64_t)iac * a.in_elem];
+                        if (!live) x[j] = {T(0), T(0)};
+                    } else {
+                        x[j] = rowin.load(ia);  // zero outside [0, n_in)
+                    }
                 }
                 if (mp) {  // uniform
 #pragma unroll
@@ -1253,7 +1296,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         // branch-free loads (clamped index, masked afterwards) so that a chunk's requests issue
         // back to back; chunks of 8 bound the registers held by data + residue twiddles in flight
         const cplx<T> *rin = in + (ok ? rplane * a.in_plane + rk * a.in_row : 0);
-        if constexpr (!COL) rin = wave_uniform_ptr(rin);  // row mode: a row belongs to whole waves
+        const RowBuf<T> rowin(rin, COL || !ok ? 0 : a.n_in);  // row mode: a row belongs to whole waves
         const int qmax = a.n_in - 1;
         const int nlo = a.n_in - hshift;  // elements with s >= 0
         constexpr int CH = NLD < 8 ? NLD : 8;
@@ -1270,15 +1313,20 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
                 // slot q: the element with s = q if there is one, else the wrapped one with s = q - Q
                 const bool hi = NLD == R1 ? q >= nlo : h + j >= NH;
                 const int ia = (hi ? q - Q : q) + hshift;
-                live[j] = ok && ia >= 0 && ia <= qmax;
                 widx[j] = hi ? n2 - (Q - q) * p : q * p;  // (s p) mod n2; (Q - q) p < Q P = n2
-                const int iac = min(max(ia, 0), qmax);
-                x[j] = COL ? rin[(int64_t)iac * a.in_elem] : rin[(uint32_t)iac];
+                if constexpr (COL) {
+                    live[j] = ok && ia >= 0 && ia <= qmax;
+                    const int iac = min(max(ia, 0), qmax);
+                    x[j] = rin[(int64_t)iac * a.in_elem];
+                } else {
+                    live[j] = true;         // the buffer load returns zero outside [0, n_in)
+                    x[j] = rowin.load(ia);
+                }
             }
             if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
                 cplx<T> w[CH];
 #pragma unroll
-                for (int j = 0; j < CH; ++j) w[j] = tw[live[j] ? widx[j] : 0];
+                for (int j = 0; j < CH; ++j) w[j] = tw[COL ? (live[j] ? widx[j] : 0) : widx[j]];  // widx is always a valid index
 #pragma unroll
                 for (int j = 0; j < CH; ++j) x[j] = cmul(x[j], w[j]);
             }
@@ -1386,9 +1434,11 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         rout = reinterpret_cast<cplx<T> *>(smem) + (int64_t)r * a.n_out + half_n;
         ostep = 1;
     }
-    // row mode: scalar base at the lowest address a thread can write (ks = -Q/2) + unsigned 32-bit offsets
-    cplx<T> *rlow = rout - (Q / 2) * ostep;
-    if constexpr (!COL) rlow = wave_uniform_ptr(rlow);
+    // row mode: a buffer descriptor over exactly this residue's run of outputs, ks in [ks_lo, ks_hi): stores
+    // outside it are dropped by the range check -- no compare, no exec masking, no branch per output
+    const int ks_lo = ceil_div_signed(-half_n - p, a.P), ks_hi = ceil_div_signed(a.n_out - half_n - p, a.P);
+    const RowBuf<T> rowout(rout + (int64_t)ks_lo * ostep,
+                           COL || !ok || ks_hi <= ks_lo ? 0 : (int64_t)(ks_hi - ks_lo - 1) * ostep + 1);
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
         int v = u + i * TPR;
@@ -1401,11 +1451,10 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
             const int kk = v + k * (Q / R3);
             const int ks = kk < Q / 2 ? kk : kk - Q;
             const int l = a.P * ks + p;
-            if (l >= -half_n && l < a.n_out - half_n) {
-                if constexpr (COL)
-                    rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
-                else
-                    rlow[(uint32_t)((ks + Q / 2) * ostep)] = vc[i][bitrev_small(k, L3)];
+            if constexpr (COL) {
+                if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
+            } else {
+                rowout.store((ks - ks_lo) * ostep, vc[i][bitrev_small(k, L3)]);
             }
         }
     }

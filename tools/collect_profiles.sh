@@ -11,7 +11,9 @@ $B --path type1 --no-cpu-baseline > $O/bench_c3_type1.json 2>/dev/null &&
 FFTVIS_HIP_NO_HERMITIAN=1 $B --steps 2 --no-cpu-baseline > $O/bench_c3_four_transforms.json 2>/dev/null &&
 $B --workload C2 > $O/bench_c2.json 2>/dev/null &&
 $B --workload C5 --ntimes 2 --steps 2 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null &&
-$B --workload C4 --nfreq 32 --ntimes 2 --steps 2 --no-cpu-baseline > $O/bench_c4slice.json 2>/dev/null
+$B --workload C4 --nfreq 32 --ntimes 2 --steps 2 --no-cpu-baseline > $O/bench_c4slice.json 2>/dev/null &&
+$B --workload C4 --steps 1 --warmup 0 --no-cpu-baseline --no-breakdown > $O/bench_c4_full.json 2>/dev/null &&
+$B --workload C5 --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $O/bench_c5_full.json 2>/dev/null
 echo bench rc=$?
 # ---- rocprofv3 kernel stats of the same commands (no breakdown step: only launches shaped like the timed region) --
 prof() { # tag, bench args...
@@ -30,4 +32,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc c3 $c --ntimes 1 && pmc c2 $c --workload C2 && pmc c4slice $c --workload C4 --nfreq 32 --ntimes 1 && pmc c3type1 $c --path type1 --ntimes 1
 done
 echo pmc rc=$?
-cut -c1-300 $O/bench_c3.json; echo; cut -c1-200 $O/bench_c2.json; echo; cut -c1-200 $O/bench_c3_type1.json; echo; cut -c1-200 $O/bench_c5.json; echo; cut -c1-200 $O/bench_c4slice.json
+cut -c1-300 $O/bench_c3.json; echo; cut -c1-200 $O/bench_c2.json; echo; cut -c1-200 $O/bench_c3_type1.json; echo; cut -c1-200 $O/bench_c5.json; echo; cut -c1-200 $O/bench_c4slice.json; echo; cut -c1-260 $O/bench_c4_full.json; echo; cut -c1-260 $O/bench_c5_full.json
