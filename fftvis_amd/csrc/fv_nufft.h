@@ -1534,6 +1534,7 @@ struct InterpArgs {
     int64_t out_k_stride;
     int64_t out_pol_off[16];      // offset of polarisation product r (r < tpol <= 16); beyond: r * out_pol_off[1]
     int accumulate;               // out += instead of out =
+    int herm;                     // 0 | 1 Hermitian strengths | 2 all-real strengths (k_interp<.., HERM>)
     // eigenbeam contraction (cpu_simulate.py:461-468): when basis != 0 every value is added as
     //   conj(C[a1,kk,f]) C[a2,ll,f] V_r            at polarisation slot r, and (kk != ll) as
     //   conj(C[a1,ll,f]) C[a2,kk,f] V_r            at the feed-transposed slot.
@@ -1546,7 +1547,9 @@ struct InterpArgs {
 //   V_00(s) = (T1(s) + conj(T1(-s))) / 2,   V_11(s) = (T1(s) - conj(T1(-s))) / 2i,
 //   V_01(s) = T2(s),                        V_10(s) = conj(T2(-s)),
 // exact identities of the non-uniform DFT of real / conjugate-paired strengths.  The caller plans a box
-// that is symmetric about s = 0, so that -s is a target like any other.
+// that is symmetric about s = 0, so that -s is a target like any other.  herm = 2: all four strengths are
+// real (real-valued Jones matrices on both sides, unpolarized sky), T2 = F[c_01 + i c_10] and
+//   V_01(s) = (T2(s) + conj(T2(-s))) / 2,   V_10(s) = (T2(s) - conj(T2(-s))) / 2i.
 template <typename T, int DIM, bool HERM>
 __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ bt0,
@@ -1707,17 +1710,31 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
         o_im[0] = 0.5 * (Pi - Mi);
         o_re[3] = 0.5 * (Pi + Mi);   // (P - conj M) / 2i = -i/2 ((Pr - Mr) + i (Pi + Mi))
         o_im[3] = -0.5 * (Pr - Mr);
-        o_re[1] = vre[0][1];         // C
-        o_im[1] = vim[0][1];
-        o_re[2] = vre[1][1];         // conj D
-        o_im[2] = -vim[1][1];
+        const double Cr = vre[0][1], Ci = vim[0][1], Dr = vre[1][1], Di = vim[1][1];
+        if (a.herm == 2) {  // all four strengths real: T2 = F[c_01 + i c_10], unpacked like T1
+            o_re[1] = 0.5 * (Cr + Dr);
+            o_im[1] = 0.5 * (Ci - Di);
+            o_re[2] = 0.5 * (Ci + Di);
+            o_im[2] = -0.5 * (Cr - Dr);
+        } else {            // Hermitian strengths: T2 = F[c_01], c_10 = conj c_01
+            o_re[1] = Cr;   // C
+            o_im[1] = Ci;
+            o_re[2] = Dr;   // conj D
+            o_im[2] = -Di;
+        }
         cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + k * a.out_k_stride;
-        cplx<double> w1 = {1.0, 0.0};
-        if (a.basis) {  // eigenbeam term (k, k): vis += conj(C[a1,k]) C[a2,k] V   (cpu_simulate.py:461-468)
+        cplx<double> w1 = {1.0, 0.0}, w2 = {0.0, 0.0};
+        if (a.basis) {  // eigenbeam term (k, l): vis += conj(C[a1,k]) C[a2,l] V  (+ the transposed (l, k) term)
             const int f = a.f_first + fg;
-            const cplx<T> c1k = coef[((int64_t)ant1[k] * a.nbasis + a.kk) * a.ncoef_freq + f];
-            const cplx<T> c2l = coef[((int64_t)ant2[k] * a.nbasis + a.ll) * a.ncoef_freq + f];
+            const int64_t cs1 = (int64_t)ant1[k] * a.nbasis, cs2 = (int64_t)ant2[k] * a.nbasis;
+            const cplx<T> c1k = coef[(cs1 + a.kk) * a.ncoef_freq + f];
+            const cplx<T> c2l = coef[(cs2 + a.ll) * a.ncoef_freq + f];
             w1 = cmul(cplx<double>{(double)c1k.re, -(double)c1k.im}, cplx<double>{(double)c2l.re, (double)c2l.im});
+            if (a.kk != a.ll) {  // cpu_simulate.py:464-468
+                const cplx<T> c1l = coef[(cs1 + a.ll) * a.ncoef_freq + f];
+                const cplx<T> c2k = coef[(cs2 + a.kk) * a.ncoef_freq + f];
+                w2 = cmul(cplx<double>{(double)c1l.re, -(double)c1l.im}, cplx<double>{(double)c2k.re, (double)c2k.im});
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1727,6 +1744,12 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                 const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
                 o->re += (T)v1.re;
                 o->im += (T)v1.im;
+                if (a.kk != a.ll) {
+                    const cplx<double> v2 = cmul(w2, cplx<double>{vr, vi});
+                    cplx<T> *o2 = ob + a.out_pol_off[(r & 1) * 2 + (r >> 1)];  // feed-transposed slot
+                    o2->re += (T)v2.re;
+                    o2->im += (T)v2.im;
+                }
             } else if (a.accumulate) {
                 o->re += (T)vr;
                 o->im += (T)vi;
@@ -2034,7 +2057,7 @@ class Nufft3 {
                 const signed char *flip, const double *scale_dev, int nfg, int tpol,
                 cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                 const int64_t *out_pol_off, bool accumulate, const struct BasisTerm *basis = nullptr,
-                bool herm = false);
+                int herm = 0);
 
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
@@ -2397,10 +2420,11 @@ template <typename T>
 void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
                        const signed char *flip, const double *scale_dev, int nfg, int tpol,
                        cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
-                       const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis, bool herm) {
+                       const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis, int herm) {
     if (N == 0 || nfg == 0) return;
-    FV_REQUIRE(!herm || (tpol == 2 && (!basis || basis->kk == basis->ll)),
-               "Hermitian gather: two transforms per frequency; eigenbeam terms only on the diagonal");
+    FV_REQUIRE(!herm || (tpol == 2 && (herm == 2 || !basis || basis->kk == basis->ll)),
+               "packed gather: two transforms per frequency; off-diagonal eigenbeam terms only with real strengths");
+    for (int d = 0; d < dim && herm; ++d) FV_REQUIRE(geo.d[d].btc == 0.0, "packed gather needs a box symmetric about 0");
     InterpArgs a{};
     const cplx<T> *coef = nullptr;
     const int *ant1 = nullptr, *ant2 = nullptr;
@@ -2439,6 +2463,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.out_k_stride = out_k_stride;
     for (int r = 0; r < 16; ++r) a.out_pol_off[r] = out_pol_off ? out_pol_off[r] : 0;
     a.accumulate = accumulate ? 1 : 0;
+    a.herm = herm;
     const int64_t items = N * nfg;
     const dim3 grid((unsigned)cdiv(items, INTERP_THREADS / GROUP));
     auto kern = dim == 2 ? (herm ? k_interp<T, 2, true> : k_interp<T, 2, false>)

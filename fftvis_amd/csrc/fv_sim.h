@@ -419,7 +419,8 @@ struct StrengthArgs {
     int f_first;        // catalog index of the group's first frequency
     int nfreq;          // catalog frequency count (flux row length)
     int polarized, pol_sky, same_beam;
-    int herm;           // Hermitian strengths packed as two transforms: c_00 + i c_11 and c_01 (see k_interp)
+    int herm;           // strengths packed as two transforms (see k_interp): 1 Hermitian (c_00 + i c_11, c_01),
+                        // 2 all real (c_00 + i c_11, c_01 + i c_10)
     int dim, w;
     double h[3], btc[3];
     int na[3];
@@ -466,9 +467,14 @@ __device__ inline void strength_eval(const StrengthArgs &a, int jc, int fidx, cp
         const cplx<double> Fj[4] = {Aj[2], Aj[3], Aj[0], Aj[1]};
         coh_AhCB(Fi, C, Fj, o);
     }
-    if (a.herm) {  // same beam on both sides: o is Hermitian (o_00, o_11 real, o_10 = conj o_01); pre = 1
+    if (a.herm == 1) {  // same beam on both sides: o is Hermitian (o_00, o_11 real, o_10 = conj o_01); pre = 1
         dst[0] = {(T)o[0].re, (T)o[3].re};
         dst[1] = {(T)o[1].re, (T)o[1].im};
+        return;
+    }
+    if (a.herm == 2) {  // real Jones matrices on both sides, unpolarized sky: all four products are real
+        dst[0] = {(T)o[0].re, (T)o[3].re};
+        dst[1] = {(T)o[1].re, (T)o[2].re};
         return;
     }
     for (int r = 0; r < 4; ++r) {
@@ -808,6 +814,7 @@ class Sim : public SimBase {
         int nfreq_tab = 0, nza = 0, naz = 0;
         double za_max = 0;
         std::unique_ptr<DevBuf> table;
+        bool real_valued = true;  // every Jones entry has zero imaginary part (Airy; tables are scanned at upload)
     };
     std::vector<Beam> beams;
 
@@ -818,7 +825,7 @@ class Sim : public SimBase {
         std::unique_ptr<DevBuf> idx, flip;
         double btc[3], B[3];   // tight box of its (sign-adjusted) baselines: centre, half-width [s]
         double Bs[3];          // half-width of the box made symmetric about 0
-        bool herm = false;     // this run packs its Hermitian strengths into two transforms (decided per run)
+        int herm = 0;          // this run packs its strengths into two transforms: 1 Hermitian, 2 all real (per run)
         const double *box_c() const { return herm ? zero3 : btc; }
         const double *box_B() const { return herm ? Bs : B; }
     };
@@ -1047,6 +1054,7 @@ class Sim : public SimBase {
     void set_beam_airy(int b, double diameter) override {
         FV_REQUIRE(b >= 0 && b < (int)beams.size(), "beam index out of range");
         beams[b].kind = 0;
+        beams[b].real_valued = true;
         beams[b].diameter = diameter;
     }
     void set_beam_table(int b, int nft, int nza, int naz, double za_max, const void *table,
@@ -1061,6 +1069,12 @@ class Sim : public SimBase {
         beam_order = order;
         Beam &bm = beams[b];
         bm.kind = 1;
+        bm.real_valued = true;
+        if (polarized) {  // Jones tables with no imaginary part anywhere make every coherency product real
+            const double *tv = static_cast<const double *>(table);
+            const size_t nc = (size_t)nft * 4 * nza * naz;
+            for (size_t i = 0; i < nc && bm.real_valued; ++i) bm.real_valued = tv[2 * i + 1] == 0.0;
+        }
         bm.nfreq_tab = nft;
         bm.nza = nza;
         bm.naz = naz;
@@ -1523,8 +1537,12 @@ class Sim : public SimBase {
             double fmax = 0;
             for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
             for (Pair &p : pairs) {
-                p.herm = false;
-                if (!polarized || herm_off || p.bi != p.bj || p.n == 0) continue;  // eigenbeams: the (k, k) terms
+                p.herm = 0;
+                if (!polarized || herm_off || p.n == 0) continue;
+                // 1: same beam on both sides (Hermitian strengths; eigenbeams: the (k, k) terms);
+                // 2: two different beams whose Jones matrices are real, unpolarized sky (all products real)
+                const int mode = p.bi == p.bj ? 1 : (!pol_sky && beams[p.bi].real_valued && beams[p.bj].real_valued ? 2 : 0);
+                if (!mode) continue;
                 double cs = 1.0, ct = 1.0;
                 for (int d = 0; d < D; ++d) {
                     DimGeom gs, gt;
@@ -1536,7 +1554,7 @@ class Sim : public SimBase {
                     cs *= gs.n2;
                     ct *= gt.n2;
                 }
-                p.herm = cs >= 4.0e6 && cs <= 1.5 * ct;
+                p.herm = cs >= 4.0e6 && cs <= 1.5 * ct ? mode : 0;
             }
         }
         int tg_max = 1;  // transforms per frequency on the grid, largest over the pairs

@@ -288,13 +288,20 @@ def test_hermitian_packing_matches_four_transforms(gpu, monkeypatch):
     frequency (c_00 + i c_11, c_01) and rebuild the four products from the baseline and its mirror image
     (k_interp<.., HERM>).  Against the plain four-transform run (FFTVIS_HIP_NO_HERMITIAN=1) and the oracle:
     unpolarized sky, polarized sky (complex c_01), a table beam with complex leakage, flipped baselines and
-    autos, a non-coplanar array (3-D transform), source chunks, fp32."""
+    autos, a non-coplanar array (3-D transform), source chunks, fp32; two different real-valued beams (the
+    cross pair's strengths are all real: c_01 + i c_10 share a transform too), a real and a complex beam."""
     cfg = synth.make_config("C3", nsrc=20_000, nfreq=3, ntimes=2)
     bl = cfg["baselines"][::23] + [(5, 5), (340, 2), (349, 17)]   # autos, and pairs given "backwards"
     cfg["baselines"] = bl
     _, _, fl4 = synth.catalog(20_000, cfg["freqs"], 3, polarized_sky=True)
     tilted = {k: v + np.array([0.0, 0.0, 0.02 * v[0] + 0.3 * np.sin(0.01 * v[1])]) for k, v in cfg["ants"].items()}
-    cases = {"unpolarized sky": cfg, "polarized sky": dict(cfg, fluxes=fl4),
+    freqs = cfg["freqs"]
+    real_a = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, 14.0).real.astype(complex), freqs)
+    real_b = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, 12.0).real.astype(complex), freqs)
+    bidx = np.arange(len(cfg["ants"])) % 2
+    two_real = dict(cfg, beam=[real_a, real_b], beam_idx=bidx)   # pairs (0,0), (1,1): Hermitian; (0,1): all-real packing
+    cases = {"unpolarized sky": cfg, "polarized sky": dict(cfg, fluxes=fl4), "two real beams": two_real,
+             "real and complex beam": dict(two_real, beam=[real_a, cfg["beam"]]),   # (0,1) keeps four transforms
              "non-coplanar": dict(cfg, ants=tilted, baselines=bl[::9]),
              "chunks": dict(cfg, min_chunks=3), "fp32": dict(cfg, precision=1, eps=1e-4)}
     sub = list(range(0, len(bl), 40)) + [len(bl) - 3, len(bl) - 2, len(bl) - 1]
@@ -310,7 +317,7 @@ def test_hermitian_packing_matches_four_transforms(gpu, monkeypatch):
         for a in range(2):
             for b in range(2):
                 assert rel_l2(packed[:, :, a, b], plain[:, :, a, b]) < 4 * tol, (name, a, b)
-        if name in ("unpolarized sky", "polarized sky"):
+        if name in ("unpolarized sky", "polarized sky", "two real beams"):
             cs = dict(c, baselines=[c["baselines"][i] for i in sub])
             assert rel_l2(packed[..., sub], oracle_simulate(cs)) < TOL, name
     monkeypatch.delenv("FFTVIS_HIP_NO_HERMITIAN", raising=False)
