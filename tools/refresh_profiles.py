@@ -77,7 +77,7 @@ for tag, dst in (("c3", "c3_bench"), ("c2", "c2_bench")):
     if os.path.exists(p2) and tag in out["counters"]:
         d = json.load(open(p2))
         k = out["counters"][tag].get(d["roofline"]["kernel"])
-        if k:
+        if k and "four" not in dst:
             d["roofline"]["traffic"] = (2 * k["FETCH_SIZE_KB_avg_per_launch"] + k["WRITE_SIZE_KB_avg_per_launch"]) * 1024
             d["roofline"]["traffic_source"] = path + " (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE; filled in by tools/refresh_profiles.py)"
             json.dump(d, open(p2, "w"))
