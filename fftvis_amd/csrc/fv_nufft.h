@@ -1013,9 +1013,10 @@ __device__ inline P *wave_uniform_ptr(P *p) {
 template <typename T>
 struct RowBuf {
     __amdgpu_buffer_rsrc_t rsrc;
+    // n_elems < 0: no extent (column mode: lanes address several rows from one base and mask by index -1)
     __device__ RowBuf(const cplx<T> *base, int64_t n_elems) {
         const cplx<T> *b = wave_uniform_ptr(base);
-        const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(n_elems * (int64_t)sizeof(cplx<T>)));
+        const uint32_t bytes = __builtin_amdgcn_readfirstlane(n_elems < 0 ? 0xFFFFFFF0u : (uint32_t)(n_elems * (int64_t)sizeof(cplx<T>)));
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx<T> *>(b), 0, bytes, 0x00020000);
     }
     __device__ cplx<T> load(int idx) const {
@@ -1235,10 +1236,22 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     // elements with s = q (mod Q): one of them when n_in <= Q, else the extras are folded on top.
     cplx<T> va[R1];
     const int hshift = a.n_in / 2;
+    // Input through a buffer descriptor.  Row mode: the row belongs to whole waves -- base = the row, extent = n_in,
+    // the range check does the masking.  Column mode: base = the workgroup's first column, every lane adds its own
+    // column's offset and masks by the index -1 (beyond any extent): one compare + select per element instead of
+    // clamp + two compares + four selects, and no 64-bit addresses in vector registers.
+    const int64_t in_base = COL ? (row0 / a.rpp) * a.in_plane + (row0 % a.rpp) * a.in_row
+                                : (ok ? rplane * a.in_plane + rk * a.in_row : 0);
+    const RowBuf<T> rowin(in + in_base, COL ? -1 : (ok ? a.n_in : 0));
+    const int lane_in = COL ? (int)(rplane * a.in_plane + rk * a.in_row - in_base) : 0;
+    const int in_elem = (int)a.in_elem;
+    auto load_in = [&](int ia) -> cplx<T> {
+        if constexpr (COL)
+            return rowin.load(ok && (unsigned)ia < (unsigned)a.n_in ? lane_in + ia * in_elem : -1);
+        else
+            return rowin.load(ia);  // zero outside [0, n_in)
+    };
     if constexpr (FOLD) {
-        const cplx<T> *rin = in + (ok ? rplane * a.in_plane + rk * a.in_row : 0);
-        const RowBuf<T> rowin(rin, COL || !ok ? 0 : a.n_in);  // row mode: a row belongs to whole waves
-        const int qmax = a.n_in - 1;
         const int nlo = a.n_in - hshift;                      // elements with s >= 0
         const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
         const int mmax = (nlo - 1) / Q;
@@ -1257,15 +1270,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
                 cplx<T> x[CH];
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    const int ia = u + (h + j) * S1 + off;
-                    if constexpr (COL) {
-                        const bool live = ok && ia >= 0 && ia <= qmax;
-                        const int iac = min(max(ia, 0), qmax);
-                        x[j] = rin[(int64_t)iac * a.in_elem];
-                        if (!live) x[j] = {T(0), T(0)};
-                    } else {
-                        x[j] = rowin.load(ia);  // zero outside [0, n_in)
-                    }
+                    x[j] = load_in(u + (h + j) * S1 + off);
                 }
                 if (mp) {  // uniform
 #pragma unroll
@@ -1295,16 +1300,12 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     } else {
         // branch-free loads (clamped index, masked afterwards) so that a chunk's requests issue
         // back to back; chunks of 8 bound the registers held by data + residue twiddles in flight
-        const cplx<T> *rin = in + (ok ? rplane * a.in_plane + rk * a.in_row : 0);
-        const RowBuf<T> rowin(rin, COL || !ok ? 0 : a.n_in);  // row mode: a row belongs to whole waves
-        const int qmax = a.n_in - 1;
         const int nlo = a.n_in - hshift;  // elements with s >= 0
         constexpr int CH = NLD < 8 ? NLD : 8;
         constexpr int NH = NLD / 2;  // NLD < R1: only the first and the last NH registers can be non-zero
 #pragma unroll
         for (int h = 0; h < NLD; h += CH) {
             cplx<T> x[CH];
-            bool live[CH];
             int widx[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
@@ -1313,27 +1314,20 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
                 // slot q: the element with s = q if there is one, else the wrapped one with s = q - Q
                 const bool hi = NLD == R1 ? q >= nlo : h + j >= NH;
                 const int ia = (hi ? q - Q : q) + hshift;
-                widx[j] = hi ? n2 - (Q - q) * p : q * p;  // (s p) mod n2; (Q - q) p < Q P = n2
-                if constexpr (COL) {
-                    live[j] = ok && ia >= 0 && ia <= qmax;
-                    const int iac = min(max(ia, 0), qmax);
-                    x[j] = rin[(int64_t)iac * a.in_elem];
-                } else {
-                    live[j] = true;         // the buffer load returns zero outside [0, n_in)
-                    x[j] = rowin.load(ia);
-                }
+                widx[j] = hi ? n2 - (Q - q) * p : q * p;  // (s p) mod n2; (Q - q) p < Q P = n2: always a valid index
+                x[j] = load_in(ia);
             }
             if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
                 cplx<T> w[CH];
 #pragma unroll
-                for (int j = 0; j < CH; ++j) w[j] = tw[COL ? (live[j] ? widx[j] : 0) : widx[j]];  // widx is always a valid index
+                for (int j = 0; j < CH; ++j) w[j] = tw[widx[j]];
 #pragma unroll
                 for (int j = 0; j < CH; ++j) x[j] = cmul(x[j], w[j]);
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
-                va[jr] = {live[j] ? x[j].re : T(0), live[j] ? x[j].im : T(0)};
+                va[jr] = x[j];  // already zero where the row has no element
             }
             if (h + CH < NLD) __builtin_amdgcn_sched_barrier(0);
         }
@@ -1434,11 +1428,16 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         rout = reinterpret_cast<cplx<T> *>(smem) + (int64_t)r * a.n_out + half_n;
         ostep = 1;
     }
-    // row mode: a buffer descriptor over exactly this residue's run of outputs, ks in [ks_lo, ks_hi): stores
-    // outside it are dropped by the range check -- no compare, no exec masking, no branch per output
+    // Output through a buffer descriptor.  Row mode: exactly this residue's run of outputs, ks in [ks_lo, ks_hi):
+    // stores outside it are dropped by the range check -- no compare, no exec masking, no branch per output.
+    // Column mode: base = the first column's run, lanes add their own row's offset and mask by the index -1.
     const int ks_lo = ceil_div_signed(-half_n - p, a.P), ks_hi = ceil_div_signed(a.n_out - half_n - p, a.P);
-    const RowBuf<T> rowout(rout + (int64_t)ks_lo * ostep,
-                           COL || !ok || ks_hi <= ks_lo ? 0 : (int64_t)(ks_hi - ks_lo - 1) * ostep + 1);
+    const int64_t res_off = (a.cnt ? ((p + half_n) % a.P) * a.cnt + (p + half_n) / a.P : p + half_n) + (int64_t)ks_lo * ostep;
+    const int64_t out_base = COL ? ((row0 / a.rpp) * a.rpp_valid + row0 % a.rpp) * a.out_pitch + res_off
+                                 : (rplane * a.rpp_valid + rk) * a.out_pitch + res_off;
+    const RowBuf<T> rowout(out + out_base,
+                           FUSED ? 0 : COL ? -1 : (!ok || ks_hi <= ks_lo ? 0 : (int64_t)(ks_hi - ks_lo - 1) * ostep + 1));
+    const int lane_out = COL ? (int)((rplane * a.rpp_valid + rk) * a.out_pitch + res_off - out_base) : 0;
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
         int v = u + i * TPR;
@@ -1451,8 +1450,10 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
             const int kk = v + k * (Q / R3);
             const int ks = kk < Q / 2 ? kk : kk - Q;
             const int l = a.P * ks + p;
-            if constexpr (COL) {
+            if constexpr (FUSED) {
                 if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
+            } else if constexpr (COL) {
+                rowout.store(ok && ks >= ks_lo && ks < ks_hi ? lane_out + (ks - ks_lo) * ostep : -1, vc[i][bitrev_small(k, L3)]);
             } else {
                 rowout.store((ks - ks_lo) * ostep, vc[i][bitrev_small(k, L3)]);
             }
@@ -2119,7 +2120,10 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
 // Row-FFT launch geometry for one dimension (shared by the launcher and the transpose decision):
 // Q/8 threads per row (16..512), 256..512 threads per workgroup.
 inline bool rowfft_uses_st(const DimGeom &g, bool col) {  // register-resident kernel applies
-    static const int colmax = std::getenv("FFTVIS_HIP_COL_LOGQ_MAX") ? std::atoi(std::getenv("FFTVIS_HIP_COL_LOGQ_MAX")) : 11;
+    // (a Q = 4096 column pass -- 2 columns per 512-thread workgroup, 120 VGPRs, two workgroups per CU -- was built
+    // and is correct, but at 2.21 ms per launch it loses to tile transpose + row pass, 0.90 + 1.03 ms: 32-B column
+    // segments cost four times the L1 / TA traffic of rows)
+    static const int colmax = std::getenv("FFTVIS_HIP_COL_LOGQ_MAX") ? std::min(11, std::atoi(std::getenv("FFTVIS_HIP_COL_LOGQ_MAX"))) : 11;
     return g.logQ >= 9 && g.logQ <= (col ? colmax : 12) && !debug_switch_old_fft();
 }
 inline void rowfft_shape(const DimGeom &g, bool col, int &tpr, int &rpw) {
@@ -2142,7 +2146,7 @@ int64_t Nufft3<T>::b_pitch() const {
     rowfft_shape(y, true, tpr, rpw);
     // whole 128-B lines per workgroup (8 columns) or per pair of neighbouring workgroups (4 columns each;
     // giving such pairs consecutive slots on one XCD was measured to change nothing: 1.836 vs 1.833 ms)
-    return rpw >= 4 ? (x.nos() + 7) / 8 * 8 : x.nos();
+    return rpw >= 2 ? (x.nos() + 7) / 8 * 8 : x.nos();
 }
 
 template <typename T>
@@ -2226,22 +2230,30 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;
         const bool col = a.colmode != 0;
 #define FV_ST_GO(LQ, COLM, NLD)                                                                        \
-    if (a.n_in > g.Q && NLD == (LQ == 9 ? 8 : 16))                                                     \
+    if (a.n_in > g.Q && NLD == (LQ == 9 ? 8 : 16)) {                                                   \
         hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, (LQ == 9 ? 8 : 16), false, true>), jobs,          \
                            dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, FusedArgs{}); \
-    else if (COLM && fused)                                                                            \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, COLM>), jobs,                                \
-                           dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, *fused); \
-    else                                                                                               \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, false>), jobs,                               \
-                           dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, FusedArgs{})
+    } else {                                                                                           \
+        bool launched = false;                                                                         \
+        if constexpr (COLM && LQ <= 10) { /* the fused gather rides on 8-column passes only */          \
+            if (fused) {                                                                               \
+                hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, COLM>), jobs,                        \
+                                   dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, *fused); \
+                launched = true;                                                                       \
+            }                                                                                          \
+        }                                                                                              \
+        if (!launched)                                                                                 \
+            hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, false>), jobs,                           \
+                               dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, FusedArgs{}); \
+    }
 #define FV_ST_NLD(LQ, COLM)                                                                            \
-    if (nld == 4)                                                                                      \
-        FV_ST_GO(LQ, COLM, 4);                                                                         \
-    else if (nld == 8 || LQ == 9)                                                                      \
-        FV_ST_GO(LQ, COLM, 8);                                                                         \
-    else                                                                                               \
-        FV_ST_GO(LQ, COLM, (LQ == 9 ? 8 : 16));
+    if (nld == 4) {                                                                                    \
+        FV_ST_GO(LQ, COLM, 4)                                                                          \
+    } else if (nld == 8 || LQ == 9) {                                                                  \
+        FV_ST_GO(LQ, COLM, 8)                                                                          \
+    } else {                                                                                           \
+        FV_ST_GO(LQ, COLM, (LQ == 9 ? 8 : 16))                                                         \
+    }
         if (g.logQ == 9) {
             if (col) { FV_ST_NLD(9, true) } else { FV_ST_NLD(9, false) }
         } else if (g.logQ == 10) {
@@ -2271,7 +2283,7 @@ double Nufft3<T>::fft_traffic_cells() const {
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
     double c = zin * ((double)x.na * y.na + (double)x.no * y.na);        // x-pass
-    if (rpw < 4) c += zin * 2.0 * x.no * y.na;                            // transpose
+    if (rpw < 2) c += zin * 2.0 * x.no * y.na;                            // transpose
     c += zin * ((double)x.no * y.na + (last_fft_fused ? 0.0 : (double)x.no * y.no));  // y-pass (no C when fused)
     if (dim > 2) c += (double)x.no * y.no * (z.na + z.no);               // z-pass
     return c;
@@ -2300,8 +2312,8 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
     std::swap(cur1, oth1);
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
-    if (rpw >= 4) {
-        // short columns: the y-pass reads rpw adjacent columns of B at once (64-128 B segments),
+    if (rpw >= 2) {
+        // the y-pass reads rpw adjacent columns of B at once (32-128 B segments; neighbouring workgroups share lines),
         // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
         // plane are skipped as rows
         rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.nos(),
