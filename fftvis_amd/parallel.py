@@ -163,12 +163,13 @@ def broadcast_catalog_device(ra, dec, fluxes, polarized: bool, precision: int, d
         eq = torch.empty((3, nsrc), dtype=rdt, device=device)
         flux = torch.empty(fshape, dtype=fdt, device=device)
     for t in (eq, flux):
+        tv = torch.view_as_real(t) if t.is_complex() else t  # RCCL has no complex type: the same bytes as reals
         if via_host:
-            h = t.cpu()
+            h = tv.cpu()
             dist.broadcast(h, src=src)
-            t.copy_(h)
+            tv.copy_(h)
         else:
-            dist.broadcast(t, src=src)
+            dist.broadcast(tv, src=src)
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
     return DeviceCatalog(eq, flux, pol_sky)
