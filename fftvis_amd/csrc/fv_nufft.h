@@ -1551,7 +1551,12 @@ struct InterpArgs {
 // that is symmetric about s = 0, so that -s is a target like any other.  herm = 2: all four strengths are
 // real (real-valued Jones matrices on both sides, unpolarized sky), T2 = F[c_01 + i c_10] and
 //   V_01(s) = (T2(s) + conj(T2(-s))) / 2,   V_10(s) = (T2(s) - conj(T2(-s))) / 2i.
-template <typename T, int DIM, bool HERM>
+// NR = rows of a footprint fetched per batch (9 for w <= 9, else 16): their loads are issued back to back in
+// straight-line code -- row indices clamped to the footprint, weights beyond it zero -- so that NR (HERM: 2 NR)
+// loads are in flight per lane group.  (With a uniform `if (rr < w)` around each row the compiler put every
+// load in a basic block of its own, followed by s_waitcnt vmcnt(0): one load in flight per wave, and the
+// gather spent 70 % of its time waiting for them one at a time.)
+template <typename T, int DIM, bool HERM, int NR>
 __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ bt0,
     const T *__restrict__ bt1, const T *__restrict__ bt2, const int *__restrict__ bl_idx,
@@ -1625,9 +1630,25 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
             j0[d] = j;
             kv[d] = g < w ? es_eval<T>((T)((double)(j + g) - e), beta, c4) : T(0);
         }
-        T k1[MAX_W];
+        T k1[NR];  // row weights: zero beyond the footprint (kv of lanes >= w is zero)
 #pragma unroll
-        for (int r = 0; r < MAX_W; ++r) k1[r] = __shfl(kv[1], lane_base + r, 64);
+        for (int r = 0; r < NR; ++r) k1[r] = __shfl(kv[1], lane_base + r, 64);
+        // row offsets of the footprint in the (residue-major) slow dimension: position of index i is
+        // (i mod P) cnt + i / P, walked incrementally from one division per side; rows beyond w repeat the last
+        int roff[NR];
+        {
+            const int P1 = a.P[1], c1 = a.cnt[1];
+            int q1 = j0[1] / P1, r1 = j0[1] - q1 * P1;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                roff[rr] = (r1 * c1 + q1) * (int)row_sz;
+                const int inc = rr + 1 < w ? 1 : 0;
+                r1 += inc;
+                const int wrap = r1 == P1 ? 1 : 0;
+                r1 = wrap ? 0 : r1;
+                q1 += wrap;
+            }
+        }
         const int gcol = out_pos(min(j0[0] + g, a.no[0] - 1), a.P[0], a.cnt[0]);
         const double pis = side ? -pi_ : pi_;  // exp(i (-s) . x_c) = conj
         constexpr int RUNROLL = HERM ? NVAL : 1;  // HERM: two transforms, compile-time indexed results
@@ -1642,14 +1663,14 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                     k2 = __shfl(kv[DIM - 1], lane_base + ro, 64);
                     slab += (int64_t)out_pos(j0[DIM - 1] + ro, a.P[DIM - 1], a.cnt[DIM - 1]) * slab_sz;
                 }
+                cplx<T> v[NR];
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) v[rr] = slab[roff[rr]];
                 T tr = T(0), ti = T(0);
 #pragma unroll
-                for (int rr = 0; rr < MAX_W; ++rr) {
-                    if (rr < w) {
-                        const cplx<T> v = slab[(int64_t)out_pos(j0[1] + rr, a.P[1], a.cnt[1]) * row_sz];
-                        tr += v.re * k1[rr];
-                        ti += v.im * k1[rr];
-                    }
+                for (int rr = 0; rr < NR; ++rr) {
+                    tr += v[rr].re * k1[rr];
+                    ti += v[rr].im * k1[rr];
                 }
                 sr += tr * k2;
                 si += ti * k2;
@@ -2478,8 +2499,11 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.herm = herm;
     const int64_t items = N * nfg;
     const dim3 grid((unsigned)cdiv(items, INTERP_THREADS / GROUP));
-    auto kern = dim == 2 ? (herm ? k_interp<T, 2, true> : k_interp<T, 2, false>)
-                         : (herm ? k_interp<T, 3, true> : k_interp<T, 3, false>);
+    const bool r9 = ker.w <= 9;
+    auto kern = dim == 2 ? (herm ? (r9 ? k_interp<T, 2, true, 9> : k_interp<T, 2, true, 16>)
+                                 : (r9 ? k_interp<T, 2, false, 9> : k_interp<T, 2, false, 16>))
+                         : (herm ? (r9 ? k_interp<T, 3, true, 9> : k_interp<T, 3, true, 16>)
+                                 : (r9 ? k_interp<T, 3, false, 9> : k_interp<T, 3, false, 16>));
     hipLaunchKernelGGL(kern, grid, dim3(INTERP_THREADS), 0, stream, (const cplx<T> *)grid_out, N, bt[0], bt[1], bt[2],
                        bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2);
 }
