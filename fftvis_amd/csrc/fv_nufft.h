@@ -133,6 +133,19 @@ inline void choose_pq(int nmin, DimGeom &g) {
     g.n2 = bp << bq;
 }
 
+// Dimensions after the first are transformed along columns of the previous pass's output.  The column
+// kernel holds 4 columns of Q <= 2048 per workgroup; a Q = 4096 column needs a tile transpose and a row
+// pass instead.  Same n2, one factor of two moved back from Q into P (4 x 2048 instead of 2 x 4096): the
+// fold costs P n_in complex FMAs more, the radix passes one level less, and the transpose goes away.
+inline void cap_column_q(DimGeom &g) {
+    static const int cap = std::getenv("FFTVIS_HIP_COL_QCAP") ? std::atoi(std::getenv("FFTVIS_HIP_COL_QCAP")) : 11;
+    while (g.logQ > cap && g.logQ > 4 && 2 * g.P <= 16) {
+        g.P *= 2;
+        g.Q /= 2;
+        --g.logQ;
+    }
+}
+
 inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
     g.S = std::fabs(scale_max) * g.B;
     double Xs = g.X, Ss = g.S;
@@ -860,6 +873,11 @@ struct RowDifArgs {
     int cnt;  // outputs per residue: row position of l is ((l + n_out/2) mod P) cnt + (l + n_out/2) / P;
               // 0 = natural order (position l + n_out/2)
     int64_t nrows, rpp, rpp_valid, in_plane, in_row, in_elem, out_pitch;  // rows k >= rpp_valid of a plane are padding
+    // Column-blocked planes (log2 of the block width in elements, 0 = plain row-major [row][pitch]): element (row k,
+    // position x) of a plane sits at (x >> b) (rows << b) + (k << b) + (x & (2^b - 1)) -- 64-byte pieces of a row, and
+    // the pieces of one block of columns contiguous over the rows.  The x-pass writes it (out_blk), the column-mode
+    // y-pass reads it (in_blk): its 4 columns are then ONE contiguous run instead of a 64-B piece per 80-KB row.
+    int in_blk, out_blk;
     const void *in1;  // gang launch (grid.y = 2): input / output of the second, identically shaped problem
     void *out1;
 };
@@ -993,6 +1011,10 @@ struct StPlan<12, COL> {
 #endif
 constexpr int ST_THREADS = 256;      // row mode
 constexpr int ST_THREADS_COL = 512;  // column mode
+#ifndef FV_COL11_THREADS
+#define FV_COL11_THREADS 512
+#endif
+constexpr int st_threads(int logq, bool col) { return !col ? ST_THREADS : logq == 12 ? 1024 : logq == 11 ? FV_COL11_THREADS : ST_THREADS_COL; }
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v / 2); }
 
 // A pointer every lane of the wave holds the same value of, moved to scalar registers: global loads /
@@ -1169,7 +1191,7 @@ __global__ void k_fg_build(int64_t N, int nfg, const T *__restrict__ btx, const 
 // over the m with -n_in/2 <= q + m Q < n_in - n_in/2: ceil(n_in / Q) + 1 sweeps of coalesced loads, one
 // uniform complex factor per sweep (none for p = 0), one per-slot twiddle at the end.
 template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false, bool FOLD = false>
-__global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_ST_MINW12 : 4) void k_rowfft_st(
+__global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_MINW12 : 4) void k_rowfft_st(
     const cplx<T> *__restrict__ in0, cplx<T> *__restrict__ out0, const cplx<T> *__restrict__ tw, RowDifArgs a,
     FusedArgs fz) {
     static_assert(!FUSED || COL, "the fused gather rides on the column-mode last pass");
@@ -1179,7 +1201,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     cplx<T> *__restrict__ out = blockIdx.y ? static_cast<cplx<T> *>(a.out1) : out0;
     using PL = StPlan<LOGQ, COL>;
     constexpr int R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, TPR = PL::TPR, A = PL::A, B = PL::B;
-    constexpr int THREADS = COL ? ST_THREADS_COL : ST_THREADS;
+    constexpr int THREADS = st_threads(LOGQ, COL);
     constexpr int Q = 1 << LOGQ, S1 = R2 * R3, RPW = THREADS / TPR, ROW = PL::ROW;
     static_assert(ROW >= R1 * A && A >= R2 * B && B >= R3, "LDS layout");
     constexpr int NI2 = R1 * R3 / TPR, NI3 = R1 * R2 / TPR;
@@ -1240,11 +1262,16 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     // the range check does the masking.  Column mode: base = the workgroup's first column, every lane adds its own
     // column's offset and masks by the index -1 (beyond any extent): one compare + select per element instead of
     // clamp + two compares + four selects, and no 64-bit addresses in vector registers.
-    const int64_t in_base = COL ? (row0 / a.rpp) * a.in_plane + (row0 % a.rpp) * a.in_row
-                                : (ok ? rplane * a.in_plane + rk * a.in_row : 0);
+    const bool in_blocked = COL && a.in_blk;
+    const int64_t in_base = in_blocked ? (row0 / a.rpp) * a.in_plane
+                            : COL      ? (row0 / a.rpp) * a.in_plane + (row0 % a.rpp) * a.in_row
+                                       : (ok ? rplane * a.in_plane + rk * a.in_row : 0);
     const RowBuf<T> rowin(in + in_base, COL ? -1 : (ok ? a.n_in : 0));
-    const int lane_in = COL ? (int)(rplane * a.in_plane + rk * a.in_row - in_base) : 0;
-    const int in_elem = (int)a.in_elem;
+    const int lane_in = in_blocked ? (int)((rplane - row0 / a.rpp) * a.in_plane) + (((int)rk >> a.in_blk) * a.n_in << a.in_blk) +
+                                         ((int)rk & ((1 << a.in_blk) - 1))
+                        : COL      ? (int)(rplane * a.in_plane + rk * a.in_row - in_base)
+                                   : 0;
+    const int in_elem = in_blocked ? 1 << a.in_blk : (int)a.in_elem;
     auto load_in = [&](int ia) -> cplx<T> {
         if constexpr (COL)
             return rowin.load(ok && (unsigned)ia < (unsigned)a.n_in ? lane_in + ia * in_elem : -1);
@@ -1433,10 +1460,15 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
     // Column mode: base = the first column's run, lanes add their own row's offset and mask by the index -1.
     const int ks_lo = ceil_div_signed(-half_n - p, a.P), ks_hi = ceil_div_signed(a.n_out - half_n - p, a.P);
     const int64_t res_off = (a.cnt ? ((p + half_n) % a.P) * a.cnt + (p + half_n) / a.P : p + half_n) + (int64_t)ks_lo * ostep;
-    const int64_t out_base = COL ? ((row0 / a.rpp) * a.rpp_valid + row0 % a.rpp) * a.out_pitch + res_off
-                                 : (rplane * a.rpp_valid + rk) * a.out_pitch + res_off;
+    const bool out_blocked = !COL && !FUSED && a.out_blk;
+    const int64_t out_base = out_blocked ? rplane * a.rpp_valid * a.out_pitch + (rk << a.out_blk)
+                             : COL       ? ((row0 / a.rpp) * a.rpp_valid + row0 % a.rpp) * a.out_pitch + res_off
+                                         : (rplane * a.rpp_valid + rk) * a.out_pitch + res_off;
     const RowBuf<T> rowout(out + out_base,
-                           FUSED ? 0 : COL ? -1 : (!ok || ks_hi <= ks_lo ? 0 : (int64_t)(ks_hi - ks_lo - 1) * ostep + 1));
+                           FUSED ? 0 : (COL || out_blocked) ? -1 : (!ok || ks_hi <= ks_lo ? 0 : (int64_t)(ks_hi - ks_lo - 1) * ostep + 1));
+    const int blk_rows = (int)a.rpp_valid << a.out_blk, blk_mask = (1 << a.out_blk) - 1, res0 = (int)res_off;
+    const int blk_step = (((Q / R3) * ostep) >> a.out_blk) * blk_rows, blk_wrap = ((Q * ostep) >> a.out_blk) * blk_rows;
+    const unsigned blk_len = ok && ks_hi > ks_lo ? (unsigned)(ks_hi - ks_lo) : 0u;
     const int lane_out = COL ? (int)((rplane * a.rpp_valid + rk) * a.out_pitch + res_off - out_base) : 0;
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
@@ -1455,7 +1487,17 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
             } else if constexpr (COL) {
                 rowout.store(ok && ks >= ks_lo && ks < ks_hi ? lane_out + (ks - ks_lo) * ostep : -1, vc[i][bitrev_small(k, L3)]);
             } else {
-                rowout.store((ks - ks_lo) * ostep, vc[i][bitrev_small(k, L3)]);
+                if (out_blocked) {
+                    // a thread's outputs are whole blocks apart (Q / R3 is a multiple of the block width), and
+                    // ks wraps exactly at k = R3 / 2 (v < Q / R3): index and validity are affine in k with
+                    // uniform constants -- two adds, a compare and a select per store
+                    const int rel = (v - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
+                    const int pos0 = res0 + (v - ks_lo) * ostep;
+                    const int idx = (pos0 >> a.out_blk) * blk_rows + (pos0 & blk_mask) + k * blk_step - (k >= R3 / 2 ? blk_wrap : 0);
+                    rowout.store((unsigned)rel < blk_len ? idx : -1, vc[i][bitrev_small(k, L3)]);
+                } else {
+                    rowout.store((ks - ks_lo) * ostep, vc[i][bitrev_small(k, L3)]);
+                }
             }
         }
     }
@@ -1467,7 +1509,7 @@ __global__ __launch_bounds__(COL ? ST_THREADS_COL : ST_THREADS, LOGQ == 12 ? FV_
         const int pol = (int)(row0 / a.rpp) % fz.tpol;       // transform = (frequency, polarisation)
         const int c = tid & 7;
         cplx<T> *obase = reinterpret_cast<cplx<T> *>(blockIdx.y ? fz.out1 : fz.out) + fz.pol_off[pol];
-        for (int e = fz_e; e < fz_s1; e += (COL ? ST_THREADS_COL : ST_THREADS) / 8) {
+        for (int e = fz_e; e < fz_s1; e += st_threads(LOGQ, COL) / 8) {
             if (e != fz_e) {  // beyond the prefetched first round
                 fz_item = fz.list[e];
                 const unsigned char *rp = fz.recs + (int64_t)fz_item * fz.rec;
@@ -1908,6 +1950,7 @@ class Nufft3 {
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
             set_dim_geom(geo.d[d], sigma, ker.w, scale_max);
+            if (d > 0) cap_column_q(geo.d[d]);
             // (residue-major storage of the last dimension as well: C3's FFT passes -2.5 %, its gather +41 %)
             geo.d[d].rm = d != dim - 1 && !debug_switch_natural_order();
             geo.nbin[d] = geo.d[d].na >> BINLOG;
@@ -2085,7 +2128,8 @@ class Nufft3 {
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                 int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row, int64_t in_elem,
                 int64_t out_pitch = 0, int64_t rpp_valid = 0, const FusedArgs *fused = nullptr,
-                const cplx<T> *in1 = nullptr, cplx<T> *out1 = nullptr);
+                const cplx<T> *in1 = nullptr, cplx<T> *out1 = nullptr, int in_blk = 0, int out_blk = 0);
+    int b_block_log() const;  // column-blocked layout of the x-pass output (0: plain)
     int64_t b_pitch() const;  // row pitch of the x-pass output
     cplx<T> *grid_out = nullptr;  // where the last fft() left Ct
 };
@@ -2144,13 +2188,13 @@ inline bool rowfft_uses_st(const DimGeom &g, bool col) {  // register-resident k
     // (a Q = 4096 column pass -- 2 columns per 512-thread workgroup, 120 VGPRs, two workgroups per CU -- was built
     // and is correct, but at 2.21 ms per launch it loses to tile transpose + row pass, 0.90 + 1.03 ms: 32-B column
     // segments cost four times the L1 / TA traffic of rows)
-    static const int colmax = std::getenv("FFTVIS_HIP_COL_LOGQ_MAX") ? std::min(11, std::atoi(std::getenv("FFTVIS_HIP_COL_LOGQ_MAX"))) : 11;
+    static const int colmax = std::getenv("FFTVIS_HIP_COL_LOGQ_MAX") ? std::min(12, std::atoi(std::getenv("FFTVIS_HIP_COL_LOGQ_MAX"))) : 11;
     return g.logQ >= 9 && g.logQ <= (col ? colmax : 12) && !debug_switch_old_fft();
 }
 inline void rowfft_shape(const DimGeom &g, bool col, int &tpr, int &rpw) {
     if (rowfft_uses_st(g, col)) {  // Q/16 threads per row (64 for 512); 8 columns / 1-4 rows per workgroup
         tpr = g.logQ == 9 ? 64 : g.Q / 16;
-        rpw = (col ? ST_THREADS_COL : ST_THREADS) / tpr;
+        rpw = st_threads(g.logQ, col) / tpr;
         return;
     }
     tpr = 16;
@@ -2168,6 +2212,21 @@ int64_t Nufft3<T>::b_pitch() const {
     // whole 128-B lines per workgroup (8 columns) or per pair of neighbouring workgroups (4 columns each;
     // giving such pairs consecutive slots on one XCD was measured to change nothing: 1.836 vs 1.833 ms)
     return rpw >= 2 ? (x.nos() + 7) / 8 * 8 : x.nos();
+}
+
+// B (x-pass output, y-pass input) in 64-byte column blocks when both passes run the register-resident kernels
+// and the y-pass reads columns: the column pass then streams contiguous memory (DRAM pages, full lines) instead
+// of one 64-B piece per row, and the x-pass writes 64-B pieces instead of whole runs.
+template <typename T>
+int Nufft3<T>::b_block_log() const {
+    static const bool off = std::getenv("FFTVIS_HIP_NO_BLOCKED_B") != nullptr;
+    const DimGeom &x = geo.d[0], &y = geo.d[1];
+    int tpr, rpw;
+    rowfft_shape(y, true, tpr, rpw);
+    if (off || dim != 2 || !rowfft_uses_st(x, false) || !rowfft_uses_st(y, true) || rpw < 2) return 0;
+    static const int force = std::getenv("FFTVIS_HIP_B_BLOCK_LOG") ? std::atoi(std::getenv("FFTVIS_HIP_B_BLOCK_LOG")) : 0;
+    if (force) return force;
+    return sizeof(cplx<T>) == 16 && rpw < 8 ? 2 : 3;  // 64-B pieces (fp32, and 8-column workgroups: 8 elements)
 }
 
 template <typename T>
@@ -2202,7 +2261,7 @@ template <typename T>
 void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
                        int64_t nplanes, int64_t rpp, int64_t in_plane, int64_t in_row,
                        int64_t in_elem, int64_t out_pitch, int64_t rpp_valid, const FusedArgs *fused,
-                       const cplx<T> *in1, cplx<T> *out1) {
+                       const cplx<T> *in1, cplx<T> *out1, int in_blk, int out_blk) {
     static const int plans[9][4] = {{4, 0, 0, 0}, {3, 2, 0, 0}, {3, 3, 0, 0}, {4, 3, 0, 0}, {4, 4, 0, 0},
                                     {3, 3, 3, 0}, {4, 3, 3, 0}, {4, 4, 3, 0}, {4, 4, 4, 0}};  // logQ = 4 .. 12
     FV_REQUIRE(g.logQ >= 4 && g.logQ <= FFT_QMAX_LOG, "row FFT length out of range");
@@ -2229,7 +2288,13 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.in_elem = in_elem;
     a.out_pitch = out_pitch ? out_pitch : g.nos();
     a.cnt = g.sP() > 1 ? g.cnt() : 0;
+    a.in_blk = in_blk;
+    a.out_blk = out_blk;
+    FV_REQUIRE((!in_blk && !out_blk) || rowfft_uses_st(g, a.colmode != 0), "blocked planes: register-resident passes only");
     const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
+    if (std::getenv("FFTVIS_HIP_DEBUG_FFT"))
+        std::fprintf(stderr, "rowfft col=%d n_in=%d n_out=%d n2=%d P=%d Q=%d nrows=%lld rpw=%d wgs=%lld\n", a.colmode, a.n_in,
+                     a.n_out, a.n2, a.P, a.Q, (long long)a.nrows, a.rpw, (long long)(ngroups8 * 8 * g.P));
     if (in1 && !rowfft_uses_st(g, a.colmode != 0)) {  // no gang variant of the LDS kernel: two launches
         rowfft(in, out, g, twd, nplanes, rpp, in_plane, in_row, in_elem, out_pitch, rpp_valid, fused);
         FusedArgs f1{};
@@ -2253,19 +2318,19 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
 #define FV_ST_GO(LQ, COLM, NLD)                                                                        \
     if (a.n_in > g.Q && NLD == (LQ == 9 ? 8 : 16)) {                                                   \
         hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, (LQ == 9 ? 8 : 16), false, true>), jobs,          \
-                           dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, FusedArgs{}); \
+                           dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FusedArgs{}); \
     } else {                                                                                           \
         bool launched = false;                                                                         \
         if constexpr (COLM && LQ <= 10) { /* the fused gather rides on 8-column passes only */          \
             if (fused) {                                                                               \
                 hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, COLM>), jobs,                        \
-                                   dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, *fused); \
+                                   dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, *fused); \
                 launched = true;                                                                       \
             }                                                                                          \
         }                                                                                              \
         if (!launched)                                                                                 \
             hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, false>), jobs,                           \
-                               dim3(COLM ? ST_THREADS_COL : ST_THREADS), 0, stream, in, out, twd, a, FusedArgs{}); \
+                               dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FusedArgs{}); \
     }
 #define FV_ST_NLD(LQ, COLM)                                                                            \
     if (nld == 4) {                                                                                    \
@@ -2282,7 +2347,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         } else if (g.logQ == 11) {
             if (col) { FV_ST_NLD(11, true) } else { FV_ST_NLD(11, false) }
         } else {
-            FV_ST_NLD(12, false)
+            if (col) { FV_ST_NLD(12, true) } else { FV_ST_NLD(12, false) }
         }
 #undef FV_ST_NLD
 #undef FV_ST_GO
@@ -2328,7 +2393,8 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
     const int64_t np = (int64_t)ntrans * zin;     // (trans, z) planes
     // x-pass: A [p][na_y][na_x] -> B [p][na_y][xp]   (xp = no_x, padded to 8 for column mode)
     const int64_t xp = b_pitch();
-    rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp, 0, nullptr, cur1, oth1);
+    const int blk = b_block_log();
+    rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp, 0, nullptr, cur1, oth1, 0, blk);
     std::swap(cur, oth);
     std::swap(cur1, oth1);
     int tpr, rpw;
@@ -2338,7 +2404,7 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
         // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
         // plane are skipped as rows
         rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.nos(),
-               fused_active ? &fused_args : nullptr, cur1, oth1);
+               fused_active ? &fused_args : nullptr, cur1, oth1, blk, 0);
         std::swap(cur, oth);
         std::swap(cur1, oth1);
     } else {
@@ -2372,7 +2438,7 @@ bool Nufft3<T>::fused_possible() const {
     const DimGeom &x = geo.d[0], &y = geo.d[1];
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
-    if (!rowfft_uses_st(y, true) || rpw != 8) return false;   // column-mode last pass, 8 columns per workgroup
+    if (!rowfft_uses_st(y, true) || rpw != 8 || y.logQ > 10) return false;   // column-mode last pass, 8 columns per workgroup
     if (x.sP() != 1 || y.P != 1) return false;                 // natural order in both dimensions
     const int row_slots = y.logQ == 9 ? 577 : 1153;            // StPlan<9|10, true>::ROW
     return 2 * y.no <= row_slots && b_pitch() % 8 == 0;        // the 8 x n_out tile fits the exchange buffers
