@@ -118,13 +118,15 @@ def test_nufft2d_shapes_and_edge_cases(gpu):
 @pytest.mark.parametrize(
     "Sx,Sy",
     [(62, 128), (128, 62), (256, 62), (62, 256), (520, 128), (128, 520), (390, 200), (200, 390),
-     (1040, 62), (62, 1040), (700, 700)],
+     (1040, 62), (62, 1040), (700, 700), (1040, 1040), (1300, 1040)],
 )
 def test_nufft2d_every_row_fft_length(gpu, Sx, Sy):
     """Target extents chosen so that the fine grid (n2 = P * Q per dimension) walks through every
-    row-FFT length the register-resident kernel handles -- Q = 512, 1024, 2048, 4096 with P = 1, 2,
-    3, contiguous rows (x) and column mode / transposed (y) -- at sizes where the exact sum is
-    cheap.  fp64 at eps = 1e-9 and fp32 at 1e-4."""
+    row-FFT length the register-resident kernel handles -- Q = 512, 1024, 2048, 4096 with P = 1 .. 5,
+    contiguous rows (x) and column mode (y; a column of 8192 runs as 4 x 2048, folded) -- at sizes
+    where the exact sum is cheap.  The last three have both passes on the register-resident kernels,
+    i.e. the x-pass output in 64-byte column blocks (plain row-major otherwise); (1300, 1040) is
+    C3's widest grid, 10240 x 8192.  fp64 at eps = 1e-9 and fp32 at 1e-4."""
     rng = np.random.default_rng(3)
     M, N = 400, 300
     x, y = rng.uniform(-3, 3, (2, M))
