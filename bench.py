@@ -327,7 +327,7 @@ def main():
                 traffic_src = PMC_FILE + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; 2*FETCH_SIZE+WRITE_SIZE per the gfx950 note)"
         except Exception:
             traffic = None
-        kern, fft = None, None
+        kern, fft, interp_rf = None, None, None
         if breakdown:
             l2 = max(st_all["spread_launches"], 1.0)
             fft_bytes = st_all["fft_cells"] * 2 * R8
@@ -359,6 +359,22 @@ def main():
                     "frac": gbps / HBM_PEAK_GBS,
                     "share_of_step": tm_all["fft"] / total,
                     "algorithmic_bytes_per_step": fft_bytes,
+                }
+            if tm_all["interp"] > 0 and a.path == "type3":
+                # gather at the targets: algorithmic bytes = w^d grid values per (target, transform[, mirror side])
+                # footprint + one output value per target and transform
+                gb = st_all["interp_items"] * (int(st["w"]) ** 2) * 2 * R8  # the bench arrays are coplanar: 2-D transforms
+                gbps = gb / (tm_all["interp"] * 1e-3) / 1e9
+                interp_rf = {
+                    "kernel": "k_interp (gather of the transform grid at the baselines)",
+                    "bound": "hbm",
+                    "achieved": gbps,
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": gbps / HBM_PEAK_GBS,
+                    "share_of_step": tm_all["interp"] / total,
+                    "algorithmic_bytes_per_step": gb,
+                    "note": "footprint rows are w-element pieces of 128-B lines: the lines fetched are about twice these bytes",
                 }
         own_ms = [1e3 * t / a.steps for t in per_rank]
         res = {
@@ -405,6 +421,7 @@ def main():
                 "launches_in_timed_region": launches,
             },
             "roofline_fft": fft,
+            "roofline_interp": interp_rf,
             "kernels": kern,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -2291,6 +2291,10 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.in_blk = in_blk;
     a.out_blk = out_blk;
     FV_REQUIRE((!in_blk && !out_blk) || rowfft_uses_st(g, a.colmode != 0), "blocked planes: register-resident passes only");
+    // column-mode and blocked accesses are 32-bit byte offsets from a plane's base (buffer descriptors)
+    if (rowfft_uses_st(g, a.colmode != 0) && (a.colmode || in_blk || out_blk))
+        FV_REQUIRE(std::max(in_plane, a.rpp_valid * a.out_pitch) * (int64_t)sizeof(cplx<T>) < (int64_t(1) << 32),
+                   "grid planes of 4 GiB and more per transform are not supported by the column pass");
     const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
     if (std::getenv("FFTVIS_HIP_DEBUG_FFT"))
         std::fprintf(stderr, "rowfft col=%d n_in=%d n_out=%d n2=%d P=%d Q=%d nrows=%lld rpw=%d wgs=%lld\n", a.colmode, a.n_in,

@@ -1826,7 +1826,7 @@ class Sim : public SimBase {
                                   d_freqs.as<double>() + fa, nfg, tg, obase + (int64_t)m * per_tf,
                                   (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr, pr.herm);
                     ev_end(e5, ls);
-                    st[4] += (double)pr.n * ntrans * nm;
+                    st[4] += (double)pr.n * ntrans * nm * (pr.herm ? 2 : 1);  // footprints: packed transforms are read at s and -s
                     st[6] = nufft->geo.d[0].n2;
                     st[7] = nufft->geo.d[1].n2;
                     st[8] = nufft->geo.d[0].na * 65536.0 + nufft->geo.d[1].na;

@@ -193,7 +193,7 @@ int fv_sim_sync(fv_sim *h);
  * [0] spread launches, counted per (time, frequency group, beam pair) -- a gang launch that serves two
  * time steps counts twice, and a launch's transforms may run as several kernel launches --, [1] fine-grid cells written by spread (all trans, summed),
  * [2] source x trans visits, [3] cells moved through HBM by the pruned FFT passes,
- * [4] interp targets x trans, [5] above-horizon sources summed over times, [6] last n2x,
+ * [4] gathered footprints (targets x transforms, x 2 for packed transforms: read at s and -s), [5] above-horizon sources summed over times, [6] last n2x,
  * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w, [10] upsampling factor the
  * last run used, [11] largest above-horizon source count of any time step since the reset.   */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
