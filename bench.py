@@ -55,6 +55,10 @@ def parse():
                         "the reference takes by default on these arrays (reported for comparison)")
     p.add_argument("--lanes", type=int, default=None, choices=[1, 2], help="FFTVIS_HIP_LANES (small grids)")
     p.add_argument("--pipe", type=int, default=None, choices=[0, 1], help="FFTVIS_HIP_PIPE (small grids)")
+    p.add_argument("--as-rank", type=int, default=None,
+                   help="with --of-ranks N: one process runs ONLY the block rank R of an N-rank job would own "
+                        "(per-rank cost of the sharding without N GPUs; value = that block's visibilities/s)")
+    p.add_argument("--of-ranks", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-breakdown", action="store_true",
                    help="skip the extra single-stream step that times every kernel family (profiling runs)")
@@ -198,6 +202,10 @@ def main():
     # ---- this rank's block of the observation ----------------------------------------------------
     blocks = parallel.shard_blocks_weighted(world, freqs, ntimes)
     mine = blocks[rank]
+    if a.as_rank is not None:
+        assert world == 1 and a.of_ranks and 0 <= a.as_rank < a.of_ranks, "--as-rank R --of-ranks N, single process"
+        blocks = [parallel.shard_blocks_weighted(a.of_ranks, freqs, ntimes)[a.as_rank]]
+        mine = blocks[0]
     R, bls, coplanar = prepare_array(cfg["ants"], baselines, 1e-6, np.float64)
     pairs, pidx, pflip = utils.prepare_beam_evaluation(list(cfg["ants"]), baselines, None)
 
@@ -282,6 +290,8 @@ def main():
     h.enable_timing(0)
     finite = all(bool(torch.isfinite(torch.view_as_real(o)).all().item()) for o in outs)
     vis_per_step = nbls * nfreq * ntimes  # the whole observation, all ranks together
+    if a.as_rank is not None:
+        vis_per_step = nbls * sum((t.stop - t.start) * (f.stop - f.start) for t, f in mine)
     value = vis_per_step * a.steps / elapsed
 
     if rank == 0:
@@ -399,7 +409,8 @@ def main():
                             f"{a.path} NUFFT eps={a.eps:g} upsampfac={st.get('upsample_used', a.upsample):g}"
                             + (" (chosen by the engine)" if a.upsample == 0 else ""),
                 "slices_per_step": nfreq * ntimes,
-                "sharding": "one observation, (time x freq) blocks per rank: "
+                "sharding": (f"ONLY the block of rank {a.as_rank} of {a.of_ranks}: " if a.as_rank is not None else "")
+                            + "one observation, (time x freq) blocks per rank: "
                             + "; ".join(f"r{r}: t[{b[0][0].start}:{b[0][0].stop}) f[{b[0][1].start}:{b[0][1].stop})" if b else f"r{r}: -"
                                         for r, b in enumerate(blocks)),
                 "per_rank_ms_per_step": own_ms,

@@ -36,14 +36,17 @@ def shard_blocks(world: int, nfreqs: int, ntimes: int):
     return blocks
 
 
-def slice_cost(freqs, fixed: float = 0.1) -> np.ndarray:
+def slice_cost(freqs, fixed: float = 0.1, power: float = 2.4) -> np.ndarray:
     """Relative cost of one (time, channel) slice on the GPU engine: the fine grid has
     ~(2 sigma b_max nu / c)^2 cells, and spread output, FFT passes and gather input all scale with
-    it, so cost ~ nu^2 (HERA's 100-200 MHz band: the top channel costs 4x the bottom one); ``fixed``
-    (in units of the top channel's grid cost) stands for the per-slice work that does not.  Measured
-    on C3: 3.06 s per 128-channel step, of which the top 64 channels take ~66 %."""
+    it (HERA's 100-200 MHz band: the top channel costs > 4x the bottom one); ``fixed`` (in units of
+    the top channel's grid cost) stands for the per-slice work that does not.  The exponent is
+    measured, not 2: FFT lengths step (n2 = 5120 ... 10240 on HERA-350) and the longer rows fold more
+    residues -- with nu^2 the two frequency parts of an 8-rank C3 job, 81 and 47 channels, ran 226 and
+    247 ms per step on the same GPU (``bench.py --as-rank R --of-ranks 8``); nu^2.4 calls that split
+    1.09 : 1, as measured."""
     f = np.abs(np.asarray(freqs, dtype=float))
-    return (f / f.max()) ** 2 + fixed
+    return (f / f.max()) ** power + fixed
 
 
 def _cut_by_weight(w: np.ndarray, parts: int):
