@@ -200,11 +200,11 @@ def main():
     torch.cuda.synchronize()
 
     # ---- this rank's block of the observation ----------------------------------------------------
-    blocks = parallel.shard_blocks_weighted(world, freqs, ntimes)
+    blocks = parallel.shard_blocks_weighted(world, freqs, ntimes, nsrc)
     mine = blocks[rank]
     if a.as_rank is not None:
         assert world == 1 and a.of_ranks and 0 <= a.as_rank < a.of_ranks, "--as-rank R --of-ranks N, single process"
-        blocks = [parallel.shard_blocks_weighted(a.of_ranks, freqs, ntimes)[a.as_rank]]
+        blocks = [parallel.shard_blocks_weighted(a.of_ranks, freqs, ntimes, nsrc)[a.as_rank]]
         mine = blocks[0]
     R, bls, coplanar = prepare_array(cfg["ants"], baselines, 1e-6, np.float64)
     pairs, pidx, pflip = utils.prepare_beam_evaluation(list(cfg["ants"]), baselines, None)
