@@ -1282,34 +1282,39 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
         const int nlo = a.n_in - hshift;                      // elements with s >= 0
         const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
         const int mmax = (nlo - 1) / Q;
-        constexpr int CH = 4;  // slots per sweep: 4 accumulators + 4 operands in flight beside va
+        constexpr int CH = 4;  // slots per chunk: 4 accumulators + 2 sweeps x 4 operands in flight beside va
 #pragma unroll
         for (int h = 0; h < R1; h += CH) {
             cplx<T> acc[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) acc[j] = {T(0), T(0)};
-            for (int m = mmin; m <= mmax; ++m) {
-                // c^m = w^{(m Q p) mod n2}: m Q p is a multiple of Q, so the index is ((m p) mod P) Q
-                int mp = (m * p) % a.P;
-                if (mp < 0) mp += a.P;
-                const cplx<T> cm = tw[mp * Q];
-                const int off = m * Q + hshift;
-                cplx<T> x[CH];
+            // two sweeps per round trip: 8 loads in flight (a sweep beyond mmax asks for index -1: zero, no access)
+            for (int m = mmin; m <= mmax; m += 2) {
+                cplx<T> x[2][CH];
 #pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    x[j] = load_in(u + (h + j) * S1 + off);
+                for (int t = 0; t < 2; ++t) {
+                    const int off = (m + t) * Q + hshift;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) x[t][j] = load_in(m + t <= mmax ? u + (h + j) * S1 + off : -1);
                 }
-                if (mp) {  // uniform
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        acc[j].re += x[j].re * cm.re - x[j].im * cm.im;
-                        acc[j].im += x[j].re * cm.im + x[j].im * cm.re;
-                    }
-                } else {
+                for (int t = 0; t < 2; ++t) {
+                    // c^m = w^{(m Q p) mod n2}: m Q p is a multiple of Q, so the index is ((m p) mod P) Q
+                    int mp = ((m + t) * p) % a.P;
+                    if (mp < 0) mp += a.P;
+                    if (mp) {  // uniform
+                        const cplx<T> cm = tw[mp * Q];
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        acc[j].re += x[j].re;
-                        acc[j].im += x[j].im;
+                        for (int j = 0; j < CH; ++j) {
+                            acc[j].re += x[t][j].re * cm.re - x[t][j].im * cm.im;
+                            acc[j].im += x[t][j].re * cm.im + x[t][j].im * cm.re;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) {
+                            acc[j].re += x[t][j].re;
+                            acc[j].im += x[t][j].im;
+                        }
                     }
                 }
             }
