@@ -1283,6 +1283,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
         const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
         const int mmax = (nlo - 1) / Q;
         constexpr int CH = 4;  // slots per chunk: 4 accumulators + 2 sweeps x 4 operands in flight beside va
+        const cplx<T> wbase = tw[u * p];  // u p < Q P = n2
 #pragma unroll
         for (int h = 0; h < R1; h += CH) {
             cplx<T> acc[CH];
@@ -1319,49 +1320,88 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
                 }
             }
             if (p) {
-                cplx<T> w[CH];
+                // slot twiddle w^{q p}, q = u + k S1:  w^{u p} (this thread's, loaded once, long before) times
+                // w^{k S1 p} (uniform: scalar loads) -- no dependent vector load per chunk
 #pragma unroll
-                for (int j = 0; j < CH; ++j) w[j] = tw[(u + (h + j) * S1) * p];  // q p < Q P = n2
-#pragma unroll
-                for (int j = 0; j < CH; ++j) acc[j] = cmul(acc[j], w[j]);
+                for (int j = 0; j < CH; ++j) acc[j] = cmul(acc[j], cmul(wbase, tw[(h + j) * S1 * p]));  // k S1 p < n2
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j) va[h + j] = acc[j];
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-        // branch-free loads (clamped index, masked afterwards) so that a chunk's requests issue
-        // back to back; chunks of 8 bound the registers held by data + residue twiddles in flight
         const int nlo = a.n_in - hshift;  // elements with s >= 0
-        constexpr int CH = NLD < 8 ? NLD : 8;
         constexpr int NH = NLD / 2;  // NLD < R1: only the first and the last NH registers can be non-zero
-#pragma unroll
-        for (int h = 0; h < NLD; h += CH) {
-            cplx<T> x[CH];
-            int widx[CH];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
-                const int q = u + jr * S1;
+        // (the Q = 4096 row kernel is allowed 168 registers: one round trip instead of two)
+        if constexpr (LOGQ == 12 && !COL && NLD == R1) {
+            // all NLD loads of the thread are issued back to back, straight into their pass-1 registers (branch-free:
+            // the descriptor / an index of -1 masks); the residue twiddles follow in chunks of 4 and are multiplied in
+            auto slot = [&](int i, int &jr, int &q, bool &hi) {
+                jr = NLD == R1 ? i : (i < NH ? i : R1 - NLD + i);
+                q = u + jr * S1;
                 // slot q: the element with s = q if there is one, else the wrapped one with s = q - Q
-                const bool hi = NLD == R1 ? q >= nlo : h + j >= NH;
-                const int ia = (hi ? q - Q : q) + hshift;
-                widx[j] = hi ? n2 - (Q - q) * p : q * p;  // (s p) mod n2; (Q - q) p < Q P = n2: always a valid index
-                x[j] = load_in(ia);
+                hi = NLD == R1 ? q >= nlo : i >= NH;
+            };
+    #pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                int jr, q;
+                bool hi;
+                slot(i, jr, q, hi);
+                va[jr] = load_in((hi ? q - Q : q) + hshift);  // zero where the row has no element
             }
             if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
-                cplx<T> w[CH];
-#pragma unroll
-                for (int j = 0; j < CH; ++j) w[j] = tw[widx[j]];
-#pragma unroll
-                for (int j = 0; j < CH; ++j) x[j] = cmul(x[j], w[j]);
+                constexpr int CH = 4;
+    #pragma unroll
+                for (int h = 0; h < NLD; h += CH) {
+                    cplx<T> w[CH];
+    #pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        int jr, q;
+                        bool hi;
+                        slot(h + j, jr, q, hi);
+                        w[j] = tw[hi ? n2 - (Q - q) * p : q * p];  // (s p) mod n2; (Q - q) p < Q P = n2: always a valid index
+                    }
+    #pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        int jr, q;
+                        bool hi;
+                        slot(h + j, jr, q, hi);
+                        va[jr] = cmul(va[jr], w[j]);
+                    }
+                }
             }
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
-                va[jr] = x[j];  // already zero where the row has no element
+        } else {
+            // branch-free loads (clamped index, masked afterwards) so that a chunk's requests issue
+            // back to back; chunks of 8 bound the registers held by data + residue twiddles in flight
+            constexpr int CH = NLD < 8 ? NLD : 8;
+    #pragma unroll
+            for (int h = 0; h < NLD; h += CH) {
+                cplx<T> x[CH];
+                int widx[CH];
+    #pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
+                    const int q = u + jr * S1;
+                    // slot q: the element with s = q if there is one, else the wrapped one with s = q - Q
+                    const bool hi = NLD == R1 ? q >= nlo : h + j >= NH;
+                    const int ia = (hi ? q - Q : q) + hshift;
+                    widx[j] = hi ? n2 - (Q - q) * p : q * p;  // (s p) mod n2; (Q - q) p < Q P = n2: always a valid index
+                    x[j] = load_in(ia);
+                }
+                if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
+                    cplx<T> w[CH];
+    #pragma unroll
+                    for (int j = 0; j < CH; ++j) w[j] = tw[widx[j]];
+    #pragma unroll
+                    for (int j = 0; j < CH; ++j) x[j] = cmul(x[j], w[j]);
+                }
+    #pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
+                    va[jr] = x[j];  // already zero where the row has no element
+                }
+                if (h + CH < NLD) __builtin_amdgcn_sched_barrier(0);
             }
-            if (h + CH < NLD) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (NLD < R1) {
 #pragma unroll
