@@ -15,6 +15,11 @@ $B --workload C4 --nfreq 32 --ntimes 2 --steps 2 --no-cpu-baseline > $O/bench_c4
 $B --workload C4 --steps 1 --warmup 0 --no-cpu-baseline --no-breakdown > $O/bench_c4_full.json 2>/dev/null &&
 $B --workload C5 --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $O/bench_c5_full.json 2>/dev/null
 echo bench rc=$?
+# ---- what an 8-rank job's ranks would each do, one block shape at a time on this one GPU (strong scaling) --
+for w in C3 C4; do for r in 0 1; do
+  $B --workload $w --as-rank $r --of-ranks 8 --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > $O/bench_${w}_rank${r}of8.json 2>/dev/null
+done; done
+echo rank-blocks rc=$?
 # ---- rocprofv3 kernel stats of the same commands (no breakdown step: only launches shaped like the timed region) --
 prof() { # tag, bench args...
   t=$1; shift

@@ -7,6 +7,9 @@ O = "gpurun_out/final"
 names = {"bench_c3": "c3_bench", "bench_c3_auto": "c3_bench_upsample_auto", "bench_c3_type1": "c3_bench_type1",
          "bench_c3_four_transforms": "c3_bench_four_transforms", "bench_c2": "c2_bench", "bench_c5": "c5_bench",
          "bench_c4slice": "c4slice_bench", "bench_c4_full": "c4_full_one_gpu_bench", "bench_c5_full": "c5_full_one_gpu_bench"}
+for w in ("C3", "C4"):
+    for r in (0, 1):
+        names[f"bench_{w}_rank{r}of8"] = f"{w.lower()}_rank{r}_of_8_block_bench"
 for src, dst in names.items():
     if os.path.exists(f"{O}/{src}.json") and os.path.getsize(f"{O}/{src}.json") > 10:
         shutil.copy(f"{O}/{src}.json", f"profiles/{tagr}_{dst}.json")
