@@ -603,67 +603,127 @@ __global__ void k_t1_strengths(StrengthArgs a, const int *__restrict__ nent, int
                      flux, freqs, cs + e * tp);
 }
 
-// One wave per 8x8 cell block of one frequency plane; TP = transforms per plane (1 or 4).
-// Same LDS staging of source chunks as k_spread2d.
+// One wave per 16 x 16 cell tile of one frequency plane (lane = (x, y): cells (x | x + 8, y | y + 8)); TP =
+// transforms per plane (1, 2 or 4).  The wave walks the entries of the 3 x 3 bins whose footprints reach the tile in
+// chunks of 16 -- 0.42 entry visits per cell instead of the 0.75 of an 8 x 8 block per wave:
+//   * the origin of an entry is wave-uniform: lane j of the chunk loads entry j's header and the loop over the
+//     entries pulls it into scalar registers with v_readlane; the TP strengths are read back from LDS by every
+//     lane (a broadcast: LDS returns bytes per lane whether or not the address is shared), which for four cells
+//     per lane is a quarter of the LDS bytes per cell of the one-cell version (that one was LDS-bound at 0.14 of
+//     HBM peak; all-readlane strengths made an 8 x 16 version VALU-bound instead: 10 readlanes per entry).
+//   * only the 2 w kernel weights go through LDS, rows of w + 2 values with a zero at either end: a lane clamps its
+//     offsets into [-1, w] (one v_med3 each) instead of testing them, and reads x, y and y + 8.
+// Every cell of the plane is written exactly once; no atomics.
 template <typename T, int TP>
 __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
     T1Args a, const unsigned char *__restrict__ recs, const int *__restrict__ bin_start,
     const cplx<T> *__restrict__ cs, cplx<T> *__restrict__ grid) {
+    constexpr int KW = MAX_W + 2;
+    constexpr int TL = BINLOG + 1;  // tile = 16 x 16 cells
+    __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][KW];
     __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TP];
-    __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][MAX_W];
-    __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int nbc = a.n2 >> BINLOG;
-    const int bx = blockIdx.x * 4 + wave, by = blockIdx.y, f = blockIdx.z;
-    if (bx >= nbc) return;
-    const int cx = (bx << BINLOG) + (lane & 7), cy = (by << BINLOG) + (lane >> 3);
-    T ar[TP], ai[TP];
+    const int bx2 = blockIdx.x * 4 + wave, by2 = blockIdx.y, f = blockIdx.z;
+    if (bx2 >= (a.n2 >> TL)) return;  // wave-uniform; the waves of a workgroup share nothing
+    const int cx = (bx2 << TL) + (lane & 7), cy = (by2 << TL) + (lane >> 3);
+    T ar[4][TP], ai[4][TP];  // cells (cx, cy), (cx + 8, cy), (cx, cy + 8), (cx + 8, cy + 8)
 #pragma unroll
-    for (int q = 0; q < TP; ++q) ar[q] = ai[q] = T(0);
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int q = 0; q < TP; ++q) ar[h][q] = ai[h][q] = T(0);
     const int w = a.w;
-    const int bxl = ((bx << BINLOG) - w + 1 + T1_PAD) >> BINLOG, bxh = ((bx << BINLOG) + 7 + T1_PAD) >> BINLOG;
-    const int byl = ((by << BINLOG) - w + 1 + T1_PAD) >> BINLOG, byh = ((by << BINLOG) + 7 + T1_PAD) >> BINLOG;
-    for (int yb = byl; yb <= byh; ++yb) {
+    // zero guards of the weight rows (slots 0 and w + 1), written once
+    for (int e = lane; e < SPREAD_CHUNK * 4; e += 64) s_kw[wave][e >> 2][(e >> 1) & 1][(e & 1) ? w + 1 : 0] = T(0);
+    const int bxl = ((bx2 << TL) - w + 1 + T1_PAD) >> BINLOG, bxh = ((bx2 << TL) + 15 + T1_PAD) >> BINLOG;
+    const int byl = ((by2 << TL) - w + 1 + T1_PAD) >> BINLOG, byh = ((by2 << TL) + 15 + T1_PAD) >> BINLOG;
+    // The chunks of the <= 3 bin rows form one sequence; chunk c + 1 is requested (global -> registers) before chunk
+    // c is accumulated, so its loads fly under the accumulation.
+    constexpr int NWV = (2 * MAX_W + 3) / 4;  // weights per staging lane (4 lanes per entry)
+    int yb = byl, s1 = 0, base = 0;
+    auto open_row = [&]() {  // [base, s1) of bin row yb; (entries beyond the capacity were dropped and flagged by k_t1_bin)
         const int rowb = (f * a.nb1 + yb) * a.nb1;
-        // (entries beyond the capacity were dropped and flagged by k_t1_bin: stay inside the buffers)
-        const int s0 = bin_start[rowb + bxl], s1 = (int)min((int64_t)bin_start[rowb + bxh + 1], a.ecap);
-        for (int base = s0; base < s1; base += SPREAD_CHUNK) {
-            const int n = min(SPREAD_CHUNK, s1 - base);
-            for (int e = lane; e < n * TP; e += 64) s_str[wave][e / TP][e % TP] = cs[(int64_t)base * TP + e];
-            const unsigned char *rb = recs + (int64_t)base * a.rec;
-            for (int e = lane; e < n * 2 * w; e += 64) {
-                const int j = e / (2 * w), k = e - j * 2 * w;
-                const T v = reinterpret_cast<const T *>(rb + (int64_t)j * a.rec + T1_HDR)[k];
-                s_kw[wave][j][k >= w][k >= w ? k - w : k] = v;
-            }
-            if (lane < n) {
-                const int2 o = *reinterpret_cast<const int2 *>(rb + (int64_t)lane * a.rec);
-                s_i0[wave][lane][0] = o.x;
-                s_i0[wave][lane][1] = o.y;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int j = 0; j < n; ++j) {
-                const int dx = cx - s_i0[wave][j][0], dy = cy - s_i0[wave][j][1];
-                T wt = T(0);
-                if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)w)
-                    wt = s_kw[wave][j][0][dx] * s_kw[wave][j][1][dy];
+        base = __builtin_amdgcn_readfirstlane(bin_start[rowb + bxl]);
+        s1 = __builtin_amdgcn_readfirstlane((int)min((int64_t)bin_start[rowb + bxh + 1], a.ecap));
+    };
+    auto next_chunk = [&](int &cb, int &cn) {  // false: no chunk left
+        while (base >= s1) {
+            if (yb > byh) return false;
+            open_row();
+            ++yb;
+        }
+        cb = base;
+        cn = min(SPREAD_CHUNK, s1 - base);
+        base += cn;
+        return true;
+    };
+    int2 hdr_n = make_int2(0, 0);
+    cplx<T> sv_n = {T(0), T(0)};
+    T wv_n[NWV];
+    auto request = [&](int cb, int cn) {
+        const unsigned char *rb = recs + (int64_t)cb * a.rec;
+        if (lane < cn) hdr_n = *reinterpret_cast<const int2 *>(rb + (int64_t)lane * a.rec);
+        if (lane < cn * TP) sv_n = cs[(int64_t)cb * TP + lane];
+        const int j = lane >> 2;  // weights: 4 lanes per entry, every fourth value each
+        const T *wr = reinterpret_cast<const T *>(rb + (int64_t)j * a.rec + T1_HDR);
 #pragma unroll
-                for (int q = 0; q < TP; ++q) {
-                    const cplx<T> cv = s_str[wave][j][q];
-                    ar[q] += cv.re * wt;
-                    ai[q] += cv.im * wt;
+        for (int i = 0; i < NWV; ++i) {
+            const int k = (lane & 3) + 4 * i;
+            wv_n[i] = j < cn && k < 2 * w ? wr[k] : T(0);
+        }
+    };
+    int cb = 0, cn = 0;
+    bool have = next_chunk(cb, cn);
+    if (have) request(cb, cn);
+    while (have) {
+        const int n = cn;
+        const int2 hdr = hdr_n;  // staging register: lane j = entry j's origin
+        if (lane < n * TP) s_str[wave][lane / TP][lane % TP] = sv_n;
+        {
+            const int j = lane >> 2;
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int k = (lane & 3) + 4 * i;
+                if (j < n && k < 2 * w) s_kw[wave][j][k >= w][(k >= w ? k - w : k) + 1] = wv_n[i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        have = next_chunk(cb, cn);
+        if (have) request(cb, cn);
+        for (int j = 0; j < n; ++j) {
+            const int ox = __builtin_amdgcn_readlane(hdr.x, j), oy = __builtin_amdgcn_readlane(hdr.y, j);
+            // offsets clamped into [-1, w]: the guards at either end of a row are zero
+            const int dx = cx - ox, dy = cy - oy;
+            auto clamp = [&](int v) {  // median(v, -1, w): one instruction (the compiler cannot prove -1 <= w for min(max()))
+                int r;
+                asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(w));
+                return r + 1;
+            };
+            const T wx0 = s_kw[wave][j][0][clamp(dx)], wx1 = s_kw[wave][j][0][clamp(dx + 8)];
+            const T wy0 = s_kw[wave][j][1][clamp(dy)], wy1 = s_kw[wave][j][1][clamp(dy + 8)];
+            const T wt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+            for (int q = 0; q < TP; ++q) {
+                const cplx<T> cv = s_str[wave][j][q];  // broadcast read
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    ar[h][q] += cv.re * wt[h];
+                    ai[h][q] += cv.im * wt[h];
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the rows are rewritten by the next chunk
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     const int64_t plane = (int64_t)a.n2 * a.n2;
     cplx<T> *o = grid + (int64_t)f * TP * plane + (int64_t)cy * a.n2 + cx;
 #pragma unroll
-    for (int q = 0; q < TP; ++q) o[q * plane] = {ar[q], ai[q]};
+    for (int q = 0; q < TP; ++q)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) o[q * plane + (int64_t)(h >> 1) * 8 * a.n2 + (h & 1) * 8] = {ar[h][q], ai[h][q]};
 }
 
 // vis[f][pol][k] = X_{f,pol}[bx_k][by_k] / (psi_hat(bx) psi_hat(by)); flipped baselines take the
@@ -1364,7 +1424,7 @@ class Sim : public SimBase {
                     const int nplanes = nfg * tg;
                     cplx<T> *A = t1fft->fft_input(nplanes);
                     size_t e3 = ev_begin(TM_SPREAD, stream);
-                    const dim3 gs((unsigned)cdiv(g.n2 >> BINLOG, 4), (unsigned)(g.n2 >> BINLOG), (unsigned)nfg);
+                    const dim3 gs((unsigned)cdiv(g.n2 >> (BINLOG + 1), 4), (unsigned)(g.n2 >> (BINLOG + 1)), (unsigned)nfg);  // 16 x 16 cells per wave
                     if (herm1)
                         hipLaunchKernelGGL((k_t1_spread<T, 2>), gs, dim3(SPREAD_THREADS), 0, stream, a,
                                            (const unsigned char *)recs.as<unsigned char>(),
