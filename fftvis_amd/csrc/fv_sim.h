@@ -551,7 +551,9 @@ __device__ inline void t1_origin(const T1Args &a, const T *__restrict__ xyz, int
 }
 
 // COUNT = true: histogram of entries per (frequency, bin); false: scatter + tabulate weights.
-template <typename T, bool COUNT>
+// W: the kernel width at compile time (9: the default tolerance in fp64; 0: any) -- with it the record is built
+// in registers and leaves as 16-byte stores (12 for w = 9) instead of 2 w + padding scattered 8-byte ones.
+template <typename T, bool COUNT, int W = 0>
 __global__ void k_t1_bin(T1Args a, const int *__restrict__ Mp, const T *__restrict__ xyz,
                          const double *__restrict__ freqs, int *__restrict__ counts,
                          const int *__restrict__ bin_start, int *__restrict__ cursor,
@@ -581,10 +583,27 @@ __global__ void k_t1_bin(T1Args a, const int *__restrict__ Mp, const T *__restri
                 unsigned char *rec = recs + pos * a.rec;
                 *reinterpret_cast<int4 *>(rec) = make_int4(jx, jy, (int)idx, 0);  // ent = p * nfg + f
                 T *wr = reinterpret_cast<T *>(rec + T1_HDR);
-                const int nreal = (a.rec - T1_HDR) / (int)sizeof(T);
-                for (int k = 0; k < a.w; ++k) wr[k] = es_eval<T>((T)(fx + k), beta, c4);
-                for (int k = 0; k < a.w; ++k) wr[a.w + k] = es_eval<T>((T)(fy + k), beta, c4);
-                for (int k = 2 * a.w; k < nreal; ++k) wr[k] = T(0);  // whole sectors, no partial writes
+                if constexpr (W > 0) {
+                    constexpr int PER = 16 / (int)sizeof(T);                       // reals per 16-byte store
+                    constexpr int NV = (T1_HDR + 2 * W * (int)sizeof(T) + 63) / 64 * 64 / (int)sizeof(T) - T1_HDR / (int)sizeof(T);
+                    T v[NV];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+                        v[k] = k < W ? es_eval<T>((T)(fx + k), beta, c4) : k < 2 * W ? es_eval<T>((T)(fy + (k - W)), beta, c4) : T(0);
+                    struct alignas(16) V16 { T x[PER]; };
+#pragma unroll
+                    for (int k = 0; k < NV; k += PER) {
+                        V16 t;
+#pragma unroll
+                        for (int i = 0; i < PER; ++i) t.x[i] = v[k + i];
+                        *reinterpret_cast<V16 *>(wr + k) = t;
+                    }
+                } else {
+                    const int nreal = (a.rec - T1_HDR) / (int)sizeof(T);
+                    for (int k = 0; k < a.w; ++k) wr[k] = es_eval<T>((T)(fx + k), beta, c4);
+                    for (int k = 0; k < a.w; ++k) wr[a.w + k] = es_eval<T>((T)(fy + k), beta, c4);
+                    for (int k = 2 * a.w; k < nreal; ++k) wr[k] = T(0);  // whole sectors, no partial writes
+                }
             }
         }
 }
@@ -1387,8 +1406,8 @@ class Sim : public SimBase {
                 t1fft->stream = ps;
                 t1fft->exclusive_scan(counts_p, binstart.as<int>(), nbn);
                 t1fft->stream = stream;
-                hipLaunchKernelGGL((k_t1_bin<T, false>), gb, dim3(256), 0, ps, a, Mp, d_xyz.as<T>(),
-                                   d_freqs.as<double>(), counts_p, (const int *)binstart.as<int>(),
+                hipLaunchKernelGGL((ker.w == 9 ? k_t1_bin<T, false, 9> : ker.w == 5 ? k_t1_bin<T, false, 5> : ker.w == 7 ? k_t1_bin<T, false, 7> : k_t1_bin<T, false, 0>), gb, dim3(256), 0, ps, a, Mp,
+                                   d_xyz.as<T>(), d_freqs.as<double>(), counts_p, (const int *)binstart.as<int>(),
                                    cursor_p, recs.as<unsigned char>(), (T)ker.beta, (T)ker.c, ovf_p);
                 ev_end(e1, ps);
                 if (pipe) {
