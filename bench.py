@@ -330,7 +330,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             if a.workload in ("C2", "C3") and not (a.nsrc or a.nfreq or a.ntimes) and a.upsample == 2.0 and world == 1 \
-                    and a.path == "type3" and "FFTVIS_HIP_NO_HERMITIAN" not in os.environ:
+                    and a.path == "type3" and "FFTVIS_HIP_NO_HERMITIAN" not in os.environ and a.as_rank is None:
                 pm = json.load(open(os.path.join(ROOT, PMC_FILE)))
                 k = pm["counters"][a.workload.lower()][spread_kernel]
                 traffic = (2 * k["FETCH_SIZE_KB_avg_per_launch"] + k["WRITE_SIZE_KB_avg_per_launch"]) * 1024
