@@ -2181,6 +2181,7 @@ class Nufft3 {
                 int64_t out_pitch = 0, int64_t rpp_valid = 0, const FusedArgs *fused = nullptr,
                 const cplx<T> *in1 = nullptr, cplx<T> *out1 = nullptr, int in_blk = 0, int out_blk = 0);
     int b_block_log() const;  // column-blocked layout of the x-pass output (0: plain)
+    bool y_reads_columns() const;  // the y-pass runs in column mode (else: tile transpose + row pass)
     int64_t b_pitch() const;  // row pitch of the x-pass output
     cplx<T> *grid_out = nullptr;  // where the last fft() left Ct
 };
@@ -2258,11 +2259,21 @@ inline void rowfft_shape(const DimGeom &g, bool col, int &tpr, int &rpw) {
 template <typename T>
 int64_t Nufft3<T>::b_pitch() const {
     const DimGeom &x = geo.d[0], &y = geo.d[1];
-    int tpr, rpw;
-    rowfft_shape(y, true, tpr, rpw);
+    (void)y;
     // whole 128-B lines per workgroup (8 columns) or per pair of neighbouring workgroups (4 columns each;
     // giving such pairs consecutive slots on one XCD was measured to change nothing: 1.836 vs 1.833 ms)
-    return rpw >= 2 ? (x.nos() + 7) / 8 * 8 : x.nos();
+    return y_reads_columns() ? (x.nos() + 7) / 8 * 8 : x.nos();
+}
+
+// Column mode needs a kernel that holds >= 2 columns per workgroup and planes below 4 GiB per transform (its
+// accesses are 32-bit byte offsets from a plane's base); larger planes take the tile transpose and a row pass.
+template <typename T>
+bool Nufft3<T>::y_reads_columns() const {
+    const DimGeom &x = geo.d[0], &y = geo.d[1];
+    int tpr, rpw;
+    rowfft_shape(y, true, tpr, rpw);
+    const int64_t pitch = (x.nos() + 7) / 8 * 8;
+    return rpw >= 2 && std::max<int64_t>(y.na, y.nos()) * pitch * (int64_t)sizeof(cplx<T>) < (int64_t(1) << 32);
 }
 
 // B (x-pass output, y-pass input) in 64-byte column blocks when both passes run the register-resident kernels
@@ -2274,7 +2285,7 @@ int Nufft3<T>::b_block_log() const {
     const DimGeom &x = geo.d[0], &y = geo.d[1];
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
-    if (off || dim != 2 || !rowfft_uses_st(x, false) || !rowfft_uses_st(y, true) || rpw < 2) return 0;
+    if (off || dim != 2 || !rowfft_uses_st(x, false) || !rowfft_uses_st(y, true) || !y_reads_columns()) return 0;
     static const int force = std::getenv("FFTVIS_HIP_B_BLOCK_LOG") ? std::atoi(std::getenv("FFTVIS_HIP_B_BLOCK_LOG")) : 0;
     if (force) return force;
     return sizeof(cplx<T>) == 16 && rpw < 8 ? 2 : 3;  // 64-B pieces (fp32, and 8-column workgroups: 8 elements)
@@ -2424,7 +2435,7 @@ double Nufft3<T>::fft_traffic_cells() const {
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
     double c = zin * ((double)x.na * y.na + (double)x.no * y.na);        // x-pass
-    if (rpw < 2) c += zin * 2.0 * x.no * y.na;                            // transpose
+    if (!y_reads_columns()) c += zin * 2.0 * x.no * y.na;                 // transpose
     c += zin * ((double)x.no * y.na + (last_fft_fused ? 0.0 : (double)x.no * y.no));  // y-pass (no C when fused)
     if (dim > 2) c += (double)x.no * y.no * (z.na + z.no);               // z-pass
     return c;
@@ -2452,9 +2463,7 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
     rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp, 0, nullptr, cur1, oth1, 0, blk);
     std::swap(cur, oth);
     std::swap(cur1, oth1);
-    int tpr, rpw;
-    rowfft_shape(y, true, tpr, rpw);
-    if (rpw >= 2) {
+    if (y_reads_columns()) {
         // the y-pass reads rpw adjacent columns of B at once (32-128 B segments; neighbouring workgroups share lines),
         // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
         // plane are skipped as rows
