@@ -337,3 +337,18 @@ def test_nufft2d_planes_of_4_gib_take_the_transpose_path(gpu):
     t = rng.uniform(-4280, 4280, N)
     got = gpu_nufft2d(x, y, c, s, t, 1e-9)
     assert rel_l2(got, nudft.nudft_type3([x, y], c, [s, t])) < 5e-9
+
+
+def test_fft_layout_switches_leave_the_result_bit_identical(gpu, tmp_path):
+    """The column-blocked layout of the x-pass output moves data, not arithmetic: switched off
+    (FFTVIS_HIP_NO_BLOCKED_B) the transform returns the same bits.  (The switch is read once per process, hence
+    the worker.)"""
+    from tests.nufft_worker import problem
+
+    ref = gpu_nufft2d(*problem(), 1e-9)
+    out = tmp_path / "plain.npy"
+    env = dict(os.environ, PYTHONPATH=ROOT, FFTVIS_HIP_NO_BLOCKED_B="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nufft_worker.py"), str(out)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert np.array_equal(np.load(out), ref)
