@@ -878,6 +878,7 @@ struct RowDifArgs {
     // the pieces of one block of columns contiguous over the rows.  The x-pass writes it (out_blk), the column-mode
     // y-pass reads it (in_blk): its 4 columns are then ONE contiguous run instead of a 64-B piece per 80-KB row.
     int in_blk, out_blk;
+    int jobs_per_xcd;  // row mode: rows per XCD (a multiple of the rows per workgroup), see k_rowfft_st
     const void *in1;  // gang launch (grid.y = 2): input / output of the second, identically shaped problem
     void *out1;
 };
@@ -1216,14 +1217,30 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
 
     const int tid = threadIdx.x;
     const int vb = blockIdx.x;
-    const int tt = vb >> 3;
-    const int p = tt % a.P;
-    const int64_t grp = (int64_t)(tt / a.P) * 8 + (vb & 7);
-    const int64_t row0 = grp * RPW;
-    if (row0 >= a.nrows) return;  // workgroup-uniform
     const int r = COL ? tid % RPW : tid / TPR;
     const int u = COL ? tid / RPW : tid % TPR;
-    const int64_t row = row0 + r;
+    int p;
+    int64_t row0, row;
+    if constexpr (COL) {
+        // column mode: a workgroup owns RPW adjacent columns and one residue; the P jobs of a column group get
+        // block ids 8 apart (same XCD, back to back)
+        const int tt = vb >> 3;
+        p = tt % a.P;
+        row0 = ((int64_t)(tt / a.P) * 8 + (vb & 7)) * RPW;
+        if (row0 >= a.nrows) return;  // workgroup-uniform
+        row = row0 + r;
+    } else {
+        // row mode: XCD x (= block id mod 8) takes the x-th eighth of the rows, a CONTIGUOUS range -- neighbouring rows
+        // write neighbouring 64-byte pieces of the blocked output, which then meet in one L2 (interleaving the row
+        // groups over the XCDs cost the Q = 4096 x-pass 10 %) -- and within it jobs run row group by row group, the
+        // P residues of a group back to back.  (The RPW wave groups of a workgroup take different rows, never two
+        // residues of one row: simultaneous requests for a line stall each other in the CU's L1 -- 1 506 vs 1 425 us.)
+        const int i = vb >> 3, g = i / a.P;
+        p = i - g * a.P;
+        row0 = (int64_t)(vb & 7) * a.jobs_per_xcd + (int64_t)g * RPW;  // jobs_per_xcd: rows per XCD here
+        if (g * RPW >= a.jobs_per_xcd || row0 >= a.nrows) return;  // workgroup-uniform
+        row = row0 + r;
+    }
     const int64_t rplane = row / a.rpp, rk = row % a.rpp;
     const bool ok = row < a.nrows && rk < a.rpp_valid;
     const int n2 = a.n2;
@@ -2373,7 +2390,13 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     }
     a.in1 = in1;
     a.out1 = out1;
-    const dim3 jobs((unsigned)(ngroups8 * 8 * g.P), in1 ? 2 : 1);
+    dim3 jobs((unsigned)(ngroups8 * 8 * g.P), in1 ? 2 : 1);
+    a.jobs_per_xcd = 0;
+    if (rowfft_uses_st(g, a.colmode != 0) && !a.colmode) {
+        FV_REQUIRE(a.nrows < (int64_t(1) << 30), "row FFT: too many rows");
+        a.jobs_per_xcd = (int)(cdiv(cdiv(a.nrows, 8), a.rpw) * a.rpw);           // rows per XCD, whole workgroups
+        jobs.x = (unsigned)(8 * (a.jobs_per_xcd / a.rpw) * g.P);
+    }
     if (rowfft_uses_st(g, a.colmode != 0)) {
         const int s1 = g.Q / (g.logQ == 9 ? 8 : 16);       // stride of the first radix pass
         // possibly non-zero inputs per thread: the row is centred (see the kernel), so the elements sit in
