@@ -1637,6 +1637,7 @@ __global__ void k_transpose(const cplx<T> *__restrict__ in, cplx<T> *__restrict_
 // dimension (y in 2-D, z in 3-D), index 1 the next one, index 2 (3-D only) the slowest.
 struct InterpArgs {
     int w, tpol, nfg;             // tpol transforms per frequency group, nfg groups
+    int64_t items_per_xcd;        // (frequency, target) items per XCD: see k_interp
     int n2[3], no[3];
     int P[3], cnt[3];             // residue-major column storage (DimGeom::out_pos), row length P cnt
     double h[3];                  // theta = h * s'
@@ -1676,8 +1677,13 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const int tid = threadIdx.x;
     const int g = tid & (GROUP - 1);
     const int lane_base = (tid & 63) & ~(GROUP - 1);
-    const int64_t item = (int64_t)blockIdx.x * (INTERP_THREADS / GROUP) + tid / GROUP;
-    if (item >= N * a.nfg) return;  // whole group exits together
+    // XCD x (= block id mod 8) takes the x-th eighth of the (frequency, target) items, a contiguous range: targets
+    // next to each other in the caller's list -- redundant baselines, when the list is ordered by baseline vector --
+    // then read their common grid lines through ONE L2 instead of up to eight
+    constexpr int IPW = INTERP_THREADS / GROUP;
+    const int64_t per_xcd = a.items_per_xcd;
+    const int64_t item = (int64_t)(blockIdx.x & 7) * per_xcd + (int64_t)(blockIdx.x >> 3) * IPW + tid / GROUP;
+    if ((int64_t)(blockIdx.x >> 3) * IPW + tid / GROUP >= per_xcd || item >= N * a.nfg) return;  // whole group exits together
     const int fg = (int)(item / N);
     const int64_t kl = item % N;
     const int64_t k = bl_idx ? bl_idx[kl] : kl;
@@ -2651,7 +2657,9 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.accumulate = accumulate ? 1 : 0;
     a.herm = herm;
     const int64_t items = N * nfg;
-    const dim3 grid((unsigned)cdiv(items, INTERP_THREADS / GROUP));
+    constexpr int IPW = INTERP_THREADS / GROUP;
+    a.items_per_xcd = cdiv(cdiv(items, 8), IPW) * IPW;  // whole workgroups
+    const dim3 grid((unsigned)(8 * (a.items_per_xcd / IPW)));
     const bool r9 = ker.w <= 9;
     auto kern = dim == 2 ? (herm ? (r9 ? k_interp<T, 2, true, 9> : k_interp<T, 2, true, 16>)
                                  : (r9 ? k_interp<T, 2, false, 9> : k_interp<T, 2, false, 16>))
