@@ -229,7 +229,7 @@ def main():
         h.set_basis(cfg["beam_coefs"], [antnums.index(b[0]) for b in baselines],
                     [antnums.index(b[1]) for b in baselines])
     else:
-        h.set_beam_pairs(pairs, pidx, pflip, None if os.environ.get("FFTVIS_HIP_NO_TARGET_SORT") else bls)
+        h.set_beam_pairs(pairs, pidx, pflip)
     outs = []
     for tsl, fsl in mine:
         outs.append(torch.empty(h.out_shape(tsl.stop - tsl.start, fsl.stop - fsl.start), dtype=cdt, device=dev))

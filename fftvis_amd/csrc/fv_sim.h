@@ -884,6 +884,7 @@ class Sim : public SimBase {
     int64_t nbls = 0;
     bool coplanar = true;
     std::vector<double> h_bls;  // (3, nbls) seconds
+    bool order_pairs = true;    // set_beam_pairs visits a pair's baselines in (u, v) order
     DevBuf d_bls;               // (3, nbls) T
 
     int beam_order = 1;  // interpolation order of the tabulated beams (1 or 3)
@@ -1186,10 +1187,37 @@ class Sim : public SimBase {
             pr.n = off[p + 1] - off[p];
             const int *ix = idx + off[p];
             const signed char *fl = flipped + off[p];
+            for (int64_t k = 0; k < pr.n; ++k) FV_REQUIRE(ix[k] >= 0 && ix[k] < nbls, "baseline index out of range");
+            // The list is visited in order of the (flipped) baseline vector: redundant baselines -- most of a regular
+            // array's -- then sit next to each other, the gather hands neighbouring items to one XCD, and they read
+            // their common grid lines through one L2 (C3: 0.31 -> 0.25 ms per launch).  The order of a list is free:
+            // every baseline writes its own output slot.
+            static const bool keep_order = std::getenv("FFTVIS_HIP_NO_TARGET_SORT") != nullptr;
+            std::vector<int> six(ix, ix + pr.n);
+            std::vector<signed char> sfl(fl, fl + pr.n);
+            if (!keep_order && order_pairs && pr.n > 1) {
+                double bmax = 0;
+                for (int64_t k = 0; k < pr.n; ++k)
+                    bmax = std::max({bmax, std::fabs(h_bls[ix[k]]), std::fabs(h_bls[(size_t)nbls + ix[k]])});
+                const double q = 1e-7 * std::max(bmax, 1e-300);  // ties for vectors equal up to rounding
+                std::vector<std::pair<int64_t, int64_t>> key(pr.n);
+                std::vector<int64_t> ord(pr.n);
+                for (int64_t k = 0; k < pr.n; ++k) {
+                    const double sg = fl[k] ? -1.0 : 1.0;
+                    key[k] = {(int64_t)std::llround(sg * h_bls[ix[k]] / q), (int64_t)std::llround(sg * h_bls[(size_t)nbls + ix[k]] / q)};
+                    ord[k] = k;
+                }
+                std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
+                for (int64_t k = 0; k < pr.n; ++k) {
+                    six[k] = ix[ord[k]];
+                    sfl[k] = fl[ord[k]];
+                }
+            }
+            ix = six.data();
+            fl = sfl.data();
             pr.trivial = pr.n == nbls;
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             for (int64_t k = 0; k < pr.n; ++k) {
-                FV_REQUIRE(ix[k] >= 0 && ix[k] < nbls, "baseline index out of range");
                 if (ix[k] != k || fl[k]) pr.trivial = false;
                 const double sg = fl[k] ? -1.0 : 1.0;
                 for (int d = 0; d < 3; ++d) {
@@ -1241,7 +1269,9 @@ class Sim : public SimBase {
                 }
                 off.push_back((int64_t)all.size());
             }
+        order_pairs = false;  // the eigenbeam contraction reads per-antenna coefficients by baseline: catalogue order (measured: no gain from (u, v) order)
         set_beam_pairs((int)bi.size(), bi.data(), bj.data(), off.data(), all.data(), fl.data());
+        order_pairs = true;
     }
 
     void set_chunking(int nchunks, double sb) override {

@@ -12,7 +12,6 @@ fallback: without the library or a GPU the calls raise.
 from __future__ import annotations
 
 import ctypes
-import os
 import atexit
 import logging
 import warnings
@@ -147,28 +146,16 @@ class SimHandle:
                                                          tab.shape[-1], float(d[2]), _lib.ptr(tab),
                                                          int(order)))
 
-    def set_beam_pairs(self, pairs, pair_idx, pair_flip, bls=None):
-        """Per beam pair the baselines it serves and their flip flags (prepare_beam_evaluation).  With the
-        baseline vectors ``bls`` (3, nbls) a pair's list is visited in order of (u, v): redundant baselines -- most
-        of a regular array's -- then sit next to each other, and the gather hands neighbouring items to one XCD, so
-        they read their common grid lines through one L2.  The order of a list is free: every baseline writes its
-        own output slot."""
+    def set_beam_pairs(self, pairs, pair_idx, pair_flip):
         bi = np.array([p[0] for p in pairs], dtype=np.int32)
         bj = np.array([p[1] for p in pairs], dtype=np.int32)
         off = np.zeros(len(pairs) + 1, dtype=np.int64)
         idx, flp = [], []
         for n, p in enumerate(pairs):
             ii = np.asarray(pair_idx[p], dtype=np.int32)
-            ff = np.asarray(pair_flip[p], dtype=np.int8)
-            if bls is not None and ii.size > 1:
-                sg = np.where(ff != 0, -1.0, 1.0)
-                u, v = sg * bls[0, ii], sg * bls[1, ii]
-                q = 1e-7 * max(float(np.abs(bls[:2]).max()), 1e-300)  # ties for vectors equal up to rounding
-                order = np.lexsort((np.round(v / q), np.round(u / q)))
-                ii, ff = ii[order], ff[order]
             off[n + 1] = off[n] + ii.size
             idx.append(ii)
-            flp.append(ff)
+            flp.append(np.asarray(pair_flip[p], dtype=np.int8))
         idx = np.ascontiguousarray(np.concatenate(idx) if idx else np.zeros(0, np.int32))
         flp = np.ascontiguousarray(np.concatenate(flp) if flp else np.zeros(0, np.int8))
         if idx.size == 0:  # keep the pointers valid
@@ -419,9 +406,7 @@ class GPUSimulationEngine(SimulationEngine):
             if use_basis:
                 h.set_basis(beam_coefs, ant1_idxs, ant2_idxs)
             else:
-                # type 3: pair lists in (u, v) order (the lattice path picks modes, it has no gather to help)
-                order_by = None if is_gridded or os.environ.get("FFTVIS_HIP_NO_TARGET_SORT") else bls
-                h.set_beam_pairs(pairs, pair_idx, pair_flip, order_by)
+                h.set_beam_pairs(pairs, pair_idx, pair_flip)
             t0, t1, _ = time_idx.indices(ntimes)
             f0, f1, _ = freq_idx.indices(nfreqs)
             # Walk the time axis in blocks whose output fits comfortably in free device memory (the
