@@ -1269,9 +1269,13 @@ class Sim : public SimBase {
                 }
                 off.push_back((int64_t)all.size());
             }
-        order_pairs = false;  // the eigenbeam contraction reads per-antenna coefficients by baseline: catalogue order (measured: no gain from (u, v) order)
+        // the eigenbeam contraction reads per-antenna coefficients by baseline: catalogue order (measured: no gain from (u, v) order)
+        struct Restore {
+            bool &b;
+            ~Restore() { b = true; }
+        } restore{order_pairs};
+        order_pairs = false;
         set_beam_pairs((int)bi.size(), bi.data(), bj.data(), off.data(), all.data(), fl.data());
-        order_pairs = true;
     }
 
     void set_chunking(int nchunks, double sb) override {
