@@ -1,5 +1,8 @@
-"""Host model of the engine's grid choices (set_dim_geom / choose_pq / freq_groups of fv_nufft.h, fv_sim.h)
-for a BASELINE workload: prints every frequency group's fine-grid geometry and FFT factorisation.
+"""Host model of the engine's grid choices (set_dim_geom / choose_pq / cap_column_q / freq_groups of fv_nufft.h,
+fv_sim.h) for a BASELINE workload: prints every frequency group's fine-grid geometry and FFT factorisation.
+Polarized single-beam runs use the target box symmetric about 0 (Hermitian packing, two transforms per channel).
+The grouping is the engine's ratio rule with the 6 GiB budget, WITHOUT its rounding of groups to whole eights of
+transforms: group boundaries can differ by a channel or two from a real run (FFTVIS_HIP_DEBUG_FFT=1 prints those).
 usage: python tools/grid_model.py [C3] [sigma] [pq_penalty]"""
 import math, sys, os
 import numpy as np
@@ -10,7 +13,7 @@ from fftvis_amd.gpu.gpu_simulate import prepare_array
 QMAX = 12
 
 
-def choose_pq(nmin, pen=0.25, qmax=QMAX):
+def choose_pq(nmin, pen=0.12, qmax=QMAX):
     best = None
     for b in range(4, qmax + 1):
         q = 1 << b
@@ -39,7 +42,7 @@ def dim_geom(X, B, sigma, w, smax, pen, qmax=QMAX):
     return dict(n1=n1, na=na, P=P, Q=Q, n2=n2, no=no)
 
 
-def groups(freqs, cells_top, tpol, budget=4 * 2**30):
+def groups(freqs, cells_top, tpol, budget=6 * 2**30):
     mb = cells_top * 16 / 2**20
     ratio = 0.5 + 0.4 * min(1.0, max(0.0, math.log2(mb / 16.0) / 4.0))
     fmax = max(freqs)
@@ -64,20 +67,23 @@ def groups(freqs, cells_top, tpol, budget=4 * 2**30):
 if __name__ == "__main__":
     wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
     sigma = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
-    pen = float(sys.argv[3]) if len(sys.argv) > 3 else 0.25
+    pen = float(sys.argv[3]) if len(sys.argv) > 3 else 0.12
     qmax = int(sys.argv[4]) if len(sys.argv) > 4 else QMAX
     cfg = synth.make_config(wl, nsrc=10, ntimes=1)
     R, bls, cop = prepare_array(cfg["ants"], cfg["baselines"], 1e-6, np.float64)
     w = 9 if sigma == 2 else 13
-    tpol = 4 if cfg["polarized"] else 1
+    herm = cfg["polarized"] and not isinstance(cfg["beam"], list)
+    tpol = 2 if herm else 4 if cfg["polarized"] else 1
     X = [2 * math.pi * (1 + 1e-9)] * 2  # flat array: full disc in both dimensions
-    B = [0.5 * (bls[d].max() - bls[d].min()) * (1 + 1e-12) for d in range(2)]
+    B = [(np.abs(bls[d]).max() if herm else 0.5 * (bls[d].max() - bls[d].min())) * (1 + 1e-12) for d in range(2)]
     f = list(cfg["freqs"])
     top = [dim_geom(X[d], B[d], sigma, w, max(f), pen, qmax) for d in range(2)]
     cells_top = 2.0 * max(top[0]["na"] * top[1]["na"], top[1]["na"] * top[0]["no"], top[0]["no"] * top[1]["no"])
     tot = 0
     for a, b in groups(f, cells_top, tpol):
         gx, gy = (dim_geom(X[d], B[d], sigma, w, f[b - 1], pen, qmax) for d in range(2))
+        while gy["Q"] > 2048 and 2 * gy["P"] <= 16:  # cap_column_q: columns run as residues of Q <= 2048
+            gy["P"], gy["Q"] = 2 * gy["P"], gy["Q"] // 2
         cells = gx["na"] * gy["na"] + 2 * gx["no"] * gy["na"] + gx["no"] * gy["no"]
         tot += cells * (b - a) * tpol
         print(f"ch {a:3d}-{b - 1:3d} ntrans {(b - a) * tpol:3d}  x: na {gx['na']} n2 {gx['n2']} = {gx['P']} x {gx['Q']} no {gx['no']}   "
