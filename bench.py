@@ -8,7 +8,8 @@ are already resident in HBM when the timed region starts.  Default workload: con
 upsample_factor 2) -- the largest configuration BASELINE.json lists for one GPU.  `--workload C2`
 keeps the HERA-37 case of round 1, C4 / C5 run the 8-GPU configurations' shapes.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): ONE observation is
+Multi-GPU (--gpus N; one rank per GPU, either launched by torch.distributed.run or, when bench.py is
+started as a single process, by bench.py itself as a child torchrun -- spawn_ranks): ONE observation is
 sharded over the ranks by independent (time, frequency) blocks (parallel.shard_blocks_weighted:
 time-major, frequency cuts balanced by the nu^2 grid cost) with no data-path collective; the only
 communication is the one-off RCCL broadcast of the source catalog from rank 0 into every rank's
@@ -138,11 +139,36 @@ def cpu_baseline(cfg, seconds: float):
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """`bench.py --gpus N` started as ONE process (no WORLD_SIZE in the environment): start the N ranks
+    ourselves, the way the reference fans its own workers out of one call (cpu_simulate.py:714-835) -- a
+    CHILD `python -m torch.distributed.run` (never an exec, and before this process touches the GPU), one
+    rank per GPU, rendezvous on 127.0.0.1.  Rank 0's JSON line passes through on stdout; returns the
+    child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free port for the rendezvous
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and a.as_rank is None:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and a.as_rank is None:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but {world} rank(s) joined (WORLD_SIZE); launch with "
+                         f"--nproc-per-node {a.gpus} or let bench.py start its own ranks")
     import torch
 
     from fftvis_amd import _lib, parallel, synth

@@ -210,6 +210,24 @@ class SimHandle:
         return dict(zip(["spread", "fft", "interp", "strengths", "prep", "spread_launches_timed"], v))
 
 
+def register_with_reference() -> bool:
+    """Make ``isinstance(engine, fftvis.core.simulate.SimulationEngine)`` hold where the reference is
+    installed (virtual-subclass registration on its ABC, core/simulate.py:22).  Called at import; the stub
+    module of INTEGRATION.md, route A, may call it again once ``fftvis.core`` is importable."""
+    import sys
+
+    try:
+        mod = sys.modules.get("fftvis.core.simulate")
+        if mod is None:
+            import importlib
+
+            mod = importlib.import_module("fftvis.core.simulate")
+        mod.SimulationEngine.register(GPUSimulationEngine)
+        return True
+    except Exception:  # the reference (or one of its dependencies) is not installed
+        return False
+
+
 def prepare_array(ants: dict, baselines, flat_array_tol: float, real_dtype):
     """Plane-fit rotation, rotated baselines in seconds, coplanarity flag
     (reference cpu_simulate.py:628-659)."""
@@ -275,13 +293,13 @@ class GPUSimulationEngine(SimulationEngine):
         * like the reference, a flat array whose antennas sit on a lattice takes the type-1 path
           unless ``force_use_type3`` (cpu_simulate.py:634-637); eigenbeam runs always use type 3
           here;
-        * ``coord_method``: matvis / ERFA astrometry is not part of this backend.  A caller holding a
-          matvis coordinate manager passes it as ``coord_mgr`` and its per-time topocentric vectors
-          (``rotate(ti)`` -> ``all_coords_topo``) are used verbatim, streamed to the device one time
-          block at a time.  Without one, ``"CoordinateRotationERFA"`` (the reference's default, and
-          ours) and ``"CoordinateRotationAstropy"`` RAISE; the mean-sidereal rotation of
-          ``core/coords.py`` (no precession / nutation / aberration: ~0.35 deg off ICRS positions at
-          2025 epochs) runs only when asked for by name, ``coord_method="SiderealRotation"``;
+        * ``coord_method``: as in the reference (cpu_simulate.py:686-709) the engine builds matvis' coordinate
+          manager ``CoordinateRotation._methods[coord_method]`` itself when the caller passes none (matvis and
+          astropy are imported lazily, here only; without them the call raises ValueError) and uses its per-time
+          topocentric vectors (``rotate(ti)`` -> ``all_coords_topo``) verbatim, streamed to the device one time
+          block at a time; a caller-built manager can be handed over as ``coord_mgr`` (extra).  The
+          mean-sidereal rotation of ``core/coords.py`` (no precession / nutation / aberration: ~0.35 deg off
+          ICRS positions at 2025 epochs) runs only when asked for by name, ``coord_method="SiderealRotation"``;
         * ``nchunks`` splits the source axis exactly like the reference's chunk loop
           (cpu_simulate.py:939,1024,1069): every time step processes the catalog in ``nchunks`` pieces
           whose visibilities accumulate on the device; ``source_buffer`` sizes the above-horizon
@@ -316,14 +334,10 @@ class GPUSimulationEngine(SimulationEngine):
             raise ValueError("nchunks must be >= 1")
         if not 0.0 < float(source_buffer) <= 1.0:
             raise ValueError("source_buffer must be in (0, 1]")
-        if coord_mgr is None and coord_method != "SiderealRotation":
-            if coord_method in ("CoordinateRotationERFA", "CoordinateRotationAstropy"):
-                raise ValueError(
-                    f"coord_method={coord_method!r} needs matvis / ERFA astrometry, which the gpu backend does "
-                    "not carry: pass the matvis coordinate manager as coord_mgr= (its per-time topocentric "
-                    "vectors are used verbatim), or ask for the mean-sidereal approximation by name with "
-                    "coord_method='SiderealRotation' (no precession / nutation / aberration)")
-            raise ValueError(f"unknown coord_method {coord_method!r}")
+        if coord_mgr is None and coord_method != "SiderealRotation" and catalog_device is not None:
+            raise ValueError(
+                "a device-resident catalog carries no ra / dec for a matvis coordinate manager: pass coord_mgr= "
+                "or coord_method='SiderealRotation'")
         freqs = np.asarray(freqs)
         nfreqs, ntimes, nbeam, nant = np.size(freqs), len(julian_dates(times)), len(beam_list), len(ants)
         real_dtype = np.float32 if precision == 1 else np.float64
@@ -353,8 +367,14 @@ class GPUSimulationEngine(SimulationEngine):
             coherency, polarized_sky = utils.prepare_source_catalog(np.asarray(fluxes), polarized)
             if coherency.shape[0] != nsrc or coherency.shape[1] != nfreqs:
                 raise ValueError("fluxes must have shape (nsources, nfreqs[, 4])")
-        elif catalog_device.nfreq != nfreqs or (catalog_device.polarized_sky and not polarized):
-            raise ValueError("catalog_device does not match freqs / polarized")
+        else:
+            _check_device_catalog(catalog_device, nfreqs, polarized, precision, self.device)
+
+        if coord_mgr is None and coord_method != "SiderealRotation":
+            # the reference's own call (wrapper.py:308-336 passes no manager): build matvis' manager exactly
+            # as the CPU engine does (cpu_simulate.py:686-709) and stream its vectors like a caller's
+            coord_mgr = build_coord_mgr(coord_method, coord_method_params, coherency.astype(complex_dtype, copy=False),
+                                        times, telescope_loc, ra, dec, precision, source_buffer, nchunks)
 
         # lattice arrays -> type 1 (reference cpu_simulate.py:634-637, 661-681)
         antvecs = np.array([ants[a] for a in ants], dtype=real_dtype)
@@ -447,6 +467,67 @@ class GPUSimulationEngine(SimulationEngine):
         return np.moveaxis(final, 0, 2)[:, :, None, None, :]
 
 
+def build_coord_mgr(coord_method, coord_method_params, coherency, times, telescope_loc, ra, dec, precision,
+                    source_buffer, nchunks):
+    """The matvis coordinate manager the CPU engine builds at reference cpu_simulate.py:686-709, built the same
+    way: ``CoordinateRotation._methods[coord_method](flux=, times=, telescope_loc=, skycoords=, precision=,
+    source_buffer=, chunk_size=, **coord_method_params)``, BCRS fixed up front when ``update_bcrs_every``
+    exceeds the observation's span.  matvis / astropy are imported here, on first use, because they are the
+    reference's dependencies, not this backend's; without them the request is refused, never approximated."""
+    try:
+        from astropy import units as un
+        from astropy.coordinates import SkyCoord
+        from astropy.time import Time
+        from matvis.core.coords import CoordinateRotation
+    except ImportError as e:
+        raise ValueError(
+            f"coord_method={coord_method!r} needs matvis / astropy ({e}): install them (they are dependencies of "
+            "fftvis), pass a matvis coordinate manager as coord_mgr= (its per-time topocentric vectors are used "
+            "verbatim), or ask for the mean-sidereal approximation by name with coord_method='SiderealRotation' "
+            "(no precession / nutation / aberration)") from e
+    if coord_method not in CoordinateRotation._methods:
+        raise ValueError(f"unknown coord_method {coord_method!r}")
+    if isinstance(times, np.ndarray):  # cpu_simulate.py:686-687
+        times = Time(times, format="jd")
+    chunk_size = int(np.ceil(dec.size / nchunks))  # :689
+    mgr = CoordinateRotation._methods[coord_method](
+        flux=coherency,
+        times=times,
+        telescope_loc=telescope_loc,
+        skycoords=SkyCoord(ra=ra * un.rad, dec=dec * un.rad, frame="icrs"),
+        precision=precision,
+        source_buffer=source_buffer,
+        chunk_size=chunk_size,
+        **(coord_method_params or {}),
+    )
+    if getattr(mgr, "update_bcrs_every", 0) > (times[-1] - times[0]).to(un.s):  # :706-709
+        mgr._set_bcrs(0)
+    return mgr
+
+
+def _check_device_catalog(cat, nfreqs, polarized, precision, device):
+    """Raw device pointers go to ``fv_sim_set_sources(on_device=1)``: everything the C side cannot see is
+    checked here -- dtypes of the run's precision, contiguity, shapes, and the device the tensors live on."""
+    import torch
+
+    rdt = torch.float32 if precision == 1 else torch.float64
+    cdt = torch.complex64 if precision == 1 else torch.complex128
+    if cat.nfreq != nfreqs or (cat.polarized_sky and not polarized):
+        raise ValueError("catalog_device does not match freqs / polarized")
+    want_flux = (cat.nsrc, nfreqs, 2, 2) if cat.polarized_sky else (cat.nsrc, nfreqs)
+    if tuple(cat.eq.shape) != (3, cat.nsrc) or tuple(cat.flux.shape) != want_flux:
+        raise ValueError(f"catalog_device: eq must be (3, nsrc) and flux {want_flux}, got {tuple(cat.eq.shape)} / "
+                         f"{tuple(cat.flux.shape)}")
+    if cat.eq.dtype != rdt or cat.flux.dtype != (cdt if cat.polarized_sky else rdt):
+        raise ValueError(f"catalog_device was built for another precision: eq {cat.eq.dtype}, flux {cat.flux.dtype}, "
+                         f"run precision={precision}")
+    if not (cat.eq.is_contiguous() and cat.flux.is_contiguous()):
+        raise ValueError("catalog_device tensors must be contiguous")
+    for t in (cat.eq, cat.flux):
+        if t.device.type != "cuda" or (t.device.index or 0) != int(device):
+            raise ValueError(f"catalog_device lives on {t.device}, the engine runs on cuda:{int(device)}")
+
+
 def _topo_from_coord_mgr(coord_mgr, time_indices):
     """Topocentric unit vectors (len(time_indices), 3, nsrc) of every source at the given time indices
     from a matvis-style manager (``rotate(ti)``, attribute ``all_coords_topo``; ``setup()`` was called)."""
@@ -460,11 +541,13 @@ def _topo_from_coord_mgr(coord_mgr, time_indices):
 def _time_block(device, nt, nf, nbls, polarized, precision, nsrc_topo=0):
     """Time steps per fv_sim_run: as many as keep the output block under 45 % of free device memory
     (and, with a coordinate manager, the staged vectors of a block under 2 GiB)."""
-    free = ctypes.c_int64(0)
-    total = ctypes.c_int64(0)
-    _lib.check(_lib.lib().fv_device_mem_info(int(device), ctypes.byref(free), ctypes.byref(total)))
+    from ..wrapper import device_memory_budget  # free + what this process's own cached handles hold
+
     per_time = max(1, nf * nbls * (4 if polarized else 1) * 8 * precision)
-    n = max(1, int(0.45 * free.value // per_time))
+    n = max(1, int(0.45 * device_memory_budget(device) // per_time))
     if nsrc_topo:
         n = min(n, max(1, int(2**31 // (3 * nsrc_topo * 4 * precision))))
     return min(n, max(nt, 1))
+
+
+register_with_reference()

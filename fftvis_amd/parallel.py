@@ -196,16 +196,70 @@ def simulate_sharded(compute_block, nfreqs: int, ntimes: int, gather_to: int | N
     parts = [(blk, compute_block(*blk)) for blk in blocks[rank]]
     if gather_to is None:
         return parts
+    # Only the block index travels as a Python object; the visibilities go as flat real tensors, block by
+    # block and in pieces of <= 256 MiB (C4: 7.5 GB per rank -- pickling that through gather_object would
+    # hold three copies of it), point to point into rank ``gather_to``: RCCL send / recv of device staging
+    # buffers under "nccl", host tensors under gloo.
+    index = [(blk, p.shape, str(p.dtype)) for blk, p in parts]
     gathered = [None] * world if rank == gather_to else None
-    dist.gather_object(parts, gathered, dst=gather_to)
+    dist.gather_object(index, gathered, dst=gather_to)
     if rank != gather_to:
+        for _, p in parts:
+            _send_array(p, gather_to)
         return None
-    first = next(p for plist in gathered for _, p in plist)
-    vis = np.zeros((nfreqs, ntimes) + first.shape[2:], dtype=first.dtype)
-    for plist in gathered:
-        for (tsl, fsl), p in plist:
+    vis = None
+    for src, plist in enumerate(gathered):
+        for n, ((tsl, fsl), shape, dt) in enumerate(plist):
+            p = parts[n][1] if src == rank else _recv_array(shape, np.dtype(dt), src)
+            if vis is None:
+                vis = np.zeros((nfreqs, ntimes) + tuple(shape[2:]), dtype=dt)
             vis[fsl, tsl] = p  # reference: vis[tc][..., fc] = future (cpu_simulate.py:846-847)
     return vis
+
+
+_PIECE_BYTES = 256 * 2**20
+
+
+def _flat_real(a: np.ndarray) -> np.ndarray:
+    """The bytes of a contiguous real / complex array as a flat real array (RCCL has no complex type)."""
+    a = np.ascontiguousarray(a)
+    return a.view(a.real.dtype).reshape(-1)
+
+
+def _staging_device():
+    import torch
+    import torch.distributed as dist
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else None
+
+
+def _send_array(a: np.ndarray, dst: int):
+    import torch
+    import torch.distributed as dist
+
+    flat, dev = _flat_real(a), _staging_device()
+    step = max(1, _PIECE_BYTES // flat.itemsize)
+    for i in range(0, flat.size, step):
+        t = torch.from_numpy(flat[i:i + step])
+        dist.send(t.to(dev) if dev is not None else t, dst=dst)
+
+
+def _recv_array(shape, dtype: np.dtype, src: int) -> np.ndarray:
+    import torch
+    import torch.distributed as dist
+
+    out = np.empty(shape, dtype=dtype)
+    flat, dev = _flat_real(out), _staging_device()
+    step = max(1, _PIECE_BYTES // flat.itemsize)
+    for i in range(0, flat.size, step):
+        piece = flat[i:i + step]
+        if dev is None:
+            dist.recv(torch.from_numpy(piece), src=src)
+        else:
+            t = torch.empty(piece.size, dtype=torch.from_numpy(piece).dtype, device=dev)
+            dist.recv(t, src=src)
+            piece[:] = t.cpu().numpy()
+    return out
 
 
 def simulate_vis_sharded(device, gather_to: int | None = 0, via_host: bool = False, **kw):
@@ -225,11 +279,18 @@ def simulate_vis_sharded(device, gather_to: int | None = 0, via_host: bool = Fal
     beam = kw.pop("beam")
     kw["beam_list"] = list(beam) if isinstance(beam, (list, tuple)) else [beam]
     polarized, precision = bool(kw.get("polarized", False)), int(kw.get("precision", 2))
+    max_memory, min_chunks = kw.pop("max_memory", np.inf), kw.pop("min_chunks", 1)
     cat = broadcast_catalog_device(kw.pop("ra", None), kw.pop("dec", None), kw.pop("fluxes", None), polarized,
                                    precision, torch.device("cuda", int(device)), via_host=via_host)
     freqs = np.asarray(kw["freqs"])
     ntimes = len(julian_dates(kw["times"]))
     engine = create_simulation_engine("gpu", device=int(device))
+    if "nchunks" not in kw:  # the wrapper's memory knobs (reference wrapper.py:292-302), against this rank's device
+        from .wrapper import device_chunks
+
+        nfeed = 2 if polarized else 1
+        kw["nchunks"] = device_chunks(int(device), max_memory, min_chunks, kw["beam_list"], nfeed, nfeed,
+                                      len(kw["ants"]), cat.nsrc, precision, kw.get("source_buffer", 1.0), len(freqs))
 
     def compute_block(tsl, fsl):
         return engine.simulate(ra=None, dec=None, fluxes=None, catalog_device=cat, time_idx=tsl, freq_idx=fsl, **kw)

@@ -40,6 +40,29 @@ def create_simulation_engine(backend: str = "gpu", **kwargs) -> SimulationEngine
     raise ValueError(f"Unsupported backend: {backend}")
 
 
+def device_memory_budget(device: int) -> int:
+    """Bytes a run on ``device`` may plan with: what the device reports free PLUS what this process's own
+    cached handles and NUFFT workspaces hold (``fv_device_bytes``) -- the next run reuses or replaces those,
+    so counting them as taken would shrink the budget after every large run (more source chunks, smaller time
+    blocks, results differing at rounding level) although nothing else is using the memory.  The reference
+    measures available host RAM (wrapper.py:292-302), which has no such self-accounting."""
+    import ctypes
+
+    from . import _lib
+
+    free, total, held = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().fv_device_mem_info(int(device), ctypes.byref(free), ctypes.byref(total)))
+    _lib.check(_lib.lib().fv_device_bytes(ctypes.byref(held)))
+    return int(min(total.value, free.value + max(held.value, 0)))
+
+
+def device_chunks(device, max_memory, min_chunks, beam_list, nax, nfeed, nant, nsrc, precision, source_buffer, nfreq):
+    """``nchunks`` as the reference derives it (wrapper.py:292-302), against device memory."""
+    nchunks, _ = get_desired_chunks(min(max_memory, device_memory_budget(device)), min_chunks, beam_list, nax, nfeed,
+                                    nant, nsrc, precision, source_buffer=source_buffer, nfreq=nfreq)
+    return nchunks
+
+
 def simulate_vis(
     ants: dict,
     fluxes: np.ndarray,
@@ -81,8 +104,9 @@ def simulate_vis(
     against DEVICE memory: the source axis is cut into at least ``min_chunks`` pieces, more if the
     per-time working set would not fit in min(max_memory, free device memory).  ``use_feed`` picks the
     feed of an E-field beam whose power an unpolarized run uses (wrapper.py:278-279).  ``coord_method``
-    defaults to the reference's "CoordinateRotationERFA", which this backend only honours through
-    ``coord_mgr=``; see ``GPUSimulationEngine.simulate``."""
+    defaults to the reference's "CoordinateRotationERFA": the engine builds matvis' manager for it as the CPU
+    engine does (cpu_simulate.py:686-709; matvis / astropy imported on first use) unless a ready one is passed
+    as ``coord_mgr=``; see ``GPUSimulationEngine.simulate``."""
     if eps is None:
         eps = default_accuracy_dict[precision]  # wrapper.py:241-242
     ants = {k: np.array(v) for k, v in ants.items()}
@@ -95,15 +119,8 @@ def simulate_vis(
     feed_index(use_feed)  # 'x' or 'y'
     nax = nfeed = 2 if polarized else 1
     engine = create_simulation_engine(backend=backend, device=device)
-    # wrapper.py:292-302 with device memory in place of host RAM
-    from . import _lib
-    import ctypes
-
-    free, total = ctypes.c_int64(0), ctypes.c_int64(0)
-    _lib.check(_lib.lib().fv_device_mem_info(int(device), ctypes.byref(free), ctypes.byref(total)))
-    nchunks, _ = get_desired_chunks(min(max_memory, free.value), min_chunks, beam_list, nax, nfeed, len(ants),
-                                    len(np.atleast_1d(ra)), precision, source_buffer=source_buffer,
-                                    nfreq=int(np.size(freqs)))
+    nchunks = device_chunks(device, max_memory, min_chunks, beam_list, nax, nfeed, len(ants),
+                            len(np.atleast_1d(ra)), precision, source_buffer, int(np.size(freqs)))
     return engine.simulate(
         ants=ants, freqs=np.asarray(freqs), fluxes=fluxes, beam_list=beam_list, beam_idx=beam_idx,
         ra=ra, dec=dec, times=times, telescope_loc=telescope_loc, baselines=baselines,

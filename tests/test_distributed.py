@@ -39,6 +39,7 @@ def _worker(rank, world, port, q):
             sub = dict(cfg, freqs=cfg["freqs"][fsl], times=cfg["times"][tsl], fluxes=fl[:, fsl])
             return oracle_simulate(sub)
 
+        parallel._PIECE_BYTES = 1000  # blocks of 4 to 8 KB travel as several point-to-point pieces
         vis = parallel.simulate_sharded(compute_block, 6, 4, gather_to=0)
         if rank == 0:
             q.put(vis)

@@ -152,9 +152,9 @@ def test_sim_source_chunks_and_memory_knobs(gpu):
         fftvis_amd.simulate_vis(**dict(c2, source_buffer=1.5))
     with pytest.raises(ValueError, match="use_feed"):
         fftvis_amd.simulate_vis(**dict(c2, use_feed="z"))
-    with pytest.raises(ValueError, match="coord_mgr"):
+    with pytest.raises(ValueError, match="needs matvis / astropy"):
         fftvis_amd.simulate_vis(**dict(c2, coord_method="CoordinateRotationERFA"))
-    with pytest.raises(ValueError, match="unknown coord_method"):
+    with pytest.raises(ValueError, match="needs matvis / astropy|unknown coord_method"):
         fftvis_amd.simulate_vis(**dict(c2, coord_method="Nope"))
 
 
@@ -184,6 +184,23 @@ def test_sim_time_blocks_and_streamed_coord_mgr(gpu, monkeypatch):
     m = Mgr()
     got = fftvis_amd.simulate_vis(**dict(cfg, coord_method="CoordinateRotationERFA"), coord_mgr=m)
     assert m.rotated == list(range(7)) and rel_l2(got, ref) < 1e-12
+
+
+def test_reference_default_call_runs_end_to_end(gpu, monkeypatch):
+    """the call the reference makes -- ``simulate_vis(..., backend="gpu")`` with the default
+    ``coord_method="CoordinateRotationERFA"`` and no manager -- runs: the engine builds matvis' manager itself
+    (stubbed here: its vectors are the oracle's sidereal ones), calls ``setup()`` once, ``rotate`` once per time
+    in order, and the visibilities equal the run that applies the same rotation on the device."""
+    from tests.helpers import install_reference_dependency_stubs
+
+    made, _ = install_reference_dependency_stubs(monkeypatch)
+    cfg = synth.make_config("C2", nsrc=900, nfreq=5, ntimes=4)
+    ref = fftvis_amd.simulate_vis(**cfg)  # coord_method="SiderealRotation" (synthetic configs name it)
+    kw = {k: v for k, v in cfg.items() if k != "coord_method"}
+    got = fftvis_amd.simulate_vis(backend="gpu", min_chunks=2, **kw)
+    (m,) = made
+    assert m.setup_calls == 1 and m.rotated == list(range(4)) and m.kw["chunk_size"] == 450
+    assert rel_l2(got, ref) < 1e-12
 
 
 def test_type1_entry_buffers_hold_a_sky_that_is_all_up(gpu):
@@ -281,6 +298,30 @@ def test_sharded_run_two_ranks_on_the_gpu(gpu, tmp_path):
     assert z["vis"].shape == single.shape == (12, 6, 2, 2, 666)
     assert rel_l2(z["vis"], single) < 1e-12
     assert [tuple(b) for b in z["blocks"]] == [(0, 3, 0, 12), (3, 6, 0, 12)]
+
+
+def test_bench_gpus_n_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` started as ONE process spawns its two ranks itself (a child
+    torchrun; gloo rendezvous and both ranks on device 0 here, because a one-GPU box cannot host two RCCL ranks) and
+    prints a line with n_gpus = 2 and one per-rank time per rank; a rank count that differs from --gpus aborts."""
+    import json
+
+    env = dict(os.environ, PYTHONPATH=ROOT, FFTVIS_BENCH_BACKEND="gloo", FFTVIS_BENCH_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "5",
+           "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and len(res["config"]["per_rank_ms_per_step"]) == 2
+    assert res["config"]["finite_output"] and res["value"] > 0 and res["scaling"] == "strong"
+    bad = subprocess.run(cmd[:2] + ["--gpus", "2", "--workload", "C2", "--no-cpu-baseline"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
+                         timeout=300)
+    assert bad.returncode != 0 and "rank(s) joined" in bad.stderr + bad.stdout
 
 
 def test_hermitian_packing_matches_four_transforms(gpu, monkeypatch):
