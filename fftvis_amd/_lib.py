@@ -50,6 +50,7 @@ SYMBOLS = {
     "fv_sim_set_array_type1": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
     "fv_sim_set_nbeams": (c_int, [c_void_p, c_int]),
     "fv_sim_set_beam_airy": (c_int, [c_void_p, c_int, c_double]),
+    "fv_sim_set_beam_airy_scaled": (c_int, [c_void_p, c_int, c_double, c_void_p, c_double]),
     "fv_sim_set_beam_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int]),
     "fv_sim_set_beam_pairs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),

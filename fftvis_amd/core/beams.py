@@ -112,10 +112,28 @@ def feed_index(use_feed: str, feed_array=None) -> int:
     return 0 if key == "x" else 1
 
 
-# Analytic third-party beams are sampled onto a regular grid of the visible hemisphere and then
-# interpolated on the device like any table: cubic B-spline on 0.5-degree nodes follows a 14 m dish at
-# 250 MHz (pattern scale ~1.6 degrees) to ~1e-5 of its peak; order 1 needs the finer grid for ~2e-3.
-SAMPLED_NODES = {3: (181, 720), 1: (361, 1440)}
+# Analytic third-party beams (objects with pyuvdata's ``compute_response``).  The reference evaluates them
+# exactly at every source (cpu/beams.py:69-81); here they reach the device in one of two checked ways:
+#  * closed form: an object with a ``diameter`` whose response at a set of probes equals THIS package's
+#    Airy form 2 J1(x)/x times one complex factor per Jones slot to 1e-12 of the peak
+#    (``fit_airy_closed_form``; pyuvdata's AiryBeam: 1/sqrt(2) in every slot) is evaluated in closed form
+#    with those factors (fv_sim_set_beam_airy_scaled) -- probe and verify, never assumed;
+#  * table: anything else is sampled through its own ``compute_response`` onto a regular (za, az) grid of
+#    the visible hemisphere and interpolated on the device (cubic B-spline).  The node spacing is not
+#    assumed either: ``sample_response`` measures the interpolation error of the table it has built against
+#    ``compute_response`` at the points between the nodes (lowest and highest frequency) and halves the
+#    spacing of the axis that misses the tolerance until it is met or the table would pass
+#    FFTVIS_HIP_BEAM_TABLE_BYTES (default 2 GiB), in which case it raises.  An azimuth-independent response
+#    (probed) is stored on 8 azimuth nodes instead of 720.
+SAMPLED_START = {3: (181, 720), 1: (361, 1440)}  # first level: 0.5-degree (cubic) / 0.25-degree (linear) nodes
+SAMPLED_AZ_SYMMETRIC_NODES = 8
+CLOSED_FORM_TOL = 1e-12
+
+
+def _table_bytes_limit() -> float:
+    import os
+
+    return float(os.environ.get("FFTVIS_HIP_BEAM_TABLE_BYTES", 2 * 2**30))
 
 
 def _response_object(beam):
@@ -146,32 +164,173 @@ def response_at(beam, polarized: bool, freq: float, az, za, use_feed: str = "x")
     return (np.abs(r[:, k]) ** 2).sum(axis=0)  # power of one feed = sum over the vector axes of |E|^2
 
 
-def sample_response(beam, polarized: bool, freqs, use_feed: str = "x", order: int = 3):
-    """(nfreq, 2, 2, nza, naz) complex Jones or (nfreq, nza, naz) power table of an object that has
-    pyuvdata's ``compute_response(az_array=, za_array=, freq_array=)`` (analytic beams,
-    ``BeamInterface``), sampled for za in [0, pi/2] -- the engine only ever looks above the horizon
-    (reference cpu/beams.py:69-81 calls the same method per slice; sampling it once is the table
-    counterpart of wrapper.py:264-269's one-off frequency interpolation).  Returns (table, za_max)."""
-    nza, naz = SAMPLED_NODES[3 if order == 3 else 1]
-    za = np.linspace(0.0, 0.5 * np.pi, nza)
+def _interp_table(tab, za_max, az, za, order):
+    """Host twin of the device interpolant (fv_sim.h eval_jones / eval_power) for ONE (nza, naz) plane, used
+    only to measure a sampled table's error: az periodic, za mirrored at both ends, order 1 bilinear or
+    order 3 interpolating cubic B-spline (scipy's ``spline_filter1d`` makes the coefficients, as pyuvdata's
+    az_za_map_coordinates -> scipy.ndimage.map_coordinates does for the reference, cpu/beams.py:69-74)."""
+    nza, naz = tab.shape
+    fa = np.mod(az, 2 * np.pi) / (2 * np.pi / naz)
+    fz = np.clip(za / (za_max / (nza - 1)), 0, nza - 1)
+    ia = np.floor(fa).astype(int)
+    iz = np.minimum(np.floor(fz).astype(int), nza - 2)
+    ta, tz = fa - ia, fz - iz
+    if order == 1:
+        ia1 = (ia + 1) % naz
+        ia = ia % naz
+        return (tab[iz, ia] * (1 - tz) * (1 - ta) + tab[iz, ia1] * (1 - tz) * ta
+                + tab[iz + 1, ia] * tz * (1 - ta) + tab[iz + 1, ia1] * tz * ta)
+    from scipy.ndimage import spline_filter1d
+
+    def coefs(x):
+        return spline_filter1d(spline_filter1d(x, order=3, axis=0, mode="mirror"), order=3, axis=1, mode="grid-wrap")
+
+    c = coefs(tab.real) + 1j * coefs(tab.imag) if np.iscomplexobj(tab) else coefs(np.asarray(tab, float))
+
+    def bw(t):
+        return [(1 - t) ** 3 / 6, (4 - 6 * t**2 + 3 * t**3) / 6, (1 + 3 * t + 3 * t**2 - 3 * t**3) / 6, t**3 / 6]
+
+    wa, wz, per = bw(ta), bw(tz), 2 * (nza - 1)
+    out = 0
+    for k in range(4):
+        jz = np.mod(iz - 1 + k, per)
+        jz = np.where(jz < nza, jz, per - jz)
+        for m in range(4):
+            out = out + c[jz, np.mod(ia - 1 + m, naz)] * (wz[k] * wa[m])
+    return out
+
+
+SAMPLED_PAD = 24  # za nodes past the horizon: the spline's end condition (mirror) is wrong for a pattern with
+#                   a slope there, and its error decays by 2 - sqrt(3) per node: 24 nodes -> 2e-14
+
+
+def _sample_planes(beam, polarized, freqs, use_feed, nza, naz):
+    """Planes on ``nza`` nodes from the zenith to the horizon plus SAMPLED_PAD nodes beyond it (the object's own
+    response there; where that is not finite, the odd reflection 2 f(horizon) - f(mirror node)).
+    Returns (planes, za_max of the padded axis)."""
+    h = 0.5 * np.pi / (nza - 1)
+    za = h * np.arange(nza + SAMPLED_PAD)
     az = 2.0 * np.pi * np.arange(naz) / naz
     Z, A = np.meshgrid(za, az, indexing="ij")
-    shape = (2, 2, nza, naz) if polarized else (nza, naz)
-    out = [response_at(beam, polarized, f, A, Z, use_feed).reshape(shape)
-           for f in np.atleast_1d(np.asarray(freqs, dtype=float))]
-    return np.stack(out), 0.5 * np.pi
+    shape = (2, 2, nza + SAMPLED_PAD, naz) if polarized else (nza + SAMPLED_PAD, naz)
+    out = np.stack([np.asarray(response_at(beam, polarized, f, A, Z, use_feed)).reshape(shape) for f in freqs])
+    if not np.all(np.isfinite(out[..., nza:, :])):
+        k = np.arange(1, SAMPLED_PAD + 1)
+        out[..., nza - 1 + k, :] = 2 * out[..., nza - 1:nza, :] - out[..., nza - 1 - k, :]
+    return out, float(za[-1])
 
 
-def describe_beam(beam, polarized: bool, freqs, use_feed: str = "x", order: int = 1):
-    """-> ("airy", diameter) or ("table", table ndarray, za_max) ready for the C ABI.
+def _table_error(beam, polarized, freqs2, tab2, za_max, use_feed, order, axis, rng):
+    """Largest |table interpolant - compute_response| / peak over probes BETWEEN the nodes of ``axis``
+    (0: za, 1: az; the other coordinate sits on nodes, so that the two axes are measured separately), at
+    the frequencies ``freqs2`` the planes ``tab2`` were sampled at."""
+    nzp, naz = tab2.shape[-2:]
+    nza = nzp - SAMPLED_PAD  # nodes from the zenith to the horizon: the part the engine reads
+    n = 512
+    iz = np.concatenate([[0, 1, nza - 3, nza - 2], rng.integers(0, nza - 1, n)])  # both ends always
+    ia = rng.integers(0, naz, iz.size)
+    za = (iz + (0.5 if axis == 0 else 0.0)) * (0.5 * np.pi / (nza - 1))
+    az = (ia + (0.5 if axis == 1 else 0.0)) * (2 * np.pi / naz)
+    err, peak = 0.0, 0.0
+    for f, plane in zip(freqs2, tab2):
+        want = response_at(beam, polarized, f, az, za, use_feed)
+        planes = plane.reshape(-1, nzp, naz)
+        got = np.stack([_interp_table(pl, za_max, az, za, order) for pl in planes]).reshape(np.shape(want))
+        err = max(err, float(np.max(np.abs(got - want))))
+        peak = max(peak, float(np.max(np.abs(plane[..., :nza, :]))))
+    return err / peak if peak > 0 else 0.0
+
+
+def sample_response(beam, polarized: bool, freqs, use_feed: str = "x", order: int = 3, tol: float = 1e-7):
+    """(nfreq, 2, 2, nza, naz) complex Jones or (nfreq, nza, naz) power table of an object that has
+    pyuvdata's ``compute_response(az_array=, za_array=, freq_array=)`` (analytic beams,
+    ``BeamInterface``), sampled from the zenith to just past the horizon -- the engine only ever looks above it
+    (reference cpu/beams.py:69-81 calls the same method per slice; sampling it once is the table
+    counterpart of wrapper.py:264-269's one-off frequency interpolation).  The node spacing is refined
+    until the device interpolant reproduces ``compute_response`` between the nodes to ``tol`` of the peak
+    (measured, see the note above SAMPLED_START); raises ValueError when no table within the byte limit does.
+    Returns (table, za_max)."""
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=float))
+    order = 3 if order == 3 else 1
+    nza, naz = SAMPLED_START[order]
+    rng = np.random.default_rng(0)
+    f2 = np.unique([freqs.min(), freqs.max()])
+    # azimuth-independent response?  (probed at the top frequency on a coarse (za, az) lattice)
+    pz = np.repeat(np.linspace(0.02, 0.5 * np.pi - 0.02, 16), 8)
+    pa = np.tile(2 * np.pi * (np.arange(8) + 0.37) / 8, 16)
+    pr = np.asarray(response_at(beam, polarized, f2[-1], pa, pz, use_feed))
+    pr = pr.reshape(pr.shape[:-1] + (16, 8))
+    if np.max(np.abs(pr - pr[..., :1])) <= 1e-13 * max(np.max(np.abs(pr)), 1e-300):
+        naz = SAMPLED_AZ_SYMMETRIC_NODES
+    cell = 64 if polarized else 8
+    last = None
+    while True:
+        if freqs.size * (nza + SAMPLED_PAD) * naz * cell > _table_bytes_limit():
+            raise ValueError(
+                f"beam {type(getattr(beam, 'beam', beam)).__name__}: no (za, az) table within "
+                f"{_table_bytes_limit() / 2**30:.1f} GiB interpolates compute_response to {tol:g} of its peak at "
+                f"order {order} (reached {last}); use beam_spline_opts order 3, a closed-form beam, or raise "
+                "FFTVIS_HIP_BEAM_TABLE_BYTES")
+        tab2, za_max = _sample_planes(beam, polarized, f2, use_feed, nza, naz)
+        ez = _table_error(beam, polarized, f2, tab2, za_max, use_feed, order, 0, rng)
+        ea = 0.0 if naz == SAMPLED_AZ_SYMMETRIC_NODES else _table_error(beam, polarized, f2, tab2, za_max, use_feed, order, 1, rng)
+        last = f"{max(ez, ea):.1e} with {nza} x {naz} nodes"
+        if ez <= tol and ea <= tol:
+            break
+        if ez > tol:
+            nza = 2 * (nza - 1) + 1
+        if ea > tol:
+            naz *= 2
+    if freqs.size == f2.size and np.array_equal(freqs, f2):
+        return tab2, za_max
+    return _sample_planes(beam, polarized, freqs, use_feed, nza, naz)
+
+
+def fit_airy_closed_form(beam, polarized: bool, freqs, use_feed: str = "x"):
+    """If the object has a ``diameter`` and its ``compute_response`` equals 2 J1(x)/x,
+    x = pi D nu sin(za)/c, times ONE complex factor per Jones slot (polarized) / one real factor on the
+    squared pattern (power) at every one of 72 probes (24 directions x lowest, middle, highest frequency)
+    to CLOSED_FORM_TOL of the peak: (diameter, jones_scale (2, 2) complex, power_scale).  Else None --
+    nothing is assumed about an object from its name."""
+    inner = getattr(beam, "beam", beam)
+    D = getattr(inner, "diameter", None)
+    if D is None or not np.isscalar(D) or not float(D) > 0:
+        return None
+    from scipy.special import j1
+
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=float))
+    rng = np.random.default_rng(1)
+    za = np.concatenate([[0.0, 1e-9], rng.uniform(0.0, 0.5 * np.pi, 22)])
+    az = rng.uniform(0.0, 2 * np.pi, za.size)
+    es, rs = [], []
+    for f in np.unique([freqs.min(), freqs[freqs.size // 2], freqs.max()]):
+        x = np.pi * float(D) * f * np.sin(za) / 299792458.0
+        es.append(np.where(x == 0.0, 1.0, 2.0 * j1(x) / np.where(x == 0.0, 1.0, x)))
+        rs.append(response_at(beam, polarized, f, az, za, use_feed))
+    e = np.concatenate(es)
+    r = np.concatenate(rs, axis=-1)
+    basis = e if polarized else e * e
+    scale = (r * basis).sum(axis=-1) / (basis * basis).sum()  # least squares, one factor per slot
+    peak = np.max(np.abs(r))
+    if not peak > 0 or np.max(np.abs(r - scale[..., None] * basis)) > CLOSED_FORM_TOL * peak:
+        return None
+    if polarized:
+        return float(D), np.asarray(scale, dtype=complex).reshape(2, 2), 1.0
+    return float(D), np.ones((2, 2), dtype=complex), float(np.real(scale))
+
+
+def describe_beam(beam, polarized: bool, freqs, use_feed: str = "x", order: int = 1, tol: float = 1e-7):
+    """-> ("airy", diameter[, jones_scale, power_scale]) or ("table", table ndarray, za_max) ready for the C ABI.
     ``freqs`` = the simulated frequencies (None: take the table's frequency axis as it is).
 
     Accepts this package's beams (``AiryBeam`` is evaluated in closed form, ``TabulatedBeam`` is
     uploaded) and duck-types pyuvdata's: a UVBeam-like object (``data_array`` (Naxes_vec, Nfeeds,
     Nfreqs, Nza, Naz), ``axis1_array`` = az, ``axis2_array`` = za, regular axes, az starting at 0),
     bare or inside a ``BeamInterface`` (``.beam``), becomes a table; any other object with a
-    ``compute_response`` method (pyuvdata's analytic beams) is SAMPLED through that method
-    (``sample_response``) -- the engine follows the object, it never substitutes a formula of its own.
+    ``compute_response`` method (pyuvdata's analytic beams) is probed through that method: it runs in
+    closed form only if the probes prove it is this package's Airy form up to constant factors
+    (``fit_airy_closed_form``), else it is SAMPLED through the method (``sample_response``, spacing refined
+    to ``tol``) -- the engine follows the object, it never substitutes a formula on the strength of a name.
     Unpolarized runs take the power of feed ``use_feed`` of an E-field beam (reference
     wrapper.py:278-279).
     """
@@ -218,12 +377,30 @@ def describe_beam(beam, polarized: bool, freqs, use_feed: str = "x", order: int 
     if callable(getattr(beam, "compute_response", None)) or callable(getattr(inner, "compute_response", None)):
         if freqs is None:
             raise ValueError("sampling an analytic beam needs the simulated frequencies")
-        tab, za_max = sample_response(beam, polarized, freqs, use_feed, order)
+        fit = fit_airy_closed_form(beam, polarized, freqs, use_feed)
+        if fit is not None:  # verified at the probes: this package's Airy form times the fitted factors
+            return ("airy",) + fit
+        tab, za_max = sample_response(beam, polarized, freqs, use_feed, order, tol)
         return describe_beam(TabulatedBeam(tab, freqs, za_max), polarized, freqs)
     raise NotImplementedError(
         f"beam of type {type(inner).__name__} cannot be placed on the GPU: pass an AiryBeam, a "
         "TabulatedBeam, an az/za UVBeam or an object with pyuvdata's compute_response"
     )
+
+
+def table_tolerance(eps: float) -> float:
+    """Interpolation error (relative to the beam's peak) a sampled analytic beam's table is refined to: the
+    run's NUFFT tolerance, kept between 1e-9 (a cubic table much finer than that is no longer small) and
+    1e-5."""
+    return float(min(1e-5, max(1e-9, eps)))
+
+
+def airy_factors(desc) -> np.ndarray:
+    """The 9 float64 of fv_sim_set_beam_airy_scaled / fv_beam_eval(kind 0): Jones factors (re, im) x 4, power
+    factor -- all ones for this package's own AiryBeam."""
+    js = np.ones((2, 2), dtype=complex) if len(desc) < 4 else np.asarray(desc[2], dtype=complex)
+    ps = 1.0 if len(desc) < 4 else float(desc[3])
+    return np.ascontiguousarray(np.concatenate([js.reshape(4).view(float), [ps]]))
 
 
 def is_sampled_analytic(beam) -> bool:

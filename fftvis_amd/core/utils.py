@@ -212,6 +212,10 @@ def get_desired_chunks(freemem: int, min_chunks: int, beam_list, nax: int, nfeed
         data = getattr(inner, "data_array", getattr(inner, "data", None))
         if data is not None:
             nbeampix += int(np.shape(data)[-2]) * int(np.shape(data)[-1])
+        elif callable(getattr(beam, "compute_response", None)) or callable(getattr(inner, "compute_response", None)):
+            # third-party analytic beam: if it is not proven closed-form it becomes a sampled table of at least
+            # the first refinement level (core/beams.py SAMPLED_START, order 3)
+            nbeampix += 205 * 720
     need = get_required_chunks(freemem, nax, nfeed, nant, nsrc, len(beam_list), nbeampix, precision,
                                source_buffer, nfreq=nfreq)
     nchunks = max(1, min(max(int(min_chunks), need), max(int(nsrc), 1)))

@@ -5,6 +5,7 @@
 #include "fv_sim.h"
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 namespace fv {
@@ -58,6 +59,8 @@ template <typename T>
 struct NufftWorkspace {
     int device = -1, dim = 0;
     double eps = 0, sigma = 0;
+    uint64_t id = 0;  // unique over the life of the process: a thread's slot is (pointer, id), so a workspace that
+                      // another thread freed and a NEW one that happens to sit at the same address never compare equal
     hipStream_t st = nullptr;
     DevBuf dx[3], ds[3], dc, dout, dscale;
     std::unique_ptr<Nufft3<T>> plan;
@@ -70,6 +73,15 @@ template <typename T>
 static NufftWorkspace<T> *&workspace_slot() {
     static thread_local NufftWorkspace<T> *ws = nullptr;
     return ws;
+}
+template <typename T>
+static uint64_t &workspace_slot_id() {
+    static thread_local uint64_t id = 0;
+    return id;
+}
+static uint64_t next_workspace_id() {
+    static std::atomic<uint64_t> n{0};
+    return ++n;
 }
 // Every live workspace, whichever thread made it, so that fv_release_workspaces() can free those of
 // threads that have exited (their thread_local pointer died with them, the device memory did not).
@@ -93,9 +105,17 @@ struct WorkspaceRegistry {
         all.erase(it);
         return true;
     }
-    bool contains(NufftWorkspace<T> *w) {
+    bool contains(NufftWorkspace<T> *w, uint64_t id) {  // registered AND the same object the slot was made for
         std::lock_guard<std::mutex> g(mu);
-        return std::find(all.begin(), all.end(), w) != all.end();
+        auto it = std::find(all.begin(), all.end(), w);
+        return it != all.end() && (*it)->id == id;
+    }
+    bool remove(NufftWorkspace<T> *w, uint64_t id) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = std::find(all.begin(), all.end(), w);
+        if (it == all.end() || (*it)->id != id) return false;
+        all.erase(it);
+        return true;
     }
     void drain() {
         std::vector<NufftWorkspace<T> *> take;
@@ -117,7 +137,7 @@ template <typename T>
 static void drop_workspace() {
     NufftWorkspace<T> *&ws = workspace_slot<T>();
     if (ws) {
-        if (WorkspaceRegistry<T>::get().remove(ws)) {  // else another thread's fv_release_workspaces() freed it
+        if (WorkspaceRegistry<T>::get().remove(ws, workspace_slot_id<T>())) {  // else another thread's fv_release_workspaces() freed it
             (void)hipSetDevice(ws->device);
             delete ws;
         }
@@ -142,7 +162,7 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
         return;
     }
     NufftWorkspace<T> *&slot = workspace_slot<T>();
-    if (slot && !WorkspaceRegistry<T>::get().contains(slot)) slot = nullptr;  // freed by another thread's release
+    if (slot && !WorkspaceRegistry<T>::get().contains(slot, workspace_slot_id<T>())) slot = nullptr;  // freed by another thread's release
     if (slot && (slot->device != device || slot->dim != dim || slot->eps != eps || slot->sigma != upsampfac))
         drop_workspace<T>();
     if (!slot) {
@@ -151,6 +171,7 @@ static void nufft3_host(int device, int dim, int64_t M, const void *const xin[3]
         slot->dim = dim;
         slot->eps = eps;
         slot->sigma = upsampfac;
+        slot->id = workspace_slot_id<T>() = next_workspace_id();
         FV_HIP(hipStreamCreateWithFlags(&slot->st, hipStreamNonBlocking));
         WorkspaceRegistry<T>::get().add(slot);
     }
@@ -233,6 +254,13 @@ static void beam_eval_host(int device, int polarized, int kind, double diameter,
     BeamDesc b{};
     b.kind = kind;
     b.diameter = diameter;
+    for (int i = 0; i < 8; ++i) b.js[i] = i % 2 ? 0.0 : 1.0;
+    b.ps = 1.0;
+    if (kind == 0 && table) {  // Airy with factors: 8 doubles (Jones slots, re / im) + the power factor
+        const double *f = static_cast<const double *>(table);
+        for (int i = 0; i < 8; ++i) b.js[i] = f[i];
+        b.ps = f[8];
+    }
     if (kind == 1) {
         FV_REQUIRE(table && nza >= 2 && naz >= 1 && nft >= 1 && za_max > 0, "bad beam table");
         FV_REQUIRE(nft == 1 || (fidx >= 0 && fidx < nft), "freq_index outside the beam table");
@@ -476,7 +504,12 @@ int fv_sim_set_nbeams(fv_sim *h, int nbeams) {
     FV_SIM_CALL(FV_REQUIRE(nbeams >= 1, "need at least one beam"); h->impl->set_nbeams(nbeams));
 }
 int fv_sim_set_beam_airy(fv_sim *h, int beam, double diameter) {
-    FV_SIM_CALL(FV_REQUIRE(diameter > 0, "diameter must be positive"); h->impl->set_beam_airy(beam, diameter));
+    FV_SIM_CALL(FV_REQUIRE(diameter > 0, "diameter must be positive"); h->impl->set_beam_airy(beam, diameter, nullptr, 1.0));
+}
+int fv_sim_set_beam_airy_scaled(fv_sim *h, int beam, double diameter, const double *jones_scale, double power_scale) {
+    FV_SIM_CALL(FV_REQUIRE(diameter > 0, "diameter must be positive");
+                FV_REQUIRE(power_scale == power_scale, "NaN power factor");
+                h->impl->set_beam_airy(beam, diameter, jones_scale, power_scale));
 }
 int fv_sim_set_beam_table(fv_sim *h, int beam, int nfreq_tab, int nza, int naz, double za_max,
                           const void *table, int order) {

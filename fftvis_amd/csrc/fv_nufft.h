@@ -2651,6 +2651,9 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
         a.xc[i] = g.xc;
         bt[i] = bts[map[i]];
     }
+    // the gather addresses a footprint's rows with 32-bit element offsets inside one (x, y) slab of a transform
+    FV_REQUIRE((int64_t)a.P[0] * a.cnt[0] * a.P[1] * a.cnt[1] < ((int64_t)1 << 31),
+               "transform output slab of 2^31 elements or more: beyond the gather's 32-bit row offsets");
     a.out_fg_stride = out_fg_stride;
     a.out_k_stride = out_k_stride;
     for (int r = 0; r < 16; ++r) a.out_pol_off[r] = out_pol_off ? out_pol_off[r] : 0;

@@ -20,6 +20,8 @@ constexpr double SPEED_OF_LIGHT = 299792458.0;  // core/utils.py:9
 struct BeamDesc {
     int kind;            // 0 Airy, 1 table
     double diameter;     // Airy
+    double js[8];        // Airy: complex factor per Jones slot A[ax][feed] = js . 2 J1(x)/x  (re, im pairs)
+    double ps;           // Airy: factor of the power beam, ps . (2 J1(x)/x)^2
     const void *table;   // device
     int nfreq_tab, nza, naz;
     double za_max;
@@ -259,7 +261,7 @@ __device__ inline void eval_jones(const BeamDesc &b, int fidx, double freq, doub
                                   cplx<double> A[4]) {
     if (b.kind == 0) {
         const double e = airy_efield(b.diameter, freq, za);
-        for (int i = 0; i < 4; ++i) A[i] = {e, 0.0};
+        for (int i = 0; i < 4; ++i) A[i] = {e * b.js[2 * i], e * b.js[2 * i + 1]};
         return;
     }
     const int ft = b.nfreq_tab > 1 ? fidx : 0;
@@ -300,7 +302,7 @@ template <int ORD>
 __device__ inline double eval_power(const BeamDesc &b, int fidx, double freq, double az, double za) {
     if (b.kind == 0) {
         const double e = airy_efield(b.diameter, freq, za);
-        return e * e;
+        return e * e * b.ps;
     }
     const int ft = b.nfreq_tab > 1 ? fidx : 0;
     const double *p = (const double *)b.table + (int64_t)ft * b.nza * b.naz;
@@ -842,7 +844,7 @@ struct SimBase {
     virtual void set_array(const double *R, int64_t nbls, const double *bls, int coplanar) = 0;
     virtual void set_array_type1(const double *basis, int64_t nbls, const int *bls_int, int n_modes) = 0;
     virtual void set_nbeams(int n) = 0;
-    virtual void set_beam_airy(int b, double diameter) = 0;
+    virtual void set_beam_airy(int b, double diameter, const double *jones_scale, double power_scale) = 0;
     virtual void set_beam_table(int b, int nfreq_tab, int nza, int naz, double za_max,
                                 const void *table, int order) = 0;
     virtual void set_beam_pairs(int npairs, const int *bi, const int *bj, const int64_t *off,
@@ -891,6 +893,7 @@ class Sim : public SimBase {
     struct Beam {
         int kind = -1;
         double diameter = 0;
+        double js[8] = {1, 0, 1, 0, 1, 0, 1, 0}, ps = 1;  // Airy: Jones-slot factors, power factor
         int nfreq_tab = 0, nza = 0, naz = 0;
         double za_max = 0;
         std::unique_ptr<DevBuf> table;
@@ -1131,11 +1134,18 @@ class Sim : public SimBase {
         beams.clear();
         beams.resize(n);
     }
-    void set_beam_airy(int b, double diameter) override {
+    void set_beam_airy(int b, double diameter, const double *jones_scale, double power_scale) override {
         FV_REQUIRE(b >= 0 && b < (int)beams.size(), "beam index out of range");
-        beams[b].kind = 0;
-        beams[b].real_valued = true;
-        beams[b].diameter = diameter;
+        Beam &bm = beams[b];
+        bm.kind = 0;
+        bm.diameter = diameter;
+        bm.ps = power_scale;
+        bm.real_valued = true;
+        for (int i = 0; i < 8; ++i) {
+            bm.js[i] = jones_scale ? jones_scale[i] : (i % 2 ? 0.0 : 1.0);
+            FV_REQUIRE(bm.js[i] == bm.js[i], "NaN in the Airy Jones factors");
+            if (i % 2 && bm.js[i] != 0.0) bm.real_valued = false;
+        }
     }
     void set_beam_table(int b, int nft, int nza, int naz, double za_max, const void *table,
                         int order) override {
@@ -1366,7 +1376,7 @@ class Sim : public SimBase {
             Lr.d_blockcnt.reserve(sizeof(int) * (nblk + 1));
             Lr.d_blockoff.reserve(sizeof(int) * (nblk + 1));
         }
-        d_mhist.reserve(sizeof(int) * rots.size() * std::max(1, src_chunks));
+        reserve_mhist(sizeof(int) * rots.size() * std::max(1, src_chunks));
         // frequencies per batch: bounded by entries (~1.3 per (source, freq)) and by grid bytes
         const char *eb = std::getenv("FFTVIS_HIP_GRID_BYTES");
         const double budget = eb ? std::atof(eb) : 8.0 * 1024 * 1024 * 1024;
@@ -1617,7 +1627,7 @@ class Sim : public SimBase {
         }
         // Baselines not covered by any pair stay zero (reference zero-initialises, :909-911).
         FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
-        d_mhist.reserve(sizeof(int) * rots.size() * std::max(1, src_chunks));
+        reserve_mhist(sizeof(int) * rots.size() * std::max(1, src_chunks));
 
         double xc[3], X[3];
         source_box(xc, X);
@@ -2002,6 +2012,8 @@ class Sim : public SimBase {
         BeamDesc d{};
         d.kind = bm.kind;
         d.diameter = bm.diameter;
+        for (int i = 0; i < 8; ++i) d.js[i] = bm.js[i];
+        d.ps = bm.ps;
         d.table = bm.table ? bm.table->p : nullptr;
         d.nfreq_tab = bm.nfreq_tab;
         d.nza = bm.nza;
@@ -2034,8 +2046,13 @@ class Sim : public SimBase {
         if (timing_level) ev_collect();
         check_errors();
     }
-    void stats(double *v, int n) override {
-        // above-horizon counts were left on the device during run(); fold them in now
+    void reserve_mhist(size_t bytes) {
+        // growing the buffer frees the counts earlier device-output runs left in it for stats(): fold them first
+        if (bytes > d_mhist.cap) fold_mhist();
+        d_mhist.reserve(bytes);
+    }
+    void fold_mhist() {
+        // above-horizon counts were left on the device during run(); fold them into the statistics
         if (!mhist_log.empty()) {
             FV_HIP(hipSetDevice(device));
             std::vector<int> mh(d_mhist.cap / sizeof(int));
@@ -2049,6 +2066,9 @@ class Sim : public SimBase {
             }
             mhist_log.clear();
         }
+    }
+    void stats(double *v, int n) override {
+        fold_mhist();
         for (int i = 0; i < n && i < 12; ++i) v[i] = st[i];
     }
     void reset_stats() override {

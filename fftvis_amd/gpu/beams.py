@@ -8,7 +8,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import _lib
-from ..core.beams import BeamEvaluator, checked_spline_order, describe_beam, is_sampled_analytic
+from ..core.beams import BeamEvaluator, airy_factors, checked_spline_order, describe_beam, is_sampled_analytic
 from ..core.utils import prepare_beam_evaluation as _prepare_beam_evaluation
 
 
@@ -52,8 +52,10 @@ class GPUBeamEvaluator(BeamEvaluator):
         az = np.ascontiguousarray(az, dtype=rdt)
         za = np.ascontiguousarray(za, dtype=rdt)
         n = az.size
-        if is_sampled_analytic(beam):  # third-party analytic beam: a one-frequency table of its own response
-            desc = describe_beam(beam, polarized, np.atleast_1d(float(freq)), order=3)
+        if is_sampled_analytic(beam):  # third-party analytic beam: closed form if its own response proves it is
+            # this package's Airy form x constant factors, else a one-frequency table of its own response
+            desc = describe_beam(beam, polarized, np.atleast_1d(float(freq)), order=3,
+                                 tol=1e-5 if prec == 1 else 1e-9)
             order, freq_index = 3, 0
         else:
             desc = describe_beam(beam, polarized, None)
@@ -61,7 +63,8 @@ class GPUBeamEvaluator(BeamEvaluator):
         L = _lib.lib()
         _lib.require_gpu()
         if desc[0] == "airy":
-            st = L.fv_beam_eval(self.device, prec, int(polarized), 0, desc[1], 0, 0, 0, 0.0, None,
+            fac = airy_factors(desc)
+            st = L.fv_beam_eval(self.device, prec, int(polarized), 0, desc[1], 0, 0, 0, 0.0, _lib.ptr(fac),
                                 1, 0, float(freq), n, _lib.ptr(az), _lib.ptr(za), _lib.ptr(out))
         else:
             tab = desc[1]

@@ -21,7 +21,8 @@ import numpy as np
 from .. import _lib
 from ..core import utils
 from ..core.antenna_gridding import check_antpos_griddability
-from ..core.beams import checked_spline_order, describe_beam, feed_index, is_sampled_analytic
+from ..core.beams import (airy_factors, checked_spline_order, describe_beam, feed_index, is_sampled_analytic,
+                          table_tolerance)
 from ..core.coords import SiderealRotation, eq_unit_vectors, julian_dates
 from ..core.simulate import SimulationEngine, default_accuracy_dict
 
@@ -77,6 +78,7 @@ class SimHandle:
         self._L = _lib.lib()
         _lib.require_gpu()
         self.precision = precision
+        self.eps = float(eps)
         self.polarized = bool(polarized)
         self.rdt = np.float32 if precision == 1 else np.float64
         self.cdt = np.complex64 if precision == 1 else np.complex128
@@ -135,11 +137,13 @@ class SimHandle:
     def set_beams(self, beam_list, freqs, order: int = 1, use_feed: str = "x"):
         _lib.check(self._L.fv_sim_set_nbeams(self._h, len(beam_list)))
         if beam_list and all(is_sampled_analytic(b) for b in beam_list):
-            order = 3  # only sampled analytic beams: their tables are ours to lay out (cubic, 0.5-degree nodes)
+            order = 3  # only third-party analytic beams: their tables (if any) are ours to lay out -- cubic
         for i, beam in enumerate(beam_list):
-            d = describe_beam(beam, self.polarized, np.asarray(freqs, dtype=float), use_feed, order)
-            if d[0] == "airy":
-                _lib.check(self._L.fv_sim_set_beam_airy(self._h, i, d[1]))
+            d = describe_beam(beam, self.polarized, np.asarray(freqs, dtype=float), use_feed, order,
+                              table_tolerance(self.eps))
+            if d[0] == "airy":  # this package's AiryBeam, or a third-party object PROVEN to be that form x factors
+                fac = airy_factors(d)
+                _lib.check(self._L.fv_sim_set_beam_airy_scaled(self._h, i, d[1], _lib.ptr(fac), float(fac[8])))
             else:
                 tab = d[1]
                 _lib.check(self._L.fv_sim_set_beam_table(self._h, i, tab.shape[0], tab.shape[-2],

@@ -65,7 +65,8 @@ int fv_nudft3_direct(int device, int precision, int dim, int64_t M, const void *
  *
  * fv_beam_eval: GPUBeamEvaluator.evaluate_beam (src/fftvis/gpu/beams.py:18-66; CPU twin
  * cpu/beams.py:12-89).  kind/diameter/table as in fv_sim_set_beam_*; out is (2,2,n) complex
- * [ax][feed][src] when polarized, else (n) complex power.
+ * [ax][feed][src] when polarized, else (n) complex power.  For kind 0 a non-NULL `table` holds 9
+ * float64: the four complex Jones factors and the power factor of fv_sim_set_beam_airy_scaled.
  * fv_apparent_coherency: GPUBeamEvaluator.get_apparent_flux_polarized (gpu/beams.py:68-88) and
  * its CPU siblings (cpu/beams.py:129-246, cpu_simulate.py:183-187); variant 0..4:
  *   0 (A^H A) I   1 A^H C A   2 Ai^H Aj I   3 Ai^H C Aj   4 sqrt(Bi Bj) I (1-D arrays).
@@ -146,6 +147,14 @@ int fv_sim_set_array_type1(fv_sim *h, const double *basis_matrix, int64_t nbls, 
  * One order per handle.                                                                       */
 int fv_sim_set_nbeams(fv_sim *h, int nbeams);
 int fv_sim_set_beam_airy(fv_sim *h, int beam, double diameter);
+/* The same dish with a complex factor per Jones slot, A[ax][feed] = jones_scale[ax][feed] 2 J1(x)/x
+ * (jones_scale: 4 complex128 = 8 float64, row-major [ax][feed]; NULL = all ones), and a real factor on
+ * the power beam, power_scale (2 J1(x)/x)^2.  How a third-party analytic Airy object is put on the device
+ * in closed form: the host probes the object's own compute_response (cpu/beams.py:69-81 calls it per
+ * slice), fits these factors and uses this entry only when every probe agrees to 1e-12 (e.g. pyuvdata's
+ * AiryBeam: 1/sqrt(2) in every slot); otherwise the object is sampled onto a table.               */
+int fv_sim_set_beam_airy_scaled(fv_sim *h, int beam, double diameter, const double *jones_scale,
+                                double power_scale);
 int fv_sim_set_beam_table(fv_sim *h, int beam, int nfreq_tab, int nza, int naz, double za_max,
                           const void *table, int order);
 

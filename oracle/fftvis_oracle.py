@@ -489,6 +489,46 @@ class TabulatedBeam:
         return v[:, :, None, :].astype(complex)
 
 
+class UnpolarizedPowerBeam:
+    """What ``prepare_beam_unpolarized(beam, use_feed=...)`` hands the reference's engine for an unpolarized
+    run (wrapper.py:278-279; the function is matvis', the conversion pyuvdata's ``efield_to_power`` without
+    cross-pols [MEM]): a single-polarisation POWER beam.  A power beam with one polarisation passes through;
+    an E-field beam becomes  P_f(az, za) = sum over the vector axes of |E[ax, f]|^2  for the one feed
+    f = use_feed ("x" -> feed 0 / the entry named x or e in ``feed_array``, "y" -> 1 / y or n), returned in
+    compute_response's shape (1, 1, Nfreqs, Npts), which evaluate_beam then indexes [0, 0, 0, :]
+    (cpu/beams.py:78-81)."""
+
+    beam_type = "power"
+
+    def __init__(self, beam, use_feed="x"):
+        self.beam = beam
+        names = [str(f).lower() for f in np.ravel(getattr(beam, "feed_array", ["x", "y"]))]
+        alias = {"x": ("x", "e"), "y": ("y", "n")}[str(use_feed).lower()]
+        hit = [names.index(a) for a in alias if a in names]
+        if not hit:
+            raise ValueError(f"beam has no feed {use_feed!r}")
+        self.feed = hit[0]
+
+    def compute_response(self, az_array, za_array, freq_array, **kw):
+        r = np.asarray(self.beam.compute_response(az_array=az_array, za_array=za_array, freq_array=freq_array, **kw))
+        if str(getattr(self.beam, "beam_type", "efield")).lower() == "power":
+            return r[:1, :1] if r.shape[1] == 1 else r[:1, self.feed:self.feed + 1]
+        k = 0 if r.shape[1] == 1 else self.feed
+        return (np.abs(r[:, k]) ** 2).sum(axis=0)[None, None].astype(complex)
+
+
+def prepare_beam_unpolarized(beam, use_feed="x"):
+    """A tabulated (UVBeam-like) beam is converted AT ITS NODES -- pyuvdata's efield_to_power works on the
+    data array, and the power table is what gets interpolated afterwards -- an analytic one point by point."""
+    if isinstance(beam, TabulatedBeam):
+        if beam.beam_type == "power":
+            return beam
+        feed = {"x": 0, "y": 1}[str(use_feed).lower()]
+        power = (np.abs(beam.data[:, :, feed]) ** 2).sum(axis=1)  # (nfreq, nza, naz)
+        return TabulatedBeam(power, beam.freqs, beam.za_max, "power", beam.order)
+    return UnpolarizedPowerBeam(beam, use_feed)
+
+
 def evaluate_beam(beam, az, za, polarized, freq):
     """CPUBeamEvaluator.evaluate_beam (cpu/beams.py:12-89)."""
     r = beam.compute_response(az_array=az, za_array=za, freq_array=np.atleast_1d(freq))

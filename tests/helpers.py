@@ -12,18 +12,26 @@ def rel_l2(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / (nb if nb else 1.0)
 
 
-def oracle_beam(beam, polarized, freqs, order=1):
+def oracle_beam(beam, polarized, freqs, order=1, use_feed="x"):
+    """The oracle's twin of a product beam.  Unpolarized runs go through the ORACLE's own restatement of
+    ``prepare_beam_unpolarized`` (E-field -> power of one feed), never through the product's reduction; objects
+    that are neither of this package's containers (third-party analytic beams) are handed over as they are: the
+    oracle calls their ``compute_response`` at every source, as the reference does (cpu/beams.py:69-81)."""
     if isinstance(beam, fftvis_amd.AiryBeam):
+        # this package's dish is DEFINED with both types (E-field e in every slot, power e^2): no reduction involved
         return orc.AiryBeam(beam.diameter, "efield" if polarized else "power")
-    tb = beam if polarized else beam.power_from_efield()
-    return orc.TabulatedBeam(tb.data, freqs, tb.za_max, "efield" if polarized else "power", order)
+    elif isinstance(beam, fftvis_amd.TabulatedBeam):
+        ob = orc.TabulatedBeam(beam.data, freqs, beam.za_max, "efield" if beam.is_efield else "power", order)
+    else:
+        ob = beam
+    return ob if polarized else orc.prepare_beam_unpolarized(ob, use_feed)
 
 
 def oracle_simulate(cfg):
     """Run the oracle on simulate_vis-style keyword arguments."""
     beams = cfg["beam"] if isinstance(cfg["beam"], list) else [cfg["beam"]]
     order = spline_order(cfg.get("beam_spline_opts"))
-    ob = [oracle_beam(b, cfg["polarized"], cfg["freqs"], order) for b in beams]
+    ob = [oracle_beam(b, cfg["polarized"], cfg["freqs"], order, cfg.get("use_feed", "x")) for b in beams]
     return orc.simulate(
         cfg["ants"], cfg["freqs"], cfg["fluxes"], ob, cfg["ra"], cfg["dec"], cfg["times"],
         cfg["telescope_loc"], baselines=cfg.get("baselines"), beam_idx=cfg.get("beam_idx"),

@@ -907,3 +907,37 @@ def test_sim_c3_geometry_subset_and_paths(gpu):
     v12 = fftvis_amd.simulate_vis(**dict(cfg, fluxes=cfg["fluxes"] - 2.0 * fl2))
     v2 = fftvis_amd.simulate_vis(**dict(cfg, fluxes=fl2))
     assert rel_l2(v12, v3 - 2.0 * v2) < 1e-10
+
+
+def test_third_party_analytic_beams_closed_form_and_sampled(gpu, monkeypatch):
+    """VERDICT r2 next #8 / weak #11, ADVICE r2 (medium): objects with pyuvdata's ``compute_response``.  (a) One
+    whose own response is the Airy form times constants (pyuvdata's AiryBeam: 1/sqrt(2) per slot; here also
+    unequal slots) runs in closed form with the fitted factors; (b) one that is not (Gaussian x dipole terms,
+    with a ``diameter`` attribute and an Airy-sounding name) is sampled and its table refined to the run's
+    tolerance.  The oracle calls ``compute_response`` at every source and frequency, as the reference does
+    (cpu/beams.py:69-81): engine vs oracle to the NUFFT tolerance, polarized and unpolarized (both feeds), and
+    the stand-alone evaluator to 1e-7 of the peak."""
+    from tests.test_host_logic import AiryBeamLookalike, _StubAnalyticBeam
+
+    cfg = synth.make_config("C1", nsrc=400, nfreq=3, ntimes=2)
+    cfg["freqs"] = np.array([110e6, 170e6, 240e6])
+    cfg["ra"], cfg["dec"], cfg["fluxes"] = synth.catalog(400, cfg["freqs"], 5)
+    ev = fftvis_amd.create_beam_evaluator("gpu")
+    rng = np.random.default_rng(8)
+    az, za = rng.uniform(0, 2 * np.pi, 3000), rng.uniform(0, np.pi / 2, 3000)
+    for beam in (_StubAnalyticBeam(14.0), AiryBeamLookalike(14.0)):
+        for pol in (True, False):
+            for feed in ("x", "y") if not pol else ("x",):
+                c = dict(cfg, beam=beam, polarized=pol, use_feed=feed, eps=6e-8)
+                got = fftvis_amd.simulate_vis(**c)
+                exp = oracle_simulate(c)
+                assert rel_l2(got, exp) < TOL, (type(beam).__name__, pol, feed, rel_l2(got, exp))
+            want = orc.evaluate_beam(oracle_beam(beam, pol, cfg["freqs"]), az, za, pol, 240e6)
+            have = ev.evaluate_beam(beam, az, za, pol, 240e6)
+            assert np.abs(have - want).max() <= 1e-7 * np.abs(want).max(), (type(beam).__name__, pol)
+    # mixed with an order-1 table beam the sampled object would need an order-1 table: refused, not degraded
+    tabb = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(cfg["freqs"], nza=46, naz=90), cfg["freqs"])
+    monkeypatch.setenv("FFTVIS_HIP_BEAM_TABLE_BYTES", str(2**28))
+    with pytest.raises(ValueError, match="no .za, az. table within"):
+        fftvis_amd.simulate_vis(**dict(cfg, beam=[tabb, AiryBeamLookalike(14.0)], polarized=True,
+                                       beam_idx=np.arange(len(cfg["ants"])) % 2))

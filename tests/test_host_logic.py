@@ -257,38 +257,89 @@ class _StubAnalyticBeam:
 
 
 class AiryBeamLookalike(_StubAnalyticBeam):
-    """A third-party class that merely LOOKS like an Airy dish (name + .diameter)."""
+    """A third-party class that merely LOOKS like an Airy dish (name + .diameter): its response is a Gaussian
+    with a dipole-like azimuth term, nothing the closed form can follow."""
+
+    def compute_response(self, *, az_array, za_array, freq_array, **kw):
+        self.calls += 1
+        g = np.exp(-0.5 * (za_array * self.diameter * freq_array[0] / 299792458.0) ** 2)
+        out = np.zeros((2, 2, 1, az_array.size), dtype=complex)
+        out[0, 0, 0], out[1, 0, 0] = g * np.cos(az_array), -g * np.sin(az_array) * np.cos(za_array)
+        out[0, 1, 0], out[1, 1, 0] = g * np.sin(az_array), g * np.cos(az_array) * np.cos(za_array)
+        return out
 
 
-def test_third_party_analytic_beams_are_sampled_not_guessed():
-    """an object with compute_response is followed through that method -- never replaced by
-    this package's Airy formula, whatever its class name says."""
-    from fftvis_amd.core.beams import SAMPLED_NODES, is_sampled_analytic, response_at
+def test_third_party_analytic_beams_are_probed_never_guessed(monkeypatch):
+    """VERDICT r1 #3 / r2 next #8 / ADVICE r2 (medium): an object with compute_response is followed through that
+    method.  It runs in closed form only when its OWN response at the probes equals this package's Airy form
+    times one constant per Jones slot (to 1e-12) -- then with exactly those constants; anything else is sampled
+    onto a table whose node spacing is refined until the device interpolant meets the tolerance against
+    compute_response between the nodes.  A class name or a .diameter attribute decides nothing."""
+    from fftvis_amd.core import beams as cb
+    from fftvis_amd.core.beams import is_sampled_analytic, response_at
 
-    freqs = np.array([120e6, 180e6])
-    for cls in (_StubAnalyticBeam, AiryBeamLookalike):
-        b = cls()
-        assert is_sampled_analytic(b) and not is_sampled_analytic(fftvis_amd.AiryBeam(14.0))
-        kind, tab, za_max = describe_beam(b, True, freqs, order=3)
-        nza, naz = SAMPLED_NODES[3]
-        assert kind == "table" and tab.shape == (2, 2, 2, nza, naz) and np.isclose(za_max, np.pi / 2)
-        assert b.calls == 2  # once per frequency
-        # the table IS the object's response (e / sqrt 2 at zenith), not 2 J1(x)/x = 1
-        np.testing.assert_allclose(tab[:, 0, 0, 0, 0], 1 / np.sqrt(2))
-        za = np.linspace(0, np.pi / 2, nza)
-        ref = response_at(b, True, freqs[1], np.zeros(nza), za)
-        np.testing.assert_allclose(tab[1, :, :, :, 0], ref)
-        # unpolarized: power of the named feed = sum over vector axes of |E|^2
-        _, px, _ = describe_beam(b, False, freqs, use_feed="x", order=3)
-        _, py, _ = describe_beam(b, False, freqs, use_feed="y", order=3)
-        np.testing.assert_allclose(px[:, 0, 0], 0.5 * (1 + 0.25))
-        np.testing.assert_allclose(py, 0.49 * px)
+    freqs = np.array([120e6, 180e6, 250e6])
+    b = _StubAnalyticBeam()
+    assert is_sampled_analytic(b) and not is_sampled_analytic(fftvis_amd.AiryBeam(14.0))
+    kind, D, js, ps = describe_beam(b, True, freqs, order=3)
+    assert kind == "airy" and D == 14.0 and ps == 1.0
+    np.testing.assert_allclose(js, np.array([[1, 0.7], [0.5, 0.35]]) / np.sqrt(2), rtol=0, atol=1e-14)
+    kind, D, js, px = describe_beam(b, False, freqs, use_feed="x")
+    _, _, _, py = describe_beam(b, False, freqs, use_feed="y")
+    assert kind == "airy" and np.isclose(px, 0.5 * (1 + 0.25)) and np.isclose(py, 0.49 * px)
+    np.testing.assert_array_equal(cb.airy_factors(("airy", 14.0)), [1, 0, 1, 0, 1, 0, 1, 0, 1])
+    # the lookalike is NOT that form: sampled, refined, and the table reproduces ITS response to the tolerance
+    look = AiryBeamLookalike()
+    assert cb.fit_airy_closed_form(look, True, freqs) is None
+    kind, tab, za_max = describe_beam(look, True, freqs, order=3, tol=1e-7)
+    nzp, naz = tab.shape[-2:]
+    nza = nzp - cb.SAMPLED_PAD
+    assert kind == "table" and tab.shape[:3] == (3, 2, 2) and naz >= 720 and nza >= 181
+    assert np.isclose(za_max, 0.5 * np.pi * (nzp - 1) / (nza - 1))  # SAMPLED_PAD nodes past the horizon
+    rng = np.random.default_rng(3)
+    za, az = rng.uniform(0, np.pi / 2, 400), rng.uniform(0, 2 * np.pi, 400)
+    for fi in (0, 2):
+        want = response_at(look, True, freqs[fi], az, za)
+        got = np.stack([cb._interp_table(pl, za_max, az, za, 3) for pl in tab[fi].reshape(4, nzp, naz)]).reshape(2, 2, -1)
+        assert np.abs(got - want).max() < 2e-7
+    # azimuth-independent but not Airy (frequency-dependent gain): 8 azimuth nodes, finer za nodes than 0.5 deg
+    class Gain(_StubAnalyticBeam):
+        def compute_response(self, *, az_array, za_array, freq_array, **kw):
+            return super().compute_response(az_array=az_array, za_array=za_array, freq_array=freq_array) * freq_array[0] / 1e8
+
+    kind, tab, za_max = describe_beam(Gain(), True, freqs, order=3, tol=1e-7)
+    assert kind == "table" and tab.shape[-1] == cb.SAMPLED_AZ_SYMMETRIC_NODES and tab.shape[-2] > 181 + cb.SAMPLED_PAD
+    # a 25 m dish at 1.4 GHz (pattern scale ~0.5 deg: under-resolved by a fixed 0.5-degree grid) is refined further
+    kind, tab25, _ = describe_beam(Gain(25.0), True, np.array([1.3e9, 1.4e9]), order=3, tol=1e-7)
+    assert tab25.shape[-2] > tab.shape[-2]
+    # an order-1 table of a pattern with azimuth structure cannot reach 1e-7 within the byte limit: refused, loudly
+    monkeypatch.setenv("FFTVIS_HIP_BEAM_TABLE_BYTES", str(2**28))
+    with pytest.raises(ValueError, match="no .za, az. table within"):
+        describe_beam(look, True, freqs[:1], order=1, tol=1e-7)
+    monkeypatch.delenv("FFTVIS_HIP_BEAM_TABLE_BYTES")
+    # a pattern that is not finite below the horizon is padded by reflection instead
+    class Hard(AiryBeamLookalike):
+        def compute_response(self, *, az_array, za_array, freq_array, **kw):
+            out = super().compute_response(az_array=az_array, za_array=za_array, freq_array=freq_array)
+            out[..., za_array > np.pi / 2 + 1e-12] = np.nan
+            return out
+
+    kind, tabh, _ = describe_beam(Hard(), True, freqs[:1], order=3, tol=1e-7)
+    assert kind == "table" and np.all(np.isfinite(tabh))
+    # the memory estimate counts a table for such beams (ADVICE r2)
+    from fftvis_amd.core.utils import get_desired_chunks
+
+    small = int(0.9 * 205 * 720 * 4 * 16 * 8)  # less than one 8-channel table: chunks cannot help, the count saturates
+    assert get_desired_chunks(small, 1, [look], 2, 2, 7, 1000, 2, nfreq=8)[0] > get_desired_chunks(
+        small, 1, [fftvis_amd.AiryBeam(14.0)], 2, 2, 7, 1000, 2, nfreq=8)[0]
+
     # a wrapper object (BeamInterface-like) around the analytic beam is followed too
     class Wrapper:
         def __init__(self, beam):
             self.beam = beam
 
-    assert describe_beam(Wrapper(_StubAnalyticBeam()), True, freqs, order=3)[0] == "table"
+    assert describe_beam(Wrapper(_StubAnalyticBeam()), True, freqs, order=3)[0] == "airy"
+    assert describe_beam(Wrapper(look), True, freqs[:1], order=3)[0] == "table"
     assert describe_beam(Wrapper(fftvis_amd.AiryBeam(12.0)), True, freqs) == ("airy", 12.0)
 
 
