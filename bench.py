@@ -61,6 +61,8 @@ def parse():
                         "(per-rank cost of the sharding without N GPUs; value = that block's visibilities/s)")
     p.add_argument("--of-ranks", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-e2e", action="store_true",
+                   help="skip the host-in -> host-out simulate_vis() calls of the `e2e` entry")
     p.add_argument("--no-breakdown", action="store_true",
                    help="skip the extra single-stream step that times every kernel family (profiling runs)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -74,15 +76,29 @@ def parse():
 
 
 def cpu_baseline(cfg, seconds: float):
-    """Time the CPU port of the reference's per-slice work (oracle/: numpy beam + coherency,
-    type-3 NUFFT port = C/OpenMP spread + interp around scipy.fft, every stage on all host cores) on a
-    bounded sample of slices, one NUFFT call per (time, frequency) as the reference does.  Slices are
-    taken from the top of the band downwards and the bottom upwards alternately so that the sample's
-    mean cost is the band's."""
+    """The CPU path timed beside the GPU on a bounded sample of (time, frequency) slices, one NUFFT call per
+    slice and beam pair as the reference does (cpu_simulate.py:969-1069).  Slices are taken from the top of the
+    band downwards and the bottom upwards alternately so that the sample's mean cost is the band's.
+
+    If ``finufft`` is importable on this box the NUFFT is the reference's own call (cpu/nufft.py:48-59:
+    ``finufft.nufft2d3(x, y, c, u, v, modeord=0, eps=eps, nthreads=all cores, showwarn=0, upsampfac=2)``) --
+    ``kind: "finufft"`` -- and a second, shorter sample times the type-1 call the reference takes by default on
+    these lattice arrays (cpu/nufft.py:162-175) for the ``default_path`` entry.  Otherwise the NUFFT is the
+    build's own CPU port (oracle/cpu_nufft: C/OpenMP spread + gather around scipy.fft, all cores) --
+    ``kind: "port"``, which is NOT finufft.  Beam and coherency are the oracle's numpy restatement either way."""
     from oracle import cpu_nufft
     from oracle import fftvis_oracle as orc
     from tests.helpers import oracle_beam
 
+    try:
+        ncores = len(os.sched_getaffinity(0))  # the cores this process may run on
+    except AttributeError:
+        ncores = os.cpu_count()
+    try:
+        import finufft
+    except Exception:
+        finufft = None
+    eps = cfg["eps"]
     freqs, times = cfg["freqs"], cfg["times"]
     pol = cfg["polarized"]
     nfeeds = 2 if pol else 1
@@ -99,44 +115,84 @@ def cpu_baseline(cfg, seconds: float):
     bpairs = [(k, l) for k in range(len(beams)) for l in range(k, len(beams))] if "beam_coefs" in cfg else [(0, 0)]
     nf = len(freqs)
     order = [i // 2 if i % 2 == 0 else nf - 1 - i // 2 for i in range(nf)]  # bottom, top, bottom + 1, ...
-    nslices, t_used, n = 0, 0.0, 0
-    t_start = time.perf_counter()
-    for ti in range(len(times)):
-        mgr.rotate(ti)
-        topo, flux, n = mgr.select_chunk(0, ti)
-        az, za = orc.enu_to_az_za(topo[0], topo[1])
-        topo = 2 * np.pi * topo
-        for fi in order:
-            bev = [orc.evaluate_beam(b, az, za, pol, freqs[fi]).astype(complex) for b in beams]
-            uvw = bls * freqs[fi]
-            for (k, l) in bpairs:
-                c = orc.compute_apparent_coherency(bev, k, l, flux, fi, pol, pol_sky, nfeeds)
-                cpu_nufft.nufft_type3([topo[0], topo[1]], c, [uvw[0], uvw[1]], eps=cfg["eps"])
-            nslices += 1
-            t_used = time.perf_counter() - t_start
-            if t_used > seconds and nslices % 2 == 0:
+
+    def type3(topo, c, uvw, fi):
+        if finufft is not None:
+            return finufft.nufft2d3(topo[0], topo[1], np.ascontiguousarray(c), np.ascontiguousarray(uvw[0]),
+                                    np.ascontiguousarray(uvw[1]), modeord=0, eps=eps, nthreads=ncores, showwarn=0,
+                                    upsampfac=2)
+        return cpu_nufft.nufft_type3([topo[0], topo[1]], c, [uvw[0], uvw[1]], eps=eps)
+
+    def sample(nufft, budget, prepare=None):
+        nslices, t_used, n = 0, 0.0, 0
+        t_start = time.perf_counter()
+        for ti in range(len(times)):
+            mgr.rotate(ti)
+            topo, flux, n = mgr.select_chunk(0, ti)
+            az, za = orc.enu_to_az_za(topo[0], topo[1])
+            topo = 2 * np.pi * (prepare(topo) if prepare else topo)
+            for fi in order:
+                bev = [orc.evaluate_beam(b, az, za, pol, freqs[fi]).astype(complex) for b in beams]
+                uvw = bls * freqs[fi]
+                for (k, l) in bpairs:
+                    c = orc.compute_apparent_coherency(bev, k, l, flux, fi, pol, pol_sky, nfeeds)
+                    nufft(topo, c.reshape(-1, c.shape[-1]) if c.ndim > 1 else c, uvw, fi)
+                nslices += 1
+                t_used = time.perf_counter() - t_start
+                if t_used > budget and nslices % 2 == 0:
+                    break
+            if t_used > budget:
                 break
-        if t_used > seconds:
-            break
+        return nslices, t_used, n
+
+    nslices, t_used, n = sample(type3, seconds)
     nbls = len(cfg["baselines"])
-    try:
-        ncores = len(os.sched_getaffinity(0))  # the cores this process may run on
-    except AttributeError:
-        ncores = os.cpu_count()
-    w = cpu_nufft.es_params(cfg["eps"], 2.0)[0]
+    w = cpu_nufft.es_params(eps, 2.0)[0]
     nfe = (nfeeds * nfeeds)
-    thr_spread = cpu_nufft._nthreads(n * nfe * w * w)
-    thr_interp = cpu_nufft._nthreads(nbls * nfe * w * w)
-    return {
+    res = {
         "value": nbls * nslices / t_used,
         "unit": "visibilities/s",
         "cores": ncores,
-        "kind": "port",
-        "sample": f"{nslices} (time,freq) slices of the workload (alternating from both ends of the band) in "
-                  f"{t_used:.1f} s; scipy.fft with {ncores} workers, C/OpenMP spread / interp (oracle/cpu_nufft.c) "
-                  f"with {thr_spread} / {thr_interp} threads, numpy beam/coherency -- CPU restatement of "
-                  "the type-3 NUFFT path, not finufft",
+        "kind": "finufft" if finufft is not None else "port",
     }
+    if finufft is not None:
+        res["sample"] = (f"{nslices} (time,freq) slices of the workload (alternating from both ends of the band) in "
+                         f"{t_used:.1f} s; finufft {getattr(finufft, '__version__', '?')} nufft2d3, eps={eps:g}, "
+                         f"upsampfac=2, nthreads={ncores} -- the reference's own type-3 call (cpu/nufft.py:48-59); "
+                         "numpy beam/coherency")
+        # the path the reference takes BY DEFAULT on these lattice arrays (cpu_simulate.py:634-637, 661-681):
+        # type 1 onto the lattice's mode grid, then the baselines' modes are picked (cpu/nufft.py:120-175)
+        try:
+            from fftvis_amd.core.antenna_gridding import check_antpos_griddability
+
+            ok, grid, basis = check_antpos_griddability(ants)
+            if ok and "beam_coefs" not in cfg:
+                bint = np.round(np.array([grid[b[1]] - grid[b[0]] for b in cfg["baselines"]]).T).astype(int)
+                n_modes = 2 * int(np.abs(bint).max()) + 1
+                B = basis / orc.speed_of_light
+
+                def type1(topo, c, uvw, fi):
+                    model = finufft.nufft2d1(topo[0] * freqs[fi], topo[1] * freqs[fi], np.ascontiguousarray(c),
+                                             n_modes, modeord=1, eps=eps, nthreads=ncores, showwarn=0, upsampfac=2)
+                    return model[..., bint[0], bint[1]]
+
+                ns1, t1, _ = sample(type1, max(4.0, seconds / 4), prepare=lambda topo: B.T @ topo)
+                res["default_path"] = {
+                    "value": nbls * ns1 / t1, "unit": "visibilities/s", "kind": "finufft type 1",
+                    "sample": f"{ns1} slices in {t1:.1f} s; finufft.nufft2d1 on the {n_modes}^2 lattice mode grid + "
+                              "mode pick (cpu/nufft.py:162-175): what simulate_vis runs on this array unless "
+                              "force_use_type3",
+                }
+        except Exception as e:  # the like-for-like number stands on its own
+            res["default_path"] = {"error": repr(e)}
+    else:
+        thr_spread = cpu_nufft._nthreads(n * nfe * w * w)
+        thr_interp = cpu_nufft._nthreads(nbls * nfe * w * w)
+        res["sample"] = (f"{nslices} (time,freq) slices of the workload (alternating from both ends of the band) in "
+                         f"{t_used:.1f} s; scipy.fft with {ncores} workers, C/OpenMP spread / interp (oracle/cpu_nufft.c) "
+                         f"with {thr_spread} / {thr_interp} threads, numpy beam/coherency -- CPU restatement of "
+                         "the type-3 NUFFT path, not finufft (finufft is not importable on this box)")
+    return res
 
 
 def spawn_ranks(n: int) -> int:
@@ -461,6 +517,37 @@ def main():
             "roofline_interp": interp_rf,
             "kernels": kern,
         }
+        if not a.no_e2e and world == 1 and a.as_rank is None:
+            # ---- host to host: what a caller of simulate_vis() waits for (never `value`) -----------------
+            # numpy in, numpy out (reference wrapper.py:85-336 -> cpu_simulate.py:843-854 returns a host array):
+            # catalog / beam / baseline upload, per-geometry tables, the step itself, and the visibilities' way
+            # back to the host -- pinned in place and overlapped with the kernels (fv_sim.h drain_to_host).
+            import fftvis_amd
+
+            h.close()
+            outs.clear()
+            del cat
+            torch.cuda.empty_cache()
+            kw = dict(cfg, upsample_factor=a.upsample if a.upsample else "auto",
+                      force_use_type3=a.path == "type3")
+            walls, nbytes = [], 0
+            for _ in range(2):
+                t_e = time.perf_counter()
+                v = fftvis_amd.simulate_vis(**kw)
+                walls.append(time.perf_counter() - t_e)
+                nbytes = v.nbytes
+                del v
+            res["e2e"] = {
+                "what": "fftvis_amd.simulate_vis(**cfg): host arrays in, host array out, one call = one step",
+                "first_call_s": walls[0],
+                "second_call_s": walls[1],
+                "ratio_to_device_resident_step": walls[1] / (elapsed / a.steps),
+                "value": vis_per_step / walls[1],
+                "unit": "visibilities/s",
+                "output_bytes": nbytes,
+                "d2h": "off" if os.environ.get("FFTVIS_HIP_D2H_OVERLAP") == "0" else
+                       "caller's array pinned in place, one async copy per (channel, finished time step) on a copy stream",
+            }
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
         print(json.dumps(res))

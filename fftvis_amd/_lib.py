@@ -14,7 +14,8 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_void_p
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfftvis_hip.so")
+# FFTVIS_HIP_LIB: another build of the same library (A/B measurements of kernel variants), else the in-tree one
+LIB_PATH = os.environ.get("FFTVIS_HIP_LIB") or os.path.join(_HERE, "libfftvis_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 HIPCC_FLAGS = [
@@ -51,6 +52,7 @@ SYMBOLS = {
     "fv_sim_set_nbeams": (c_int, [c_void_p, c_int]),
     "fv_sim_set_beam_airy": (c_int, [c_void_p, c_int, c_double]),
     "fv_sim_set_beam_airy_scaled": (c_int, [c_void_p, c_int, c_double, c_void_p, c_double]),
+    "fv_sim_set_reference_compat": (c_int, [c_void_p, c_int]),
     "fv_sim_set_beam_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int]),
     "fv_sim_set_beam_pairs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),

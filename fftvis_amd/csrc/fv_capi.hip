@@ -506,6 +506,7 @@ int fv_sim_set_nbeams(fv_sim *h, int nbeams) {
 int fv_sim_set_beam_airy(fv_sim *h, int beam, double diameter) {
     FV_SIM_CALL(FV_REQUIRE(diameter > 0, "diameter must be positive"); h->impl->set_beam_airy(beam, diameter, nullptr, 1.0));
 }
+int fv_sim_set_reference_compat(fv_sim *h, int on) { FV_SIM_CALL(h->impl->set_reference_compat(on)); }
 int fv_sim_set_beam_airy_scaled(fv_sim *h, int beam, double diameter, const double *jones_scale, double power_scale) {
     FV_SIM_CALL(FV_REQUIRE(diameter > 0, "diameter must be positive");
                 FV_REQUIRE(power_scale == power_scale, "NaN power factor");

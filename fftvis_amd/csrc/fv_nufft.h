@@ -1092,6 +1092,21 @@ __device__ inline void st_twiddle(cplx<T> *v, cplx<T> w) {
     }
 }
 
+// the same with a common factor: X[k] *= start w^k, k = 0 .. R-1  (start = the residue twiddle w^{u p} of the thread's
+// slots, which the radix-R butterfly commutes with: applying it here costs one multiply more than the plain pass-1
+// twiddle, applying it to the R inputs cost R of them)
+template <typename T, int R>
+__device__ inline void st_twiddle_from(cplx<T> *v, cplx<T> start, cplx<T> w) {
+    constexpr int LR = ilog2_c(R);
+    cplx<T> wk = start;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        v[bitrev_small(k, LR)] = cmul(v[bitrev_small(k, LR)], wk);
+        if (k + 1 < R) wk = cmul(wk, w);
+    }
+}
+__device__ inline int mul24(int a, int b) { return (int)__mul24(a, b); }  // both factors below 2^23: full-rate multiply
+
 // --- fused gather (small 2-D problems) ---------------------------------------------------------
 // When the last FFT pass runs in column mode (8 adjacent lx per workgroup, all ly of one transform)
 // and both dimensions are stored in natural order (P = 1), the workgroup can serve the targets
@@ -1116,6 +1131,7 @@ struct FusedArgs {
     void *out;                    // cplx<T> *, base of this (time, frequency-group) block
     void *out1;                   // the same for the second problem of a gang launch
     int64_t pol_off[4];
+    int tflip;                    // flipped baselines land in the feed-transposed slot (InterpArgs::transpose_flipped)
 };
 struct FgGeom {
     int w, nox, noy, n2x, n2y;
@@ -1191,12 +1207,14 @@ __global__ void k_fg_build(int64_t N, int nfg, const T *__restrict__ btx, const 
 //     w^{q p} sum_m x[q + m Q] c^m,      c = w^{Q p} = exp(2 pi i p / P)  (uniform),
 // over the m with -n_in/2 <= q + m Q < n_in - n_in/2: ceil(n_in / Q) + 1 sweeps of coalesced loads, one
 // uniform complex factor per sweep (none for p = 0), one per-slot twiddle at the end.
-template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false, bool FOLD = false>
+// INBLK (column mode): the input plane is in 64-byte column blocks (RowDifArgs::in_blk = BLKLOG).
+template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false, bool FOLD = false, bool INBLK = false>
 __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_MINW12 : 4) void k_rowfft_st(
     const cplx<T> *__restrict__ in0, cplx<T> *__restrict__ out0, const cplx<T> *__restrict__ tw, RowDifArgs a,
     FusedArgs fz) {
     static_assert(!FUSED || COL, "the fused gather rides on the column-mode last pass");
     static_assert(!FOLD || (!FUSED && NLD == (1 << (LOGQ == 9 ? 3 : 4))), "folding runs on full pass-1 operands");
+    static_assert(!INBLK || (COL && !FUSED), "blocked input planes are read by the plain column pass");
     // gang launch: blockIdx.y = 1 runs the same transform on a second pair of buffers
     const cplx<T> *__restrict__ in = blockIdx.y ? static_cast<const cplx<T> *>(a.in1) : in0;
     cplx<T> *__restrict__ out = blockIdx.y ? static_cast<cplx<T> *>(a.out1) : out0;
@@ -1279,28 +1297,48 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
     // the range check does the masking.  Column mode: base = the workgroup's first column, every lane adds its own
     // column's offset and masks by the index -1 (beyond any extent): one compare + select per element instead of
     // clamp + two compares + four selects, and no 64-bit addresses in vector registers.
-    const bool in_blocked = COL && a.in_blk;
-    const int64_t in_base = in_blocked ? (row0 / a.rpp) * a.in_plane
-                            : COL      ? (row0 / a.rpp) * a.in_plane + (row0 % a.rpp) * a.in_row
-                                       : (ok ? rplane * a.in_plane + rk * a.in_row : 0);
-    const RowBuf<T> rowin(in + in_base, COL ? -1 : (ok ? a.n_in : 0));
-    const int lane_in = in_blocked ? (int)((rplane - row0 / a.rpp) * a.in_plane) + (((int)rk >> a.in_blk) * a.n_in << a.in_blk) +
-                                         ((int)rk & ((1 << a.in_blk) - 1))
-                        : COL      ? (int)(rplane * a.in_plane + rk * a.in_row - in_base)
-                                   : 0;
-    const int in_elem = in_blocked ? 1 << a.in_blk : (int)a.in_elem;
+    // Column mode, blocked input (INBLK): element (column x, row ia) of a plane sits at
+    // (x >> BLKLOG) (n_in << BLKLOG) + (ia << BLKLOG) + (x & (2^BLKLOG - 1)).  When the workgroup's RPW columns are exactly
+    // one block (ONEBLK: fp64 Q = 2048, fp32 Q <= 1024) that block is ONE contiguous run [ia][column] and a descriptor over
+    // just that run does all the masking -- ia < 0 wraps to a huge offset, ia >= n_in lies past the extent -- so an
+    // address is a single add; padding columns of the last block read allocated memory and are never stored.  Otherwise
+    // one compare + select per element (the bound is 0 for a lane without a column), shifts or a 24-bit multiply
+    // for the index -- no 32-bit integer multiplies (quarter rate) and no exec-mask regions.
+    constexpr int BLKLOG = sizeof(T) == 8 ? 2 : 3;
+    constexpr bool ONEBLK = COL && INBLK && RPW == (1 << BLKLOG);
+    const int64_t plane0 = (row0 / a.rpp) * a.in_plane;
+    const int64_t in_base = ONEBLK ? plane0 + ((((row0 % a.rpp) >> BLKLOG) * (int64_t)a.n_in) << BLKLOG)
+                            : INBLK ? plane0
+                            : COL   ? plane0 + (row0 % a.rpp) * a.in_row
+                                    : (ok ? rplane * a.in_plane + rk * a.in_row : 0);
+    const RowBuf<T> rowin(in + in_base, ONEBLK ? ((int64_t)a.n_in << BLKLOG) : COL ? -1 : (ok ? a.n_in : 0));
+    const int lane_in = ONEBLK ? r
+                        : INBLK ? (int)((rplane - row0 / a.rpp) * a.in_plane) + ((((int)rk >> BLKLOG) * a.n_in) << BLKLOG) +
+                                      ((int)rk & ((1 << BLKLOG) - 1))
+                        : COL   ? (int)(rplane * a.in_plane + rk * a.in_row - in_base)
+                                : 0;
+    const int in_elem = (int)a.in_elem;
+    const unsigned nin_lane = ok ? (unsigned)a.n_in : 0u;
     auto load_in = [&](int ia) -> cplx<T> {
-        if constexpr (COL)
-            return rowin.load(ok && (unsigned)ia < (unsigned)a.n_in ? lane_in + ia * in_elem : -1);
+        if constexpr (ONEBLK)
+            return rowin.load((ia << BLKLOG) + lane_in);
+        else if constexpr (INBLK)
+            return rowin.load((unsigned)ia < nin_lane ? lane_in + (ia << BLKLOG) : -1);
+        else if constexpr (COL)
+            return rowin.load((unsigned)ia < nin_lane ? lane_in + mul24(ia, in_elem) : -1);
         else
             return rowin.load(ia);  // zero outside [0, n_in)
     };
+    // Residue twiddle of slot q = u + k S1:  w^{q p} = w^{u p} (this thread's, one vector load) x w^{k S1 p} (uniform:
+    // scalar loads).  Only the uniform part is applied to the inputs; w^{u p} is common to the thread's R1 slots, commutes
+    // with their butterfly and rides on the pass-1 twiddle below (loaded there: no registers held across the loads and the butterfly).
     if constexpr (FOLD) {
         const int nlo = a.n_in - hshift;                      // elements with s >= 0
         const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
         const int mmax = (nlo - 1) / Q;
         constexpr int CH = 4;  // slots per chunk: 4 accumulators + 2 sweeps x 4 operands in flight beside va
-        const cplx<T> wbase = tw[u * p];  // u p < Q P = n2
+        int mp_min = (mmin * p) % a.P;  // (mmin p) mod P, mmin <= 0
+        if (mp_min < 0) mp_min += a.P;
 #pragma unroll
         for (int h = 0; h < R1; h += CH) {
             cplx<T> acc[CH];
@@ -1313,6 +1351,8 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
             const int m_lo = mmax - mmin < 2 ? mmin : max(mmin, (-hshift - ((h + CH) * S1 - 1)) / Q);  // ceil of a negative quotient
             const int m_hi = mmax - mmin < 2 ? mmax : min(mmax, (nlo - 1 - h * S1) / Q);               // numerator >= 0 there
             // two sweeps per round trip: 8 loads in flight (a sweep beyond m_hi asks for index -1: zero, no access)
+            int mpw = mp_min + (m_lo - mmin) * p;  // (m_lo p) mod P: m_lo - mmin is 0 or 1
+            while (mpw >= a.P) mpw -= a.P;
             for (int m = m_lo; m <= m_hi; m += 2) {
                 cplx<T> x[2][CH];
 #pragma unroll
@@ -1323,9 +1363,11 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    // c^m = w^{(m Q p) mod n2}: m Q p is a multiple of Q, so the index is ((m p) mod P) Q
-                    int mp = ((m + t) * p) % a.P;
-                    if (mp < 0) mp += a.P;
+                    // c^m = w^{(m Q p) mod n2}: m Q p is a multiple of Q, so the index is ((m p) mod P) Q -- walked
+                    // incrementally (a modulo by a run-time P is a dozen scalar instructions, and this is per sweep)
+                    const int mp = mpw;
+                    mpw += p;
+                    if (mpw >= a.P) mpw -= a.P;
                     if (mp) {  // uniform
                         const cplx<T> cm = tw[mp * Q];
 #pragma unroll
@@ -1343,10 +1385,10 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
                 }
             }
             if (p) {
-                // slot twiddle w^{q p}, q = u + k S1:  w^{u p} (this thread's, loaded once, long before) times
-                // w^{k S1 p} (uniform: scalar loads) -- no dependent vector load per chunk
+                // the uniform part of the slot twiddle, w^{k S1 p} (k = 0: one)
 #pragma unroll
-                for (int j = 0; j < CH; ++j) acc[j] = cmul(acc[j], cmul(wbase, tw[(h + j) * S1 * p]));  // k S1 p < n2
+                for (int j = 0; j < CH; ++j)
+                    if (h + j) acc[j] = cmul(acc[j], tw[(h + j) * S1 * p]);  // k S1 p < n2
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j) va[h + j] = acc[j];
@@ -1372,25 +1414,22 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
                 slot(i, jr, q, hi);
                 va[jr] = load_in((hi ? q - Q : q) + hshift);  // zero where the row has no element
             }
-            if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
-                constexpr int CH = 4;
+            if (p) {  // workgroup-uniform
+                // uniform part of the residue twiddle: slot k holds s = u + k S1 (twiddle w^{k S1 p}) or the wrapped
+                // element s = u + k S1 - Q (w^{k S1 p} conj(c), c = w^{Q p}); which one is a per-lane select between two
+                // uniform values when the row is long (NLD == R1), a compile-time fact otherwise
+                const cplx<T> cq = tw[Q * p];  // Q p < n2 for p < P
     #pragma unroll
-                for (int h = 0; h < NLD; h += CH) {
-                    cplx<T> w[CH];
-    #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        int jr, q;
-                        bool hi;
-                        slot(h + j, jr, q, hi);
-                        w[j] = tw[hi ? n2 - (Q - q) * p : q * p];  // (s p) mod n2; (Q - q) p < Q P = n2: always a valid index
-                    }
-    #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        int jr, q;
-                        bool hi;
-                        slot(h + j, jr, q, hi);
-                        va[jr] = cmul(va[jr], w[j]);
-                    }
+                for (int i = 0; i < NLD; ++i) {
+                    int jr, q;
+                    bool hi;
+                    slot(i, jr, q, hi);
+                    const cplx<T> f = tw[jr * S1 * p];
+                    const cplx<T> fc = cmul(f, cplx<T>{cq.re, -cq.im});
+                    if (NLD == R1)
+                        va[jr] = cmul(va[jr], cplx<T>{hi ? fc.re : f.re, hi ? fc.im : f.im});
+                    else
+                        va[jr] = cmul(va[jr], i >= NH ? fc : f);
                 }
             }
         } else {
@@ -1400,23 +1439,28 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
     #pragma unroll
             for (int h = 0; h < NLD; h += CH) {
                 cplx<T> x[CH];
-                int widx[CH];
+                bool his[CH];
     #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
                     const int q = u + jr * S1;
                     // slot q: the element with s = q if there is one, else the wrapped one with s = q - Q
                     const bool hi = NLD == R1 ? q >= nlo : h + j >= NH;
-                    const int ia = (hi ? q - Q : q) + hshift;
-                    widx[j] = hi ? n2 - (Q - q) * p : q * p;  // (s p) mod n2; (Q - q) p < Q P = n2: always a valid index
-                    x[j] = load_in(ia);
+                    his[j] = hi;
+                    x[j] = load_in((hi ? q - Q : q) + hshift);
                 }
-                if (p) {  // workgroup-uniform for G = 1, wave-uniform otherwise
-                    cplx<T> w[CH];
+                if (p) {  // workgroup-uniform: the uniform part of the residue twiddle, w^{k S1 p} (wrapped: x conj(w^{Q p}))
+                    const cplx<T> cq = tw[Q * p];  // Q p < n2 for p < P
     #pragma unroll
-                    for (int j = 0; j < CH; ++j) w[j] = tw[widx[j]];
-    #pragma unroll
-                    for (int j = 0; j < CH; ++j) x[j] = cmul(x[j], w[j]);
+                    for (int j = 0; j < CH; ++j) {
+                        const int jr = NLD == R1 ? h + j : (h + j < NH ? h + j : R1 - NLD + h + j);
+                        const cplx<T> f = tw[jr * S1 * p];
+                        const cplx<T> fc = cmul(f, cplx<T>{cq.re, -cq.im});
+                        if (NLD == R1)
+                            x[j] = cmul(x[j], cplx<T>{his[j] ? fc.re : f.re, his[j] ? fc.im : f.im});
+                        else
+                            x[j] = cmul(x[j], h + j >= NH ? fc : f);
+                    }
                 }
     #pragma unroll
                 for (int j = 0; j < CH; ++j) {
@@ -1432,7 +1476,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
         }
     }
     dif_regs<T, R1>(va);
-    st_twiddle<T, R1>(va, tw[u * a.P]);  // w_Q^{u k1} = w_{n2}^{P u k1}
+    st_twiddle_from<T, R1>(va, tw[mul24(u, p)], tw[mul24(u, a.P)]);  // w^{u p} w_Q^{u k1}, w_Q = w_{n2}^P; u p < n2 (p = 0: tw[0] = 1)
     const int s1 = (u / R3) * B + (u % R3);
 
     int base2[NI2], base3[NI3];
@@ -1477,7 +1521,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
     for (int i = 0; i < NI2; ++i) {
         const int j3 = (u + i * TPR) / R1;
         dif_regs<T, R2>(vb2[i]);
-        st_twiddle<T, R2>(vb2[i], tw[j3 * a.P * R1]);  // w_{Q/R1}^{j3 k2}
+        st_twiddle<T, R2>(vb2[i], tw[mul24(j3, a.P * R1)]);  // w_{Q/R1}^{j3 k2}
     }
 
     // ---- exchange 2 -> pass 3 (pass-2 items write back to the slots they read: no sync before) --
@@ -1538,6 +1582,10 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
     const int blk_step = (((Q / R3) * ostep) >> a.out_blk) * blk_rows, blk_wrap = ((Q * ostep) >> a.out_blk) * blk_rows;
     const unsigned blk_len = ok && ks_hi > ks_lo ? (unsigned)(ks_hi - ks_lo) : 0u;
     const int lane_out = COL ? (int)((rplane * a.rpp_valid + rk) * a.out_pitch + res_off - out_base) : 0;
+    const int col_step = (Q / R3) * ostep, col_wrap = Q * ostep;  // uniform
+    int col_pos0[NI3];
+#pragma unroll
+    for (int i = 0; i < NI3; ++i) col_pos0[i] = lane_out + mul24(u + i * TPR - ks_lo, ostep);
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
         int v = u + i * TPR;
@@ -1553,18 +1601,22 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
             if constexpr (FUSED) {
                 if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
             } else if constexpr (COL) {
-                rowout.store(ok && ks >= ks_lo && ks < ks_hi ? lane_out + (ks - ks_lo) * ostep : -1, vc[i][bitrev_small(k, L3)]);
+                // ks wraps exactly at k = R3 / 2 (v < Q / R3): position and validity are affine in k
+                const int rel = (v - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
+                rowout.store((unsigned)rel < blk_len ? col_pos0[i] + k * col_step - (k >= R3 / 2 ? col_wrap : 0) : -1,
+                             vc[i][bitrev_small(k, L3)]);
             } else {
                 if (out_blocked) {
                     // a thread's outputs are whole blocks apart (Q / R3 is a multiple of the block width), and
                     // ks wraps exactly at k = R3 / 2 (v < Q / R3): index and validity are affine in k with
                     // uniform constants -- two adds, a compare and a select per store
                     const int rel = (v - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
-                    const int pos0 = res0 + (v - ks_lo) * ostep;
-                    const int idx = (pos0 >> a.out_blk) * blk_rows + (pos0 & blk_mask) + k * blk_step - (k >= R3 / 2 ? blk_wrap : 0);
+                    const int pos0 = res0 + mul24(v - ks_lo, ostep);
+                    const int idx = mul24(pos0 >> a.out_blk, blk_rows) + (pos0 & blk_mask) + k * blk_step - (k >= R3 / 2 ? blk_wrap : 0);
                     rowout.store((unsigned)rel < blk_len ? idx : -1, vc[i][bitrev_small(k, L3)]);
                 } else {
-                    rowout.store((ks - ks_lo) * ostep, vc[i][bitrev_small(k, L3)]);
+                    // outside the residue's run the index is negative or past the extent: dropped by the descriptor
+                    rowout.store(mul24(v - ks_lo, ostep) + k * col_step - (k >= R3 / 2 ? col_wrap : 0), vc[i][bitrev_small(k, L3)]);
                 }
             }
         }
@@ -1576,7 +1628,9 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
         const int64_t rk0 = row0 % a.rpp;                    // first column of the workgroup
         const int pol = (int)(row0 / a.rpp) % fz.tpol;       // transform = (frequency, polarisation)
         const int c = tid & 7;
-        cplx<T> *obase = reinterpret_cast<cplx<T> *>(blockIdx.y ? fz.out1 : fz.out) + fz.pol_off[pol];
+        cplx<T> *obase0 = reinterpret_cast<cplx<T> *>(blockIdx.y ? fz.out1 : fz.out);
+        const int64_t po_plain = fz.pol_off[pol];
+        const int64_t po_flip = fz.tflip && fz.tpol == 4 ? fz.pol_off[(pol & 1) * 2 + (pol >> 1)] : po_plain;
         for (int e = fz_e; e < fz_s1; e += st_threads(LOGQ, COL) / 8) {
             if (e != fz_e) {  // beyond the prefetched first round
                 fz_item = fz.list[e];
@@ -1605,7 +1659,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
             if (c == 0) {
                 const double vr = (double)sr * fz_h.pr - (double)si * fz_h.pi;
                 const double vi = ((double)sr * fz_h.pi + (double)si * fz_h.pr) * fz_h.sgn;
-                cplx<T> *o = obase + fz_h.out_off;
+                cplx<T> *o = obase0 + (fz_h.sgn < 0 ? po_flip : po_plain) + fz_h.out_off;
                 atomicAdd(&o->re, (T)vr);
                 atomicAdd(&o->im, (T)vi);
             }
@@ -1651,6 +1705,13 @@ struct InterpArgs {
     //   conj(C[a1,kk,f]) C[a2,ll,f] V_r            at polarisation slot r, and (kk != ll) as
     //   conj(C[a1,ll,f]) C[a2,kk,f] V_r            at the feed-transposed slot.
     int basis, kk, ll, nbasis, ncoef_freq, f_first;
+    // reference_compat = 0 (the reference's forms are the default):
+    //   transpose_flipped: a flipped baseline of a two-beam pair is V_ij(-b)^H -- conjugated (as the reference does,
+    //   cpu_simulate.py:298) AND written to the feed-transposed slot;
+    //   basis_part: 1 = add only the (kk, ll) term, 2 = add only the transposed (ll, kk) term (from THIS launch's
+    //   values: with negate_all they are conj(V_kl(-b)), the exact V_lk(b)^T for complex basis beams), 0 = both
+    //   from V_kl(b) (cpu_simulate.py:464-468);  negate_all: every target is taken at -s and conjugated.
+    int transpose_flipped, basis_part, negate_all;
 };
 
 // HERM (Hermitian strengths): the grid holds two transforms per frequency instead of four --
@@ -1687,7 +1748,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const int fg = (int)(item / N);
     const int64_t kl = item % N;
     const int64_t k = bl_idx ? bl_idx[kl] : kl;
-    const double sg = (flip && flip[kl]) ? -1.0 : 1.0;
+    const double sg = ((flip && flip[kl]) != (a.negate_all != 0)) ? -1.0 : 1.0;
     const double sc = scale[fg];
     const int w = a.w;
     const T beta = (T)ker.beta, c4 = (T)ker.c;
@@ -1807,7 +1868,8 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
             }
             if (g != 0) continue;
             if (sg < 0) vi = -vi;  // conj for flipped baselines (cpu_simulate.py:298)
-            const int64_t po = r < 16 ? a.out_pol_off[r] : (int64_t)r * a.out_pol_off[1];
+            const int rt = a.transpose_flipped && sg < 0 && a.tpol == 4 ? (r & 1) * 2 + (r >> 1) : r;
+            const int64_t po = rt < 16 ? a.out_pol_off[rt] : (int64_t)rt * a.out_pol_off[1];
             cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + k * a.out_k_stride;
             cplx<T> *o = ob + po;
             if (a.basis) {
@@ -1818,9 +1880,11 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                 const cplx<double> w1 = cmul(cplx<double>{(double)c1k.re, -(double)c1k.im},
                                              cplx<double>{(double)c2l.re, (double)c2l.im});
                 const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
-                o->re += (T)v1.re;
-                o->im += (T)v1.im;
-                if (a.kk != a.ll) {
+                if (a.basis_part != 2) {
+                    o->re += (T)v1.re;
+                    o->im += (T)v1.im;
+                }
+                if (a.kk != a.ll && a.basis_part != 1) {
                     const cplx<T> c1l = coef[(cs1 + a.ll) * a.ncoef_freq + f];
                     const cplx<T> c2k = coef[(cs2 + a.kk) * a.ncoef_freq + f];
                     const cplx<double> w2 = cmul(cplx<double>{(double)c1l.re, -(double)c1l.im},
@@ -1877,7 +1941,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double vr = o_re[r], vi = sg < 0 ? -o_im[r] : o_im[r];  // conj for flipped baselines
-            cplx<T> *o = ob + a.out_pol_off[r];
+            cplx<T> *o = ob + a.out_pol_off[a.transpose_flipped && sg < 0 ? (r & 1) * 2 + (r >> 1) : r];
             if (a.basis) {
                 const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
                 o->re += (T)v1.re;
@@ -1906,12 +1970,14 @@ struct BasisTerm {
     const void *coef;   // device (nant, K, nfreq) complex
     const int *ant1, *ant2;  // device (nbls) antenna index of each baseline
     int kk, ll, nbasis, nfreq, f_first;
+    int part = 0, negate = 0;  // InterpArgs::basis_part / negate_all
 };
 
 template <typename T>
 class Nufft3 {
    public:
     int dim;
+    bool transpose_flipped = false;  // InterpArgs::transpose_flipped / FusedArgs::tflip (fv_sim_set_reference_compat)
     double eps, sigma;
     KerParams ker;
     Geom geo;
@@ -2410,10 +2476,19 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         const int need = a.n_in > g.Q ? 16 : 2 * (int)cdiv(a.n_in - a.n_in / 2, s1);
         const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;
         const bool col = a.colmode != 0;
+        FV_REQUIRE(!in_blk || !col || (in_blk == (sizeof(T) == 8 ? 2 : 3) && !fused), "blocked column input: 64-byte blocks");
+        FV_REQUIRE(!col || in_elem < (1 << 23), "column pass: row pitch beyond the 24-bit index multiply");
+#define FV_ST_LAUNCH(LQ, COLM, NLD, FUSEDV, FOLDV, FZ)                                                  \
+    if (COLM && in_blk && !FUSEDV) {                                                                   \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, false, FOLDV, COLM>), jobs,                  \
+                           dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FZ);                \
+    } else {                                                                                           \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, false>), jobs,                \
+                           dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FZ);                \
+    }
 #define FV_ST_GO(LQ, COLM, NLD)                                                                        \
     if (a.n_in > g.Q && NLD == (LQ == 9 ? 8 : 16)) {                                                   \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, (LQ == 9 ? 8 : 16), false, true>), jobs,          \
-                           dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FusedArgs{}); \
+        FV_ST_LAUNCH(LQ, COLM, (LQ == 9 ? 8 : 16), false, true, FusedArgs{})                           \
     } else {                                                                                           \
         bool launched = false;                                                                         \
         if constexpr (COLM && LQ <= 10) { /* the fused gather rides on 8-column passes only */          \
@@ -2423,9 +2498,9 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
                 launched = true;                                                                       \
             }                                                                                          \
         }                                                                                              \
-        if (!launched)                                                                                 \
-            hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, false>), jobs,                           \
-                               dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FusedArgs{}); \
+        if (!launched) {                                                                               \
+            FV_ST_LAUNCH(LQ, COLM, NLD, false, false, FusedArgs{})                                     \
+        }                                                                                              \
     }
 #define FV_ST_NLD(LQ, COLM)                                                                            \
     if (nld == 4) {                                                                                    \
@@ -2446,6 +2521,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         }
 #undef FV_ST_NLD
 #undef FV_ST_GO
+#undef FV_ST_LAUNCH
         return;
     }
     const size_t smem = sizeof(cplx<T>) * (size_t)a.lds_row * a.rpw;
@@ -2604,6 +2680,7 @@ bool Nufft3<T>::prepare_fused_gather(int64_t N, const T *btx, const T *bty, cons
     fused_args.out = out;
     fused_args.out1 = out_mate;
     for (int r = 0; r < 4; ++r) fused_args.pol_off[r] = out_pol_off ? out_pol_off[r] : 0;
+    fused_args.tflip = transpose_flipped ? 1 : 0;
     fused_active = true;
     return true;
 }
@@ -2627,6 +2704,8 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
         a.nbasis = basis->nbasis;
         a.ncoef_freq = basis->nfreq;
         a.f_first = basis->f_first;
+        a.basis_part = basis->part;
+        a.negate_all = basis->negate;
         coef = (const cplx<T> *)basis->coef;
         ant1 = basis->ant1;
         ant2 = basis->ant2;
@@ -2659,6 +2738,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     for (int r = 0; r < 16; ++r) a.out_pol_off[r] = out_pol_off ? out_pol_off[r] : 0;
     a.accumulate = accumulate ? 1 : 0;
     a.herm = herm;
+    a.transpose_flipped = transpose_flipped ? 1 : 0;
     const int64_t items = N * nfg;
     constexpr int IPW = INTERP_THREADS / GROUP;
     a.items_per_xcd = cdiv(cdiv(items, 8), IPW) * IPW;  // whole workgroups

@@ -7,6 +7,10 @@
 // spread launch and one batched FFT as extra "transforms" (DESIGN.md "Frequency groups").
 #pragma once
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
 #include "fv_nufft.h"
 
 #include <algorithm>
@@ -755,7 +759,7 @@ __global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int P, int cnt,
                           const int *__restrict__ bl_idx, const signed char *__restrict__ flip,
                           const T *__restrict__ dec, cplx<T> *__restrict__ out,
                           int64_t out_fg_stride, int64_t p0, int64_t p1, int64_t p2, int64_t p3, bool accumulate,
-                          bool herm) {
+                          bool herm, bool tflip) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * nfg) return;
     const int f = (int)(idx / N);
@@ -765,7 +769,9 @@ __global__ void k_t1_pick(const cplx<T> *__restrict__ X, int no, int P, int cnt,
     const int mx = fl ? -blx[k] : blx[k], my = fl ? -bly[k] : bly[k];
     const int lx = mx + no / 2, ly = my + no / 2;
     const T d = dec[lx] * dec[ly];
-    const int64_t pol[4] = {p0, p1, p2, p3};
+    // tflip (reference_compat = 0): a flipped baseline's block goes to the feed-transposed slots (V_ij(-b)^H)
+    const bool sw = fl && tflip && tp != 1;
+    const int64_t pol[4] = {p0, sw ? p2 : p1, sw ? p1 : p2, p3};
     if (herm) {
         // Hermitian packing (see k_interp): planes T1 = F[c_00 + i c_11], T2 = F[c_01]; the mirror mode
         // (-mx, -my) is on the grid too and shares the deconvolution factor (psi_hat is even)
@@ -845,6 +851,7 @@ struct SimBase {
     virtual void set_array_type1(const double *basis, int64_t nbls, const int *bls_int, int n_modes) = 0;
     virtual void set_nbeams(int n) = 0;
     virtual void set_beam_airy(int b, double diameter, const double *jones_scale, double power_scale) = 0;
+    virtual void set_reference_compat(int on) = 0;
     virtual void set_beam_table(int b, int nfreq_tab, int nza, int naz, double za_max,
                                 const void *table, int order) = 0;
     virtual void set_beam_pairs(int npairs, const int *bi, const int *bj, const int64_t *off,
@@ -909,8 +916,9 @@ class Sim : public SimBase {
         double btc[3], B[3];   // tight box of its (sign-adjusted) baselines: centre, half-width [s]
         double Bs[3];          // half-width of the box made symmetric about 0
         int herm = 0;          // this run packs its strengths into two transforms: 1 Hermitian, 2 all real (per run)
-        const double *box_c() const { return herm ? zero3 : btc; }
-        const double *box_B() const { return herm ? Bs : B; }
+        bool mirror = false;   // this run also gathers at the mirror targets -b (exact eigenbeam (l, k) terms)
+        const double *box_c() const { return herm || mirror ? zero3 : btc; }
+        const double *box_B() const { return herm || mirror ? Bs : B; }
     };
     static constexpr double zero3[3] = {0.0, 0.0, 0.0};
     std::vector<Pair> pairs;
@@ -946,6 +954,14 @@ class Sim : public SimBase {
     int lane_mode = -1;       // 0 one stream per lane, 1 pipelined, 2 pipelined gangs: what the lanes last ran as
     int64_t lane_serial = 0;  // units processed in that mode (lane rotation continues across runs)
     hipStream_t prep_stream = nullptr;  // low priority: per-time preparation of the next step
+    // Host output of a large run (drain_*): the caller's array is pinned in place while the GPU computes, and every
+    // finished time step leaves through this stream beside the later steps' kernels.
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> drain_events;  // "time step(s) finished", reused from run to run
+    struct DrainItem {
+        hipEvent_t ev;
+        int t, n;  // time steps [t, t + n) of the run's block
+    };
     hipEvent_t ev_start = nullptr;
     DevBuf d_out, d_mhist;
     // sticky device-side error counters, read at every host synchronisation point (check_errors):
@@ -1045,6 +1061,8 @@ class Sim : public SimBase {
             if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);
         }
         if (prep_stream) (void)hipStreamDestroy(prep_stream);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        for (hipEvent_t e : drain_events) (void)hipEventDestroy(e);
         if (ev_start) (void)hipEventDestroy(ev_start);
         for (auto &e : ev_pool) {
             (void)hipEventDestroy(e.a);
@@ -1130,6 +1148,12 @@ class Sim : public SimBase {
         upload(d_blint, bls_int, sizeof(int) * 2 * nb, 0);
         pairs.clear();
     }
+    // SURVEY App. B Q1 / Q2.  on (default): the reference's forms -- flipped baselines of a two-beam pair are
+    // conjugated but their 2 x 2 block is not transposed (cpu_simulate.py:298); the eigenbeam (l, k) term reuses
+    // V_kl(b)^T (:464-468, exact for real basis beams only).  off: V_ji(b) = V_ij(-b)^H and
+    // V_lk(b) = conj(V_kl(-b))^T -- the transform is evaluated at -b as well.
+    bool reference_compat = true;
+    void set_reference_compat(int on) override { reference_compat = on != 0; }
     void set_nbeams(int n) override {
         beams.clear();
         beams.resize(n);
@@ -1521,7 +1545,7 @@ class Sim : public SimBase {
                                        pr.trivial ? (const signed char *)nullptr
                                                   : (const signed char *)pr.flip->template as<signed char>(),
                                        (const T *)t1_dec.as<T>(), obase, (int64_t)nt * per_tf, pol_off[0],
-                                       pol_off[1], pol_off[2], pol_off[3], chunk > 0, herm1);
+                                       pol_off[1], pol_off[2], pol_off[3], chunk > 0, herm1, !reference_compat);
                     ev_end(e5, stream);
                     st[4] += (double)pr.n * nplanes;
                     st[6] = g.n2;
@@ -1601,6 +1625,74 @@ class Sim : public SimBase {
         return g;
     }
 
+    // ---- host output, overlapped (reference cpu_simulate.py:843-854 returns a host array) ---------------------
+    // A block of visibilities is 10 GB at C3.  Copied after the last kernel into fresh pageable memory it moves at
+    // ~16 GB/s (first touch of every page included: 0.6 s after 1.6 s of compute).  Instead a helper thread pins
+    // the caller's array in place (hipHostRegister: 22 GB/s measured, CPU work) while this thread queues the run
+    // -- queueing a C3 block blocks on the hardware queue's depth for most of the run, so pinning afterwards would
+    // not overlap anything --, every time step's last kernel records an event, and as soon as the array is pinned
+    // the queueing thread issues, on a separate stream, one asynchronous copy per (channel, finished time step)
+    // behind that step's event (53 GB/s, PCIe Gen5).  Only the last step's copy (0.5 GB, 10 ms) is left when the
+    // kernels end.  FFTVIS_HIP_D2H_OVERLAP=0 or a block under 64 MiB keeps the single copy; so does a buffer the
+    // driver refuses to pin.
+    static size_t drain_min_bytes() {
+        const char *e = std::getenv("FFTVIS_HIP_D2H_OVERLAP");
+        if (e && std::atoi(e) == 0) return (size_t)-1;
+        const char *m = std::getenv("FFTVIS_HIP_D2H_MIN_BYTES");
+        return m ? (size_t)std::atof(m) : ((size_t)64 << 20);
+    }
+    hipEvent_t drain_event(size_t k) {
+        while (drain_events.size() <= k) {
+            hipEvent_t e;
+            FV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            drain_events.push_back(e);
+        }
+        return drain_events[k];
+    }
+    struct HostPin {
+        std::thread th;
+        std::atomic<int> state{0};  // 0 pinning, 1 pinned, -1 refused (locked-memory limit, exotic mapping)
+        void *p = nullptr;
+        double t_pinned = 0;  // seconds after start() (FFTVIS_HIP_DEBUG_DRAIN)
+        std::chrono::steady_clock::time_point t0;
+        double since() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+        void start(int device, void *ptr, size_t bytes) {
+            p = ptr;
+            t0 = std::chrono::steady_clock::now();
+            th = std::thread([this, device, ptr, bytes] {
+                (void)hipSetDevice(device);
+                const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+                if (e != hipSuccess) (void)hipGetLastError();
+                t_pinned = since();
+                state.store(e == hipSuccess ? 1 : -1, std::memory_order_release);
+            });
+        }
+        bool pinned() const { return state.load(std::memory_order_acquire) == 1; }
+        bool wait() {
+            if (th.joinable()) th.join();
+            return pinned();
+        }
+        ~HostPin() {  // also on the error paths: never leave the caller's memory pinned
+            if (th.joinable()) th.join();
+            if (pinned()) (void)hipHostUnregister(p);
+        }
+    };
+    // queue the copies of the finished time steps items[done ...) behind their events
+    void drain_flush(void *out, const cplx<T> *dout, int nt, int nf, int64_t per_tf, const std::vector<DrainItem> &items,
+                     size_t &done) {
+        if (!copy_stream) FV_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        cplx<T> *hout = static_cast<cplx<T> *>(out);
+        for (; done < items.size(); ++done) {
+            const DrainItem &it = items[done];
+            FV_HIP(hipStreamWaitEvent(copy_stream, it.ev, 0));
+            for (int f = 0; f < nf; ++f) {
+                const int64_t off = ((int64_t)f * nt + it.t) * per_tf;
+                FV_HIP(hipMemcpyAsync(hout + off, dout + off, sizeof(cplx<T>) * (size_t)it.n * per_tf,
+                                      hipMemcpyDeviceToHost, copy_stream));
+            }
+        }
+    }
+
     void run(int t0, int t1, int f0, int f1, void *out, int out_on_device) override {
         FV_HIP(hipSetDevice(device));
         FV_REQUIRE(nsrc >= 0 && !rots.empty() && !freqs.empty() && nbls > 0 && !pairs.empty(),
@@ -1628,6 +1720,11 @@ class Sim : public SimBase {
         // Baselines not covered by any pair stay zero (reference zero-initialises, :909-911).
         FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
         reserve_mhist(sizeof(int) * rots.size() * std::max(1, src_chunks));
+        const bool drain = !out_on_device && out_bytes >= drain_min_bytes();
+        std::vector<DrainItem> drain_items;
+        size_t drained = 0;
+        HostPin pin;
+        if (drain) pin.start(device, out, out_bytes);
 
         double xc[3], X[3];
         source_box(xc, X);
@@ -1679,6 +1776,9 @@ class Sim : public SimBase {
                 }
                 p.herm = cs >= 4.0e6 && cs <= 1.5 * ct ? mode : 0;
             }
+            // reference_compat off, eigenbeams: an off-diagonal pair that is not packed gathers its (l, k) term
+            // at -b: its targets need the symmetric box too
+            for (Pair &p : pairs) p.mirror = nbasis && !reference_compat && p.bi != p.bj && !p.herm && p.n > 0;
         }
         int tg_max = 1;  // transforms per frequency on the grid, largest over the pairs
         for (const Pair &p : pairs)
@@ -1779,6 +1879,7 @@ class Sim : public SimBase {
             if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma)
                 L.nufft.reset(new Nufft3<T>(D, eps, sigma, li < 2 ? L.stream : stream));
             L.nufft->err_oob = d_err.as<int>();
+            L.nufft->transpose_flipped = !reference_compat;
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
             L.d_az.reserve(sizeof(T) * cap);
             L.d_za.reserve(sizeof(T) * cap);
@@ -1813,7 +1914,22 @@ class Sim : public SimBase {
                 ch = 0;
                 tnext += nm;
             }
-            if (nsrc == 0 || sn <= 0) continue;  // nothing above the horizon: the block stays zero (:945-946)
+            // host output: once the last chunk of these time steps is queued, an event marks them finished
+            auto close_time = [&]() {
+                if (!drain || chunk != nch - 1) return;
+                if (nlanes > 1 && !pipe) {  // free-running lanes: the step's chunks may sit on either stream
+                    FV_HIP(hipEventRecord(lanes[1].done, lanes[1].stream));
+                    FV_HIP(hipStreamWaitEvent(stream, lanes[1].done, 0));
+                }
+                const hipEvent_t ev = drain_event(drain_items.size());
+                FV_HIP(hipEventRecord(ev, stream));  // pipelined and single-lane runs: every big kernel is on `stream`
+                drain_items.push_back({ev, tu - t0, nm});
+                if (pin.pinned()) drain_flush(out, dout, nt, nf, per_tf, drain_items, drained);
+            };
+            if (nsrc == 0 || sn <= 0) {  // nothing above the horizon: the block stays zero (:945-946)
+                close_time();
+                continue;
+            }
             const int64_t unit = lane_serial++;
             Lane *Ls[2];
             if (gang) {
@@ -1940,14 +2056,21 @@ class Sim : public SimBase {
                     size_t e5 = ev_begin(TM_INTERP, ls);
                     BasisTerm bt{d_coefs.p, d_ant1.as<int>(), d_ant2.as<int>(), pr.bi, pr.bj, nbasis,
                                  (int)freqs.size(), fa};
+                    // exact eigenbeam symmetry (reference_compat off): the (l, k) term of an off-diagonal pair of
+                    // complex basis beams comes from a second gather at -b (all-real pairs: packed, exact already)
+                    const int nparts = nbasis && !reference_compat && pr.bi != pr.bj && !pr.herm ? 2 : 1;
                     if (!fused)
                         for (int m = 0; m < nm; ++m)
-                            Ls[m]->nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
-                                  D > 2 ? d_bls.as<T>() + 2 * nbls : nullptr,
-                                  pr.trivial ? nullptr : pr.idx->template as<int>(),
-                                  pr.trivial ? nullptr : pr.flip->template as<signed char>(),
-                                  d_freqs.as<double>() + fa, nfg, tg, obase + (int64_t)m * per_tf,
-                                  (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr, pr.herm);
+                            for (int part = 1; part <= nparts; ++part) {
+                                bt.part = nparts == 2 ? part : 0;
+                                bt.negate = nparts == 2 && part == 2;
+                                Ls[m]->nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
+                                      D > 2 ? d_bls.as<T>() + 2 * nbls : nullptr,
+                                      pr.trivial ? nullptr : pr.idx->template as<int>(),
+                                      pr.trivial ? nullptr : pr.flip->template as<signed char>(),
+                                      d_freqs.as<double>() + fa, nfg, tg, obase + (int64_t)m * per_tf,
+                                      (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr, pr.herm);
+                            }
                     ev_end(e5, ls);
                     st[4] += (double)pr.n * ntrans * nm * (pr.herm ? 2 : 1);  // footprints: packed transforms are read at s and -s
                     st[6] = nufft->geo.d[0].n2;
@@ -1960,14 +2083,32 @@ class Sim : public SimBase {
                 if (!heavy_recorded) FV_HIP(hipEventRecord(L0.heavy_done, ls));
                 L0.heavy_pending = true;
             }
+            close_time();
         }
         if (nlanes > 1 && !pipe) {  // join: everything queued on the main stream afterwards sees both lanes
             FV_HIP(hipEventRecord(lanes[1].done, lanes[1].stream));
             FV_HIP(hipStreamWaitEvent(stream, lanes[1].done, 0));
         }
         if (!out_on_device) {
-            FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
-            FV_HIP(hipStreamSynchronize(stream));
+            if (drain && pin.wait()) {
+                const bool dbg = std::getenv("FFTVIS_HIP_DEBUG_DRAIN") != nullptr;
+                const double t_queued = pin.since();
+                const size_t early = drained;
+                drain_flush(out, dout, nt, nf, per_tf, drain_items, drained);
+                if (dbg) {
+                    FV_HIP(hipStreamSynchronize(stream));
+                    std::fprintf(stderr, "drain: run queued %.3f s, pinned %.3f s, kernels done %.3f s, ", t_queued,
+                                 pin.t_pinned, pin.since());
+                }
+                FV_HIP(hipStreamSynchronize(copy_stream));
+                FV_HIP(hipStreamSynchronize(stream));
+                if (dbg)
+                    std::fprintf(stderr, "copies done %.3f s (%zu of %zu time-step items queued before the end)\n",
+                                 pin.since(), early, drain_items.size());
+            } else {
+                FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
+                FV_HIP(hipStreamSynchronize(stream));
+            }
             if (timing_level) ev_collect();
             check_errors();
         }

@@ -167,6 +167,11 @@ class SimHandle:
         _lib.check(self._L.fv_sim_set_beam_pairs(self._h, len(pairs), _lib.ptr(bi), _lib.ptr(bj),
                                                  _lib.ptr(off), _lib.ptr(idx), _lib.ptr(flp)))
 
+    def set_reference_compat(self, on: bool = True):
+        """The reference's forms for flipped two-beam baselines / the eigenbeam (l, k) term, or the exact ones
+        (fv_sim_set_reference_compat)."""
+        _lib.check(self._L.fv_sim_set_reference_compat(self._h, int(bool(on))))
+
     def set_chunking(self, nchunks: int = 1, source_buffer: float = 1.0):
         """Source chunks per time step and the above-horizon buffer fraction (fv_sim_set_chunking)."""
         _lib.check(self._L.fv_sim_set_chunking(self._h, int(nchunks), float(source_buffer)))
@@ -288,6 +293,7 @@ class GPUSimulationEngine(SimulationEngine):
         freq_idx: slice = slice(None),
         use_feed: str = "x",
         catalog_device=None,
+        reference_compat: bool = True,
     ) -> np.ndarray:
         """Simulate visibilities on the GPU.
 
@@ -315,6 +321,11 @@ class GPUSimulationEngine(SimulationEngine):
           reference gpu/nufft.py:38): accepted, unused;
         * ``beam_coefs`` (eigenbeams): like the reference, the (l, k) term reuses V_kl transposed
           (exact for real-valued basis beams, reference cpu_simulate.py:464-468);
+        * ``reference_compat`` (extra, default True = the reference's arithmetic): False switches the two places
+          where the reference departs from the exact symmetry of the visibilities to the
+          exact forms -- flipped baselines of a two-beam polarized pair become V_ij(-b)^H (conjugated AND feed
+          block transposed; the reference only conjugates, cpu_simulate.py:298), and the eigenbeam (l, k) term
+          becomes conj(V_kl(-b))^T (one more gather at -b; exact for complex basis beams too);
         * ``beam_spline_opts``: order 1 (bilinear, also when None) or 3 (cubic B-spline; ``kx/ky``
           of ``az_za_simple`` are read the same way -- both interpolation functions of the reference
           are regular-grid splines of that order and map onto the same device interpolant); other
@@ -427,6 +438,7 @@ class GPUSimulationEngine(SimulationEngine):
                 h.set_array(R.astype(float), bls.astype(float), is_coplanar)
             h.set_beams(beam_list, freqs.astype(float), beam_order, use_feed)
             h.set_chunking(min(nchunks, max(nsrc, 1)), float(source_buffer))
+            h.set_reference_compat(reference_compat)
             if use_basis:
                 h.set_basis(beam_coefs, ant1_idxs, ant2_idxs)
             else:

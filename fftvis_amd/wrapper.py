@@ -96,6 +96,7 @@ def simulate_vis(
     beam_coefs: np.ndarray = None,
     device: int = 0,
     coord_mgr=None,
+    reference_compat: bool = True,
 ) -> np.ndarray:
     """Visibilities (nfreqs, ntimes, nbls) or (nfreqs, ntimes, 2, 2, nbls); arguments as the
     reference's ``simulate_vis`` (wrapper.py:85-238).
@@ -106,7 +107,8 @@ def simulate_vis(
     feed of an E-field beam whose power an unpolarized run uses (wrapper.py:278-279).  ``coord_method``
     defaults to the reference's "CoordinateRotationERFA": the engine builds matvis' manager for it as the CPU
     engine does (cpu_simulate.py:686-709; matvis / astropy imported on first use) unless a ready one is passed
-    as ``coord_mgr=``; see ``GPUSimulationEngine.simulate``."""
+    as ``coord_mgr=``; ``reference_compat=False`` (extra) replaces the reference's forms for flipped two-beam
+    baselines and the eigenbeam (l, k) term by the exact ones; see ``GPUSimulationEngine.simulate``."""
     if eps is None:
         eps = default_accuracy_dict[precision]  # wrapper.py:241-242
     ants = {k: np.array(v) for k, v in ants.items()}
@@ -130,5 +132,5 @@ def simulate_vis(
         coord_method=coord_method, coord_method_params=coord_method_params,
         force_use_type3=force_use_type3, force_use_ray=force_use_ray, trace_mem=trace_mem,
         nchunks=nchunks, source_buffer=source_buffer, beam_coefs=beam_coefs,
-        coord_mgr=coord_mgr, use_feed=use_feed,
+        coord_mgr=coord_mgr, use_feed=use_feed, reference_compat=reference_compat,
     )

@@ -174,6 +174,14 @@ int fv_sim_set_beam_pairs(fv_sim *h, int npairs, const int *bi, const int *bj, c
 int fv_sim_set_basis(fv_sim *h, int nant, int nbasis, int nfreq, const void *coefs, const int *ant1,
                      const int *ant2);
 
+/* Two places where the reference's arithmetic differs from the exact symmetry of the visibilities (SURVEY
+ * App. B Q1 / Q2).  on != 0 (the default): as the reference -- (1) a flipped baseline of a two-beam polarized pair
+ * is evaluated at -b and conjugated, its 2 x 2 feed block NOT transposed (cpu_simulate.py:271,298); (2) the
+ * eigenbeam (l, k) term reuses V_kl(b) transposed (:464-468), exact for real-valued basis beams only.
+ * on == 0: (1) V_ji(b) = V_ij(-b)^H, conjugated and transposed; (2) V_lk(b) = conj(V_kl(-b))^T -- one more
+ * gather at -b per off-diagonal term of complex basis beams.  Sticky on the handle; takes effect at the next run. */
+int fv_sim_set_reference_compat(fv_sim *h, int on);
+
 /* Source-axis chunking: the `for chunk in range(nchunks)` loop inside the reference's time loop
  * (cpu_simulate.py:939-946; visibilities accumulate with += over chunks, :1024,1069) and matvis'
  * source_buffer (cpu_simulate.py:693-704: the above-horizon arrays of a chunk hold

@@ -232,9 +232,12 @@ def cpu_nufft2d_type1(x, y, weights, n_modes, index, eps=None, **_):
 
 def run_nufft(
     apparent_coherency, topo, uvw, bls, flipped, bls_idxs, use_type1, is_coplanar,
-    tx, ty, type1_n_modes, nfeeds,
+    tx, ty, type1_n_modes, nfeeds, reference_compat=True,
 ):
-    """Dispatch + flip/conj + reshape/swapaxes (cpu_simulate.py:205-300)."""
+    """Dispatch + flip/conj + reshape/swapaxes (cpu_simulate.py:205-300).
+
+    ``reference_compat=False``: a flipped baseline of a two-beam pair is V_ji(b) =
+    V_ij(-b)^H -- conjugated AND its feed block transposed; the reference conjugates only (:298)."""
     nbls_here = len(bls_idxs)
     flipped = np.asarray(flipped, dtype=bool)
     if use_type1:
@@ -249,15 +252,21 @@ def run_nufft(
                 topo[0], topo[1], topo[2], apparent_coherency, _uvw[0], _uvw[1], _uvw[2]
             )
     v = np.where(flipped, np.conj(v), v)  # :298
-    return np.swapaxes(v.reshape(nfeeds, nfeeds, nbls_here), 2, 0)  # :300
+    out = np.swapaxes(v.reshape(nfeeds, nfeeds, nbls_here), 2, 0)  # :300
+    if not reference_compat and nfeeds > 1:
+        out = np.where(flipped[:, None, None], out.swapaxes(1, 2), out)
+    return out
 
 
 def compute_basis_visibilities(
     beam_evaluations, flux_here, ant1_idxs, ant2_idxs, beam_coefs, freqidx, topo, uvw,
     bls, tx, ty, nbls, nfeeds, use_type1, is_coplanar, type1_n_modes,
-    polarized=False, polarized_sky_model=False,
+    polarized=False, polarized_sky_model=False, reference_compat=True,
 ):
-    """Eigenbeam path (cpu_simulate.py:303-470)."""
+    """Eigenbeam path (cpu_simulate.py:303-470).
+
+    ``reference_compat=False``: the (l, k) term is V_lk(b) = conj(V_kl(-b))^T, exact for
+    complex basis beams; the reference reuses V_kl(b)^T (:464-468), exact only for real-valued ones."""
     K = len(beam_evaluations)
     vis_out = np.zeros((nbls, nfeeds, nfeeds), dtype=complex)
     flipped = np.zeros(nbls, dtype=bool)  # :403
@@ -275,8 +284,14 @@ def compute_basis_visibilities(
                 tx, ty, type1_n_modes, nfeeds,
             )
             vis_out += (a1[:, k] * a2[:, l])[:, None, None] * vkl  # :461-462
-            if l != k:
+            if l != k and reference_compat:
                 vis_out += (a1[:, l] * a2[:, k])[:, None, None] * vkl.swapaxes(1, 2)  # :464-468
+            elif l != k:
+                vm = run_nufft(
+                    phi, topo, uvw, bls, ~flipped, bls_idxs, use_type1, is_coplanar,
+                    tx, ty, type1_n_modes, nfeeds,
+                )  # conj(V_kl(-b)), every baseline "flipped"
+                vis_out += (a1[:, l] * a2[:, k])[:, None, None] * vm.swapaxes(1, 2)
     return vis_out
 
 
@@ -647,7 +662,7 @@ def evaluate_vis_chunk(
     time_idx, freq_idx, beam_list, coord_mgr, rotation_matrix, antnums, baselines, bls,
     freqs, nfeeds, beam_idx=None, polarized=False, polarized_sky_model=False,
     is_coplanar=False, nchunks=1, beam_coefs=None, use_type1=False, basis_matrix=None,
-    type1_n_modes=None,
+    type1_n_modes=None, reference_compat=True,
 ):
     """_evaluate_vis_chunk (cpu_simulate.py:856-1071), type-3 and type-1 branches.
 
@@ -693,7 +708,7 @@ def evaluate_vis_chunk(
                     vis[tloc, :, :, :, floc] += compute_basis_visibilities(
                         bev, flux, a1, a2, beam_coefs, fi, topo, uvw, bls, tx, ty,
                         nbls, nfeeds, use_type1, is_coplanar, type1_n_modes, polarized,
-                        polarized_sky_model,
+                        polarized_sky_model, reference_compat,
                     )  # :998-1024
                 else:
                     for bi, bj in pairs:  # :1030
@@ -705,7 +720,7 @@ def evaluate_vis_chunk(
                         )
                         v = run_nufft(
                             c, topo, uvw, bls, pair_flip[(bi, bj)], idxs, use_type1,
-                            is_coplanar, tx, ty, type1_n_modes, nfeeds,
+                            is_coplanar, tx, ty, type1_n_modes, nfeeds, reference_compat,
                         )
                         vis[tloc, idxs, :, :, floc] += v  # :1069
     return vis
@@ -714,7 +729,7 @@ def evaluate_vis_chunk(
 def simulate(
     ants, freqs, fluxes, beam_list, ra, dec, times, telescope_loc, baselines=None,
     beam_idx=None, polarized=False, flat_array_tol=1e-6, nchunks=1, beam_coefs=None,
-    coord_mgr=None, force_use_type3=True,
+    coord_mgr=None, force_use_type3=True, reference_compat=True,
 ):
     """CPUSimulationEngine.simulate (cpu_simulate.py:537-854), nprocesses=1, precision=2;
     ``force_use_type3=False`` takes the reference's type-1 branch for griddable flat arrays
@@ -758,6 +773,7 @@ def simulate(
         nfeeds, beam_idx=beam_idx, polarized=polarized, polarized_sky_model=pol_sky,
         is_coplanar=is_coplanar, nchunks=nchunks, beam_coefs=beam_coefs,
         use_type1=is_gridded, basis_matrix=basis_matrix, type1_n_modes=n_modes,
+        reference_compat=reference_compat,
     )
     if polarized:
         return np.transpose(vis, (4, 0, 2, 3, 1))  # :851

@@ -37,6 +37,7 @@ def oracle_simulate(cfg):
         cfg["telescope_loc"], baselines=cfg.get("baselines"), beam_idx=cfg.get("beam_idx"),
         polarized=cfg["polarized"], beam_coefs=cfg.get("beam_coefs"),
         force_use_type3=cfg.get("force_use_type3", True),
+        reference_compat=cfg.get("reference_compat", True),
     )
 
 

@@ -324,6 +324,51 @@ def test_bench_gpus_n_starts_its_own_ranks(gpu):
     assert bad.returncode != 0 and "rank(s) joined" in bad.stderr + bad.stdout
 
 
+def _band_block(name, f0, f1, ntimes, seed=0):
+    """Channels [f0, f1) of the FULL band of a BASELINE configuration (its channel spacing, hence its frequency
+    groups), the full catalog and every baseline, ``ntimes`` time steps."""
+    _, ns, nf, _, _, _ = synth.CONFIGS[name]
+    cfg = synth.make_config(name, nsrc=1000, nfreq=2, ntimes=ntimes)  # skeleton: array, times, baselines
+    freqs = np.linspace(100e6, 200e6, nf)[f0:f1]
+    cfg["ra"], cfg["dec"], cfg["fluxes"] = synth.catalog(ns, freqs, seed)
+    cfg["freqs"] = freqs
+    cfg["beam"] = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs), freqs)
+    return cfg
+
+
+@pytest.mark.parametrize("name,f0,f1,ntimes,nsub", [("C3", 96, 128, 2, 16), ("C3", 0, 32, 2, 16), ("C4", 240, 256, 1, 8)])
+def test_launches_the_bench_times_are_parity_checked(gpu, monkeypatch, name, f0, f1, ntimes, nsub):
+    """what the driver's bench line times -- C3 / C4 geometry, the full catalog, all
+    61 075 baselines on the device, frequency groups of 8 / 16 / 24 packed transforms under the default grid
+    budget (k_spread2d<.., 8|16> at C3's density, k_spread2d_cg<.., 16> at C4's 10^6 sources), gang launches as
+    the engine picks them -- checked: a subset of baselines against the CPU oracle (exact sums), ALL baselines
+    against the four-transform run (FFTVIS_HIP_NO_HERMITIAN=1: different launches, same answer)."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    cfg = _band_block(name, f0, f1, ntimes)
+    nch = f1 - f0
+    gpu_simulate.release_handles()
+    monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))  # keep the handle: its counters are read below
+    v = fftvis_amd.simulate_vis(**cfg)
+    assert v.shape == (nch, ntimes, 2, 2, 61075) and np.isfinite(v).all()
+    (h,) = gpu_simulate._IDLE_HANDLES.values()
+    st = h.stats()
+    # launches are counted per (time, frequency group): the groups hold 8, 16 or 24 packed transforms
+    per_launch = 2.0 * nch * ntimes / st["spread_launches"]
+    assert 8 <= per_launch <= 24 and st["spread_launches"] >= 2 * ntimes, st
+    sub = sorted(np.random.default_rng(17).choice(61075, nsub, replace=False))
+    exact = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
+    assert rel_l2(v[..., sub], exact) < TOL
+    monkeypatch.setenv("FFTVIS_HIP_NO_HERMITIAN", "1")
+    plain = fftvis_amd.simulate_vis(**cfg)
+    monkeypatch.delenv("FFTVIS_HIP_NO_HERMITIAN")
+    assert 0 < rel_l2(v, plain) < TOL
+    for a in range(2):
+        for b in range(2):
+            assert rel_l2(v[:, :, a, b], plain[:, :, a, b]) < 4 * TOL, (a, b)
+    gpu_simulate.release_handles()
+
+
 def test_hermitian_packing_matches_four_transforms(gpu, monkeypatch):
     """Single-beam polarized runs on large grids pack their Hermitian strengths into two transforms per
     frequency (c_00 + i c_11, c_01) and rebuild the four products from the baseline and its mirror image
