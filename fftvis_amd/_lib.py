@@ -41,11 +41,13 @@ SYMBOLS = {
     "fv_apparent_coherency": (c_int, [c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "fv_inplace_rot": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64]),
+    "fv_astrom_topo": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "fv_sim_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_double, c_double, c_int]),
     "fv_sim_destroy": (c_int, [c_void_p]),
     "fv_sim_set_sources": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int]),
     "fv_sim_set_times": (c_int, [c_void_p, c_int, c_void_p]),
     "fv_sim_set_topo": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int]),
+    "fv_sim_set_astrom": (c_int, [c_void_p, c_int, c_void_p]),
     "fv_sim_set_freqs": (c_int, [c_void_p, c_int, c_void_p]),
     "fv_sim_set_array": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
     "fv_sim_set_array_type1": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),

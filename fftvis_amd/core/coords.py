@@ -62,3 +62,56 @@ class SiderealRotation:
         R[:, 1, 0], R[:, 1, 1], R[:, 1, 2] = -sp * cl, -sp * sl, cp
         R[:, 2, 0], R[:, 2, 1], R[:, 2, 2] = cp * cl, cp * sl, sp
         return R
+
+
+# ---- per-time astrometry contexts for the device-side coordinate manager (fv_sim_set_astrom) ---------------------
+# 31 float64 per time, ERFA's eraASTROM in its field order:
+#   pmt, eb[3], eh[3], em, v[3], bm1, bpn[9], along, phi, xpl, ypl, sphi, cphi, diurab, eral, refa, refb
+ASTROM_LEN = 31
+
+
+def sidereal_astrom_context(times, telescope_loc) -> np.ndarray:
+    """(ntimes, 31) contexts under which the device-side astrometry reduces to ``SiderealRotation``: no deflection
+    (Sun at 1e30 au), no aberration (v = 0), identity bias-precession-nutation, no polar motion / diurnal
+    aberration / refraction, and eral = GMST + longitude."""
+    jd = julian_dates(times)
+    lat, lon = latlon_of(telescope_loc)
+    c = np.zeros((jd.size, ASTROM_LEN))
+    c[:, 4] = 1.0
+    c[:, 7] = 1e30
+    c[:, 11] = 1.0
+    c[:, 12:21] = np.eye(3).ravel()
+    c[:, 21], c[:, 22] = lon, lat
+    c[:, 25], c[:, 26] = np.sin(lat), np.cos(lat)
+    c[:, 28] = np.mod(gmst_rad(jd) + lon, 2 * np.pi)
+    return c
+
+
+def erfa_astrom_context(times, telescope_loc, pressure=0.0) -> np.ndarray:
+    """(ntimes, 31) contexts from astropy / ERFA -- the astrometry context astropy's own ICRS -> AltAz
+    transformation uses (``erfa_astrom.get().apco(AltAz(obstime, location, pressure))``, i.e. ``erfa.apco`` with the
+    IERS Earth-orientation data astropy carries), one per time.  This is source-independent work of microseconds per
+    time; the per-source part then runs on the device.  astropy is a dependency of the reference, not of this
+    backend: imported here, on request only; raises ValueError without it."""
+    try:
+        from astropy import units as un
+        from astropy.coordinates import AltAz, EarthLocation
+        from astropy.coordinates.erfa_astrom import erfa_astrom
+        from astropy.time import Time
+    except ImportError as e:
+        raise ValueError(f"device_astrometry=True needs astropy ({e}); pass astrom= contexts built elsewhere, or "
+                         "coord_mgr=, or coord_method='SiderealRotation'") from e
+    t = times if hasattr(times, "jd") else Time(np.asarray(times, dtype=float), format="jd")
+    loc = telescope_loc
+    if not isinstance(loc, EarthLocation):
+        lat, lon = latlon_of(loc)
+        height = float(loc[2]) if not hasattr(loc, "lat") and len(loc) > 2 else 0.0
+        loc = EarthLocation.from_geodetic(lon * un.rad, lat * un.rad, height * un.m)
+    out = np.zeros((len(t), ASTROM_LEN))
+    for i in range(len(t)):
+        a = erfa_astrom.get().apco(AltAz(obstime=t[i], location=loc, pressure=pressure * un.hPa))
+        row = [a["pmt"], *np.ravel(a["eb"]), *np.ravel(a["eh"]), a["em"], *np.ravel(a["v"]), a["bm1"],
+               *np.ravel(a["bpn"]), a["along"], a["phi"], a["xpl"], a["ypl"], a["sphi"], a["cphi"], a["diurab"],
+               a["eral"], a["refa"], a["refb"]]
+        out[i] = np.asarray(row, dtype=float).ravel()
+    return out

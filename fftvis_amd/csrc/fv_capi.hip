@@ -340,6 +340,25 @@ static void inplace_rot_host(int device, const double *rot, void *b, int64_t n) 
     FV_HIP(hipGetLastError());
 }
 
+template <typename T>
+static void astrom_topo_host(int device, const double *astrom, int64_t n, const void *eq, void *out) {
+    FV_REQUIRE(astrom && n >= 0 && ((eq && out) || n == 0), "bad astrom_topo arrays");
+    FV_HIP(hipSetDevice(device));
+    if (n == 0) return;
+    Astrom a;
+    std::memcpy(&a, astrom, sizeof(a));
+    FV_REQUIRE(a.em > 0 && a.bm1 > 0, "astrometry context: em and bm1 must be positive");
+    StreamGuard sg;
+    DevBuf din, dout;
+    din.reserve(sizeof(T) * 3 * n);
+    dout.reserve(sizeof(T) * 3 * n);
+    FV_HIP(hipMemcpyAsync(din.p, eq, sizeof(T) * 3 * n, hipMemcpyHostToDevice, sg.s));
+    hipLaunchKernelGGL(k_astrom_topo<T>, dim3(cdiv(n, 256)), dim3(256), 0, sg.s, n, n, (int64_t)0, din.as<T>(), a, dout.as<T>());
+    FV_HIP(hipMemcpyAsync(out, dout.p, sizeof(T) * 3 * n, hipMemcpyDeviceToHost, sg.s));
+    FV_HIP(hipStreamSynchronize(sg.s));
+    FV_HIP(hipGetLastError());
+}
+
 }  // namespace fv
 
 using namespace fv;
@@ -452,6 +471,16 @@ int fv_inplace_rot(int device, int precision, const double *rot, void *b, int64_
     });
 }
 
+int fv_astrom_topo(int device, int precision, const double *astrom, int64_t n, const void *eq, void *topo) {
+    return guarded([&] {
+        FV_REQUIRE(precision == 1 || precision == 2, "precision must be 1 or 2");
+        if (precision == 2)
+            astrom_topo_host<double>(device, astrom, n, eq, topo);
+        else
+            astrom_topo_host<float>(device, astrom, n, eq, topo);
+    });
+}
+
 int fv_sim_create(fv_sim **h, int device, int precision, double eps, double upsampfac,
                   int polarized) {
     return guarded([&] {
@@ -486,6 +515,9 @@ int fv_sim_set_sources(fv_sim *h, int64_t nsrc, int nfreq, const void *eq, const
 }
 int fv_sim_set_times(fv_sim *h, int ntimes, const double *rot) {
     FV_SIM_CALL(FV_REQUIRE(ntimes >= 0 && (rot || !ntimes), "bad times"); h->impl->set_times(ntimes, rot));
+}
+int fv_sim_set_astrom(fv_sim *h, int ntimes, const double *astrom) {
+    FV_SIM_CALL(FV_REQUIRE(ntimes >= 1 && astrom, "bad astrometry contexts"); h->impl->set_astrom(ntimes, astrom));
 }
 int fv_sim_set_topo(fv_sim *h, int ntimes, int64_t nsrc, const void *topo, int on_device) {
     FV_SIM_CALL(FV_REQUIRE(ntimes >= 1 && topo, "bad topo"); h->impl->set_topo(ntimes, nsrc, topo, on_device));

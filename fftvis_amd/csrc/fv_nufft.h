@@ -1207,14 +1207,15 @@ __global__ void k_fg_build(int64_t N, int nfg, const T *__restrict__ btx, const 
 //     w^{q p} sum_m x[q + m Q] c^m,      c = w^{Q p} = exp(2 pi i p / P)  (uniform),
 // over the m with -n_in/2 <= q + m Q < n_in - n_in/2: ceil(n_in / Q) + 1 sweeps of coalesced loads, one
 // uniform complex factor per sweep (none for p = 0), one per-slot twiddle at the end.
-// INBLK (column mode): the input plane is in 64-byte column blocks (RowDifArgs::in_blk = BLKLOG).
-template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false, bool FOLD = false, bool INBLK = false>
+// INB (column mode): 0 = plain row-major input plane; 1 = column blocks of 2^in_blk elements (RowDifArgs::in_blk);
+// 2 = column blocks exactly as wide as the workgroup's RPW columns.
+template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false, bool FOLD = false, int INB = 0>
 __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_MINW12 : 4) void k_rowfft_st(
     const cplx<T> *__restrict__ in0, cplx<T> *__restrict__ out0, const cplx<T> *__restrict__ tw, RowDifArgs a,
     FusedArgs fz) {
     static_assert(!FUSED || COL, "the fused gather rides on the column-mode last pass");
     static_assert(!FOLD || (!FUSED && NLD == (1 << (LOGQ == 9 ? 3 : 4))), "folding runs on full pass-1 operands");
-    static_assert(!INBLK || (COL && !FUSED), "blocked input planes are read by the plain column pass");
+    static_assert(!INB || COL, "blocked input planes are read by the column pass");
     // gang launch: blockIdx.y = 1 runs the same transform on a second pair of buffers
     const cplx<T> *__restrict__ in = blockIdx.y ? static_cast<const cplx<T> *>(a.in1) : in0;
     cplx<T> *__restrict__ out = blockIdx.y ? static_cast<cplx<T> *>(a.out1) : out0;
@@ -1297,33 +1298,34 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
     // the range check does the masking.  Column mode: base = the workgroup's first column, every lane adds its own
     // column's offset and masks by the index -1 (beyond any extent): one compare + select per element instead of
     // clamp + two compares + four selects, and no 64-bit addresses in vector registers.
-    // Column mode, blocked input (INBLK): element (column x, row ia) of a plane sits at
-    // (x >> BLKLOG) (n_in << BLKLOG) + (ia << BLKLOG) + (x & (2^BLKLOG - 1)).  When the workgroup's RPW columns are exactly
-    // one block (ONEBLK: fp64 Q = 2048, fp32 Q <= 1024) that block is ONE contiguous run [ia][column] and a descriptor over
-    // just that run does all the masking -- ia < 0 wraps to a huge offset, ia >= n_in lies past the extent -- so an
-    // address is a single add; padding columns of the last block read allocated memory and are never stored.  Otherwise
-    // one compare + select per element (the bound is 0 for a lane without a column), shifts or a 24-bit multiply
-    // for the index -- no 32-bit integer multiplies (quarter rate) and no exec-mask regions.
-    constexpr int BLKLOG = sizeof(T) == 8 ? 2 : 3;
-    constexpr bool ONEBLK = COL && INBLK && RPW == (1 << BLKLOG);
+    // Column mode, blocked input (INB): element (column x, row ia) of a plane sits at
+    // (x >> b) (n_in << b) + (ia << b) + (x & (2^b - 1)), b = in_blk.  When the workgroup's RPW columns are exactly one
+    // block (INB = 2: every fp64 pass, fp32 up to Q = 1024) that block is ONE contiguous run [ia][column] and a
+    // descriptor over just that run does all the masking -- ia < 0 wraps to a huge offset, ia >= n_in lies past the
+    // extent -- so an address is a single add; padding columns of the last block read allocated memory and are never
+    // stored.  Otherwise one compare + select per element (the bound is 0 for a lane without a column), a shift or a
+    // 24-bit multiply for the index -- no 32-bit integer multiplies (quarter rate) and no exec-mask regions.
+    constexpr bool INBLK = INB != 0, ONEBLK = INB == 2;
+    constexpr int BLK1 = ilog2_c(RPW);  // the block width of INB = 2
+    const int blk = ONEBLK ? BLK1 : a.in_blk;
     const int64_t plane0 = (row0 / a.rpp) * a.in_plane;
-    const int64_t in_base = ONEBLK ? plane0 + ((((row0 % a.rpp) >> BLKLOG) * (int64_t)a.n_in) << BLKLOG)
+    const int64_t in_base = ONEBLK ? plane0 + ((((row0 % a.rpp) >> BLK1) * (int64_t)a.n_in) << BLK1)
                             : INBLK ? plane0
                             : COL   ? plane0 + (row0 % a.rpp) * a.in_row
                                     : (ok ? rplane * a.in_plane + rk * a.in_row : 0);
-    const RowBuf<T> rowin(in + in_base, ONEBLK ? ((int64_t)a.n_in << BLKLOG) : COL ? -1 : (ok ? a.n_in : 0));
+    const RowBuf<T> rowin(in + in_base, ONEBLK ? ((int64_t)a.n_in << BLK1) : COL ? -1 : (ok ? a.n_in : 0));
     const int lane_in = ONEBLK ? r
-                        : INBLK ? (int)((rplane - row0 / a.rpp) * a.in_plane) + ((((int)rk >> BLKLOG) * a.n_in) << BLKLOG) +
-                                      ((int)rk & ((1 << BLKLOG) - 1))
+                        : INBLK ? (int)((rplane - row0 / a.rpp) * a.in_plane) + ((((int)rk >> blk) * a.n_in) << blk) +
+                                      ((int)rk & ((1 << blk) - 1))
                         : COL   ? (int)(rplane * a.in_plane + rk * a.in_row - in_base)
                                 : 0;
     const int in_elem = (int)a.in_elem;
     const unsigned nin_lane = ok ? (unsigned)a.n_in : 0u;
     auto load_in = [&](int ia) -> cplx<T> {
         if constexpr (ONEBLK)
-            return rowin.load((ia << BLKLOG) + lane_in);
+            return rowin.load((ia << BLK1) + lane_in);
         else if constexpr (INBLK)
-            return rowin.load((unsigned)ia < nin_lane ? lane_in + (ia << BLKLOG) : -1);
+            return rowin.load((unsigned)ia < nin_lane ? lane_in + (ia << blk) : -1);
         else if constexpr (COL)
             return rowin.load((unsigned)ia < nin_lane ? lane_in + mul24(ia, in_elem) : -1);
         else
@@ -2039,44 +2041,79 @@ class Nufft3 {
     // blocks fill that tail.  The weight is only a heuristic -- any order is correct.
     // One table per (nbx, nby), kept for the life of the plan: frequency groups cycle through a
     // handful of grid sizes every time step.
-    std::map<std::pair<int, int>, std::unique_ptr<DevBuf>> order_cache;
+    // (Shared between the plans of one simulator -- its lanes cycle through the same geometries -- and filled by a
+    // blocking copy that does not involve the plans' streams: a cold handle met 23 grid sizes x 4 lanes in its first
+    // two time steps, each a weight table of 10^5 entries, a sort and a stream synchronisation: 0.4 s of a 2 s C3 call.)
+    using OrderCache = std::map<std::pair<int, int>, std::unique_ptr<DevBuf>>;
+    std::shared_ptr<OrderCache> order_cache = std::make_shared<OrderCache>();
     const int *order_ptr = nullptr;
-    std::vector<int> order_host;
     void build_block_order() {
         const int nbx = geo.nbin[0], nby = geo.nbin[1], ngx = (int)cdiv(nbx, 4);
-        auto hit = order_cache.find({nbx, nby});
-        if (hit != order_cache.end()) {
+        auto hit = order_cache->find({nbx, nby});
+        if (hit != order_cache->end()) {
             order_ptr = hit->second->template as<int>();
             return;
         }
-        std::vector<std::pair<float, int>> wg((size_t)ngx * nby);
-        for (int by = 0; by < nby; ++by) {
-            const double ry = ((by + 0.5) * (1 << BINLOG) - 0.5 * geo.d[1].na) / (0.5 * geo.d[1].na);
-            for (int gx = 0; gx < ngx; ++gx) {
-                double wsum = 0;
-                for (int k = 0; k < 4; ++k) {
-                    const int bx = gx * 4 + k;
-                    if (bx >= nbx) break;
-                    const double rx = ((bx + 0.5) * (1 << BINLOG) - 0.5 * geo.d[0].na) / (0.5 * geo.d[0].na);
-                    const double r2 = rx * rx + ry * ry;
-                    wsum += r2 < 1.0 ? 1.0 / std::sqrt(std::max(1.0 - r2, 0.02)) : 0.05;
+        std::vector<int> order_host((size_t)ngx * nby);
+        if (order_host.size() > 16384) {
+            // huge grids are HBM-bound and have thousands of groups per CU: raster order keeps their
+            // writes local and the tail is negligible there
+            for (int by = 0; by < nby; ++by)
+                for (int gx = 0; gx < ngx; ++gx) order_host[(size_t)by * ngx + gx] = (by << 16) | gx;
+        } else {
+            std::vector<std::pair<float, int>> wg((size_t)ngx * nby);
+            for (int by = 0; by < nby; ++by) {
+                const double ry = ((by + 0.5) * (1 << BINLOG) - 0.5 * geo.d[1].na) / (0.5 * geo.d[1].na);
+                for (int gx = 0; gx < ngx; ++gx) {
+                    double wsum = 0;
+                    for (int k = 0; k < 4; ++k) {
+                        const int bx = gx * 4 + k;
+                        if (bx >= nbx) break;
+                        const double rx = ((bx + 0.5) * (1 << BINLOG) - 0.5 * geo.d[0].na) / (0.5 * geo.d[0].na);
+                        const double r2 = rx * rx + ry * ry;
+                        wsum += r2 < 1.0 ? 1.0 / std::sqrt(std::max(1.0 - r2, 0.02)) : 0.05;
+                    }
+                    wg[(size_t)by * ngx + gx] = {(float)wsum, (by << 16) | gx};
                 }
-                wg[(size_t)by * ngx + gx] = {(float)wsum, (by << 16) | gx};
             }
-        }
-        // huge grids are HBM-bound and have thousands of groups per CU: raster order keeps their
-        // writes local and the tail is negligible there
-        if (wg.size() <= 16384)
             std::stable_sort(wg.begin(), wg.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-        order_host.resize(wg.size());
-        for (size_t i = 0; i < wg.size(); ++i) order_host[i] = wg[i].second;
+            for (size_t i = 0; i < wg.size(); ++i) order_host[i] = wg[i].second;
+        }
         std::unique_ptr<DevBuf> buf(new DevBuf);
         buf->reserve(sizeof(int) * order_host.size());
-        FV_HIP(hipMemcpyAsync(buf->p, order_host.data(), sizeof(int) * order_host.size(),
-                              hipMemcpyHostToDevice, stream));
-        FV_HIP(hipStreamSynchronize(stream));  // once per grid size; keeps order_host reusable
+        FV_HIP(hipMemcpy(buf->p, order_host.data(), sizeof(int) * order_host.size(), hipMemcpyHostToDevice));
         order_ptr = buf->template as<int>();
-        order_cache[{nbx, nby}] = std::move(buf);
+        (*order_cache)[{nbx, nby}] = std::move(buf);
+    }
+
+    // Upper bound (cells per transform) of the grid buffers a geometry will need: the same grid sizing as
+    // set_geometry, host arithmetic only.  Lets a run size its buffers once, before any kernel is queued -- growing
+    // them group by group means a hipFree + hipMalloc of gigabytes, each a device synchronisation, in the middle of
+    // the first time step (0.45 s of a cold 2 s C3 call).
+    int64_t plan_buffer_cells(const double *X, const double *B, double scale_max, int *na_max = nullptr,
+                              int *n2_max = nullptr) const {
+        DimGeom g[3];
+        for (int d = 0; d < dim; ++d) {
+            g[d].X = X[d];
+            g[d].B = B[d];
+            set_dim_geom(g[d], sigma, ker.w, scale_max);
+            if (d > 0) cap_column_q(g[d]);
+            g[d].rm = d != dim - 1 && !debug_switch_natural_order();
+            if (na_max) na_max[d] = std::max(na_max[d], g[d].na);
+            if (n2_max) n2_max[d] = std::max(n2_max[d], g[d].n2);
+        }
+        const int64_t zin = dim > 2 ? g[2].na : 1, zout = dim > 2 ? g[2].nos() : 1;
+        const int64_t pitch = (g[0].nos() + 7) / 8 * 8;
+        return std::max({zin * g[1].na * g[0].na, zin * g[1].na * pitch, zin * pitch * g[1].nos(), zout * pitch * g[1].nos()});
+    }
+    // grid buffers of `bytes_cells` cells in all, and the per-dimension deconvolution / twiddle tables
+    void reserve_buffers(int64_t cells, const int *na_max, const int *n2_max) {
+        buf0.reserve(sizeof(cplx<T>) * (size_t)cells);
+        buf1.reserve(sizeof(cplx<T>) * (size_t)cells);
+        for (int d = 0; d < dim; ++d) {
+            dec[d].reserve(sizeof(T) * (size_t)na_max[d]);
+            tw[d].reserve(sizeof(cplx<T>) * (size_t)n2_max[d]);
+        }
     }
 
     // Bounds -> grid sizes, deconvolution + twiddle tables.
@@ -2225,6 +2262,9 @@ class Nufft3 {
         return v;
     }
 
+    void strengths_buffer_reserve(int64_t cap, int ntrans) {
+        strengths.reserve(sizeof(cplx<T>) * std::max<int64_t>(cap, 1) * ntrans);
+    }
     cplx<T> *strengths_buffer(int ntrans) {
         strengths.reserve(sizeof(cplx<T>) * std::max<int64_t>(M, 1) * ntrans);
         return strengths.as<cplx<T>>();
@@ -2476,14 +2516,16 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         const int need = a.n_in > g.Q ? 16 : 2 * (int)cdiv(a.n_in - a.n_in / 2, s1);
         const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;
         const bool col = a.colmode != 0;
-        FV_REQUIRE(!in_blk || !col || (in_blk == (sizeof(T) == 8 ? 2 : 3) && !fused), "blocked column input: 64-byte blocks");
         FV_REQUIRE(!col || in_elem < (1 << 23), "column pass: row pitch beyond the 24-bit index multiply");
 #define FV_ST_LAUNCH(LQ, COLM, NLD, FUSEDV, FOLDV, FZ)                                                  \
-    if (COLM && in_blk && !FUSEDV) {                                                                   \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, false, FOLDV, COLM>), jobs,                  \
+    if (COLM && in_blk && (1 << in_blk) == a.rpw) {                                                    \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, COLM ? 2 : 0>), jobs,         \
+                           dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FZ);                \
+    } else if (COLM && in_blk) {                                                                       \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, COLM ? 1 : 0>), jobs,         \
                            dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FZ);                \
     } else {                                                                                           \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, false>), jobs,                \
+        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, 0>), jobs,                    \
                            dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FZ);                \
     }
 #define FV_ST_GO(LQ, COLM, NLD)                                                                        \
@@ -2493,8 +2535,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         bool launched = false;                                                                         \
         if constexpr (COLM && LQ <= 10) { /* the fused gather rides on 8-column passes only */          \
             if (fused) {                                                                               \
-                hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, COLM>), jobs,                        \
-                                   dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, *fused); \
+                FV_ST_LAUNCH(LQ, COLM, NLD, COLM, false, *fused)                                       \
                 launched = true;                                                                       \
             }                                                                                          \
         }                                                                                              \

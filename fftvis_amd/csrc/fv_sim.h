@@ -419,6 +419,88 @@ __global__ void k_inplace_rot(Rot9 r, T *__restrict__ b, int64_t n) {
     b[2 * n + j] = (T)(r.m[6] * x + r.m[7] * y + r.m[8] * z);
 }
 
+// ---------------------------------------------------------------------------------------------
+// per-source astrometry from a per-time context (reference cpu_simulate.py:693-709,937)
+// ---------------------------------------------------------------------------------------------
+// ICRS -> observed is a source-independent context per time -- what ERFA keeps in eraASTROM and erfa.apco13 (or
+// astropy's erfa_astrom) fills in microseconds on the host -- applied to every source: light deflection by the Sun,
+// annual aberration, bias-precession-nutation (ICRS -> CIRS: the published algorithm of eraAtciqz = eraLdsun + eraAb +
+// the BPN matrix), then Earth rotation, polar motion, diurnal aberration, the rotation to the local horizon and the
+// A tan z + B tan^3 z refraction (CIRS -> observed: eraAtioq).  The context is taken in eraASTROM's field order so
+// that a caller can hand over the bytes of the array ERFA filled.  One thread per source; arithmetic in fp64 whatever
+// the catalog's precision.  Output: topocentric (east, north, up) unit vectors, the layout of fv_sim_set_topo.
+// PARITY UNPINNED versus ERFA / matvis (neither is in this pipeline): pinned to the numpy restatement in oracle/.
+struct Astrom {
+    double pmt, eb[3], eh[3], em, v[3], bm1, bpn[9], along, phi, xpl, ypl, sphi, cphi, diurab, eral, refa, refb;
+};
+static_assert(sizeof(Astrom) == 31 * sizeof(double), "eraASTROM is 31 doubles");
+
+__device__ inline void astrom_icrs_to_enu(const Astrom &a, double px, double py, double pz, double *enu) {
+    constexpr double SRS = 1.97412574336e-8;  // Schwarzschild radius of the Sun in au
+    // light deflection by the Sun (unit mass; q = p: the source is at infinity)
+    const double em2 = fmax(a.em * a.em, 1.0), dlim = 1e-6 / em2;
+    const double qdqpe = px * (px + a.eh[0]) + py * (py + a.eh[1]) + pz * (pz + a.eh[2]);
+    const double wd = SRS / a.em / fmax(qdqpe, dlim);
+    const double ex = a.eh[1] * pz - a.eh[2] * py, ey = a.eh[2] * px - a.eh[0] * pz, ez = a.eh[0] * py - a.eh[1] * px;  // e x q
+    double qx = px + wd * (py * ez - pz * ey), qy = py + wd * (pz * ex - px * ez), qz = pz + wd * (px * ey - py * ex);  // p + w p x (e x q)
+    // annual aberration (relativistic, with the Sun's potential term)
+    const double pdv = qx * a.v[0] + qy * a.v[1] + qz * a.v[2];
+    const double w1 = 1.0 + pdv / (1.0 + a.bm1), w2 = SRS / a.em;
+    double ax = qx * a.bm1 + w1 * a.v[0] + w2 * (a.v[0] - pdv * qx);
+    double ay = qy * a.bm1 + w1 * a.v[1] + w2 * (a.v[1] - pdv * qy);
+    double az = qz * a.bm1 + w1 * a.v[2] + w2 * (a.v[2] - pdv * qz);
+    const double rn = 1.0 / sqrt(ax * ax + ay * ay + az * az);
+    ax *= rn;
+    ay *= rn;
+    az *= rn;
+    // bias-precession-nutation: CIRS
+    const double cx = a.bpn[0] * ax + a.bpn[1] * ay + a.bpn[2] * az;
+    const double cy = a.bpn[3] * ax + a.bpn[4] * ay + a.bpn[5] * az;
+    const double cz = a.bpn[6] * ax + a.bpn[7] * ay + a.bpn[8] * az;
+    // Earth rotation: (-HA, Dec) Cartesian
+    double se, ce;
+    sincos(a.eral, &se, &ce);
+    const double x = ce * cx + se * cy, y = -se * cx + ce * cy, z = cz;
+    // polar motion
+    double sx, cxp, sy, cyp;
+    sincos(a.xpl, &sx, &cxp);
+    sincos(a.ypl, &sy, &cyp);
+    const double xhd = cxp * x + sx * z;
+    const double yhd = sx * sy * x + cyp * y - cxp * sy * z;
+    const double zhd = -sx * cyp * x + sy * y + cxp * cyp * z;
+    // diurnal aberration
+    const double f = 1.0 - a.diurab * yhd;
+    const double xhdt = f * xhd, yhdt = f * (yhd + a.diurab), zhdt = f * zhd;
+    // to the horizon frame (x south -> north is -x, y east, z up)
+    const double xaet = a.sphi * xhdt - a.cphi * zhdt, yaet = yhdt, zaet = a.cphi * xhdt + a.sphi * zhdt;
+    // refraction, A tan z + B tan^3 z with ERFA's guards near the horizon (identity for refa = refb = 0)
+    double r = sqrt(xaet * xaet + yaet * yaet);
+    r = r > 1e-6 ? r : 1e-6;
+    const double zc = zaet > 0.05 ? zaet : 0.05;
+    const double tz = r / zc, wr = a.refb * tz * tz;
+    const double del = (a.refa + wr) * tz / (1.0 + (a.refa + 3.0 * wr) / (zc * zc));
+    const double cosdel = 1.0 - del * del / 2.0, fr = cosdel - del * zc / r;
+    const double xo = xaet * fr, yo = yaet * fr, zo = cosdel * zaet + del * r;
+    const double on = 1.0 / sqrt(xo * xo + yo * yo + zo * zo);
+    enu[0] = yo * on;
+    enu[1] = -xo * on;
+    enu[2] = zo * on;
+}
+
+// sources [off, off + n) of the (3, stride) catalog -> the same positions of a (3, stride) array of ENU vectors
+template <typename T>
+__global__ void k_astrom_topo(int64_t n, int64_t stride, int64_t off, const T *__restrict__ eq, Astrom a,
+                              T *__restrict__ topo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = off + i;
+    double enu[3];
+    astrom_icrs_to_enu(a, (double)eq[j], (double)eq[stride + j], (double)eq[2 * stride + j], enu);
+    topo[j] = (T)enu[0];
+    topo[stride + j] = (T)enu[1];
+    topo[2 * stride + j] = (T)enu[2];
+}
+
 struct StrengthArgs {
     int64_t M;          // capacity of the per-time arrays (stride); live count is *Mp
     int nfg;            // frequencies in this group
@@ -846,6 +928,7 @@ struct SimBase {
                              int on_device) = 0;
     virtual void set_times(int ntimes, const double *rot) = 0;
     virtual void set_topo(int ntimes, int64_t nsrc, const void *topo, int on_device) = 0;
+    virtual void set_astrom(int ntimes, const double *astrom) = 0;
     virtual void set_freqs(int nfreq, const double *freqs) = 0;
     virtual void set_array(const double *R, int64_t nbls, const double *bls, int coplanar) = 0;
     virtual void set_array_type1(const double *basis, int64_t nbls, const int *bls_int, int n_modes) = 0;
@@ -885,6 +968,7 @@ class Sim : public SimBase {
 
     std::vector<Rot9> rots;
     int ntimes_topo = 0;  // > 0: per-time topocentric unit vectors were supplied instead
+    std::vector<Astrom> astroms;  // non-empty: per-time astrometry contexts, applied on the device (k_astrom_topo)
     DevBuf d_topo;        // (ntimes, 3, nsrc) T
     std::vector<double> freqs;
     DevBuf d_freqs;
@@ -946,7 +1030,7 @@ class Sim : public SimBase {
         hipEvent_t prep_done = nullptr, heavy_done = nullptr;  // pipelined mode (see run())
         bool heavy_pending = false;
         std::unique_ptr<Nufft3<T>> nufft;
-        DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scan_tot, d_scan_off;
+        DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scan_tot, d_scan_off, d_enu;
         int binned_ti = -1;
         int64_t binned_serial = -1;
     };
@@ -1091,9 +1175,21 @@ class Sim : public SimBase {
         upload(d_eq, eq, sizeof(T) * 3 * n, on_device);
         upload(d_flux, flux, (pol_sky ? sizeof(T) * 8 : sizeof(T)) * (size_t)n * nfreq, on_device);
     }
+    void set_astrom(int ntimes, const double *astrom) override {
+        mhist_log.clear();
+        ntimes_topo = 0;
+        rots.assign(ntimes, Rot9{{1, 0, 0, 0, 1, 0, 0, 0, 1}});  // the horizon kernels then read finished ENU vectors
+        astroms.resize(ntimes);
+        std::memcpy(astroms.data(), astrom, sizeof(Astrom) * (size_t)ntimes);
+        for (const Astrom &a : astroms) {
+            FV_REQUIRE(a.em > 0 && a.bm1 > 0, "astrometry context: em (Sun distance, au) and bm1 must be positive");
+            for (int i = 0; i < 31; ++i) FV_REQUIRE(std::isfinite(reinterpret_cast<const double *>(&a)[i]), "astrometry context: not finite");
+        }
+    }
     void set_times(int ntimes, const double *rot) override {
         mhist_log.clear();  // entries index the previous configuration's time axis
         ntimes_topo = 0;
+        astroms.clear();
         rots.resize(ntimes);
         for (int i = 0; i < ntimes; ++i) std::memcpy(rots[i].m, rot + 9 * i, 9 * sizeof(double));
     }
@@ -1102,6 +1198,7 @@ class Sim : public SimBase {
         FV_REQUIRE(n == nsrc, "topo source count != catalog (set_sources first)");
         mhist_log.clear();
         ntimes_topo = ntimes;
+        astroms.clear();
         rots.assign(ntimes, Rot9{{1, 0, 0, 0, 1, 0, 0, 0, 1}});
         upload(d_topo, topo, sizeof(T) * 3 * (size_t)n * ntimes, on_device);
     }
@@ -1329,8 +1426,15 @@ class Sim : public SimBase {
         DevBuf &d_blockcnt = L.d_blockcnt, &d_blockoff = L.d_blockoff, &d_scan_tot = L.d_scan_tot,
                &d_scan_off = L.d_scan_off, &d_xyz = L.d_xyz, &d_az = L.d_az, &d_za = L.d_za,
                &d_srcidx = L.d_srcidx;
-        // either R_t . eq on the fly, or topocentric vectors the caller computed
+        // R_t . eq on the fly, topocentric vectors the caller computed, or this time's astrometry context applied to the
+        // chunk's sources first (into the lane's own (3, nsrc) scratch)
         const T *vec = ntimes_topo ? d_topo.as<T>() + (size_t)ti * 3 * nsrc : d_eq.as<T>();
+        if (!astroms.empty()) {
+            L.d_enu.reserve(sizeof(T) * 3 * (size_t)std::max<int64_t>(nsrc, 1));
+            hipLaunchKernelGGL(k_astrom_topo<T>, dim3((unsigned)cdiv(sn, 256)), dim3(256), 0, stream, sn, nsrc, s0,
+                               d_eq.as<T>(), astroms[ti], L.d_enu.template as<T>());
+            vec = L.d_enu.template as<T>();
+        }
         hipLaunchKernelGGL(k_horizon_count<T>, dim3(nblk), dim3(256), 0, stream, sn, nsrc, s0, vec,
                            rots[ti], d_blockcnt.as<int>());
         if (nblk <= 4096) {
@@ -1628,9 +1732,8 @@ class Sim : public SimBase {
     // ---- host output, overlapped (reference cpu_simulate.py:843-854 returns a host array) ---------------------
     // A block of visibilities is 10 GB at C3.  Copied after the last kernel into fresh pageable memory it moves at
     // ~16 GB/s (first touch of every page included: 0.6 s after 1.6 s of compute).  Instead a helper thread pins
-    // the caller's array in place (hipHostRegister: 22 GB/s measured, CPU work) while this thread queues the run
-    // -- queueing a C3 block blocks on the hardware queue's depth for most of the run, so pinning afterwards would
-    // not overlap anything --, every time step's last kernel records an event, and as soon as the array is pinned
+    // the caller's array in place (hipHostRegister: 22 GB/s measured, CPU work) while this thread queues the run,
+    // every time step's last kernel records an event, and as soon as the array is pinned
     // the queueing thread issues, on a separate stream, one asynchronous copy per (channel, finished time step)
     // behind that step's event (53 GB/s, PCIe Gen5).  Only the last step's copy (0.5 GB, 10 ms) is left when the
     // kernels end.  FFTVIS_HIP_D2H_OVERLAP=0 or a block under 64 MiB keeps the single copy; so does a buffer the
@@ -1644,7 +1747,7 @@ class Sim : public SimBase {
     hipEvent_t drain_event(size_t k) {
         while (drain_events.size() <= k) {
             hipEvent_t e;
-            FV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            FV_HIP(hipEventCreateWithFlags(&e, std::getenv("FFTVIS_HIP_DEBUG_DRAIN") ? hipEventDefault : hipEventDisableTiming));
             drain_events.push_back(e);
         }
         return drain_events[k];
@@ -1652,19 +1755,33 @@ class Sim : public SimBase {
     struct HostPin {
         std::thread th;
         std::atomic<int> state{0};  // 0 pinning, 1 pinned, -1 refused (locked-memory limit, exotic mapping)
-        void *p = nullptr;
+        std::vector<std::pair<char *, size_t>> pieces;  // registered so far (helper thread only, until joined)
         double t_pinned = 0;  // seconds after start() (FFTVIS_HIP_DEBUG_DRAIN)
         std::chrono::steady_clock::time_point t0;
         double since() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+        // In pieces cut at the multiples of 256 MiB of the address space (no page is registered twice; a copy is split
+        // at the same addresses, drain_flush): the driver serialises a registration with other memory calls, and a cold
+        // handle still allocates its tables while the first time step is being queued -- behind ONE 10-GB registration
+        // (0.42 s) that thread, and with it the GPU, sat idle.
+        static constexpr uintptr_t PIECE = (uintptr_t)256 << 20;
         void start(int device, void *ptr, size_t bytes) {
-            p = ptr;
-            t0 = std::chrono::steady_clock::now();
             th = std::thread([this, device, ptr, bytes] {
                 (void)hipSetDevice(device);
-                const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
-                if (e != hipSuccess) (void)hipGetLastError();
+                char *p = static_cast<char *>(ptr), *end = p + bytes;
+                bool ok = true;
+                while (ok && p < end) {
+                    const uintptr_t stop = (reinterpret_cast<uintptr_t>(p) / PIECE + 1) * PIECE;
+                    char *q = std::min(end, reinterpret_cast<char *>(stop));
+                    if (hipHostRegister(p, (size_t)(q - p), hipHostRegisterDefault) == hipSuccess) {
+                        pieces.push_back({p, (size_t)(q - p)});
+                        p = q;
+                    } else {
+                        (void)hipGetLastError();
+                        ok = false;
+                    }
+                }
                 t_pinned = since();
-                state.store(e == hipSuccess ? 1 : -1, std::memory_order_release);
+                state.store(ok ? 1 : -1, std::memory_order_release);
             });
         }
         bool pinned() const { return state.load(std::memory_order_acquire) == 1; }
@@ -1674,7 +1791,7 @@ class Sim : public SimBase {
         }
         ~HostPin() {  // also on the error paths: never leave the caller's memory pinned
             if (th.joinable()) th.join();
-            if (pinned()) (void)hipHostUnregister(p);
+            for (auto &pc : pieces) (void)hipHostUnregister(pc.first);
         }
     };
     // queue the copies of the finished time steps items[done ...) behind their events
@@ -1687,8 +1804,18 @@ class Sim : public SimBase {
             FV_HIP(hipStreamWaitEvent(copy_stream, it.ev, 0));
             for (int f = 0; f < nf; ++f) {
                 const int64_t off = ((int64_t)f * nt + it.t) * per_tf;
-                FV_HIP(hipMemcpyAsync(hout + off, dout + off, sizeof(cplx<T>) * (size_t)it.n * per_tf,
-                                      hipMemcpyDeviceToHost, copy_stream));
+                // split where the pinned pieces meet (HostPin): a copy must lie inside one registration
+                char *dst = reinterpret_cast<char *>(hout + off);
+                const char *src = reinterpret_cast<const char *>(dout + off);
+                size_t left = sizeof(cplx<T>) * (size_t)it.n * per_tf;
+                while (left) {
+                    const uintptr_t stop = (reinterpret_cast<uintptr_t>(dst) / HostPin::PIECE + 1) * HostPin::PIECE;
+                    const size_t n = std::min<size_t>(left, stop - reinterpret_cast<uintptr_t>(dst));
+                    FV_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, copy_stream));
+                    dst += n;
+                    src += n;
+                    left -= n;
+                }
             }
         }
     }
@@ -1723,8 +1850,10 @@ class Sim : public SimBase {
         const bool drain = !out_on_device && out_bytes >= drain_min_bytes();
         std::vector<DrainItem> drain_items;
         size_t drained = 0;
-        HostPin pin;
-        if (drain) pin.start(device, out, out_bytes);
+        HostPin pin;  // started once the first unit is queued: a cold handle's first-use allocations would otherwise
+                      // wait on the registration (the driver serialises them) while the GPU has nothing to do yet
+        bool pin_started = false;
+        pin.t0 = std::chrono::steady_clock::now();
 
         double xc[3], X[3];
         source_box(xc, X);
@@ -1880,6 +2009,7 @@ class Sim : public SimBase {
                 L.nufft.reset(new Nufft3<T>(D, eps, sigma, li < 2 ? L.stream : stream));
             L.nufft->err_oob = d_err.as<int>();
             L.nufft->transpose_flipped = !reference_compat;
+            if (li > 0) L.nufft->order_cache = lanes[0].nufft->order_cache;  // one table per grid size for all lanes
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
             L.d_az.reserve(sizeof(T) * cap);
             L.d_za.reserve(sizeof(T) * cap);
@@ -1887,6 +2017,27 @@ class Sim : public SimBase {
             L.d_blockcnt.reserve(sizeof(int) * (nblk + 1));
             L.d_blockoff.reserve(sizeof(int) * (nblk + 1));
             L.binned_ti = -1;
+        }
+        // Size every lane's grid and strength buffers for the largest (frequency group, beam pair) of this run now,
+        // before anything is queued (Nufft3::plan_buffer_cells): no reallocation -- a device synchronisation each --
+        // while the first time step runs.
+        {
+            int64_t need = 0, need_str = 0;
+            int na_max[3] = {8, 8, 8}, n2_max[3] = {64, 64, 64};
+            for (const auto &grp : groups) {
+                double smax = 0;
+                for (int f = grp.first; f < grp.second; ++f) smax = std::max(smax, std::fabs(freqs[f]));
+                for (const Pair &pr : pairs) {
+                    if (pr.n == 0) continue;
+                    const int ntrans = (grp.second - grp.first) * (pr.herm ? 2 : tpol);
+                    need = std::max(need, lanes[0].nufft->plan_buffer_cells(X, pr.box_B(), smax, na_max, n2_max) * ntrans);
+                    need_str = std::max<int64_t>(need_str, ntrans);
+                }
+            }
+            for (int li = 0; li < nlanes_used; ++li) {
+                lanes[li].nufft->reserve_buffers(need, na_max, n2_max);
+                lanes[li].nufft->strengths_buffer_reserve(cap, (int)need_str);
+            }
         }
         if (nlanes > 1 && !pipe) {  // lane 1 starts after the output memset queued on the main stream
             FV_HIP(hipEventRecord(ev_start, stream));
@@ -2084,7 +2235,13 @@ class Sim : public SimBase {
                 L0.heavy_pending = true;
             }
             close_time();
+            if (drain && !pin_started) {
+                if (std::getenv("FFTVIS_HIP_DEBUG_DRAIN")) std::fprintf(stderr, "drain: first unit queued %.3f s\n", pin.since());
+                pin.start(device, out, out_bytes);
+                pin_started = true;
+            }
         }
+        if (drain && !pin_started) pin.start(device, out, out_bytes);
         if (nlanes > 1 && !pipe) {  // join: everything queued on the main stream afterwards sees both lanes
             FV_HIP(hipEventRecord(lanes[1].done, lanes[1].stream));
             FV_HIP(hipStreamWaitEvent(stream, lanes[1].done, 0));
@@ -2102,9 +2259,16 @@ class Sim : public SimBase {
                 }
                 FV_HIP(hipStreamSynchronize(copy_stream));
                 FV_HIP(hipStreamSynchronize(stream));
-                if (dbg)
+                if (dbg) {
                     std::fprintf(stderr, "copies done %.3f s (%zu of %zu time-step items queued before the end)\n",
                                  pin.since(), early, drain_items.size());
+                    std::fprintf(stderr, "drain: time steps finished at [ms after the first]:");
+                    for (size_t i = 1; i < drain_items.size(); ++i) {
+                        float ms = 0;
+                        if (hipEventElapsedTime(&ms, drain_items[0].ev, drain_items[i].ev) == hipSuccess) std::fprintf(stderr, " %.0f", ms);
+                    }
+                    std::fprintf(stderr, "\n");
+                }
             } else {
                 FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
                 FV_HIP(hipStreamSynchronize(stream));

@@ -112,6 +112,11 @@ class SimHandle:
         rot = np.ascontiguousarray(rot, dtype=np.float64)
         _lib.check(self._L.fv_sim_set_times(self._h, rot.shape[0], _lib.ptr(rot)))
 
+    def set_astrom(self, astrom):
+        """(ntimes, 31) float64 eraASTROM contexts: per-source astrometry runs on the device (fv_sim_set_astrom)."""
+        a = np.ascontiguousarray(astrom, dtype=np.float64)
+        _lib.check(self._L.fv_sim_set_astrom(self._h, a.shape[0], _lib.ptr(a)))
+
     def set_topo(self, topo):
         topo = np.ascontiguousarray(topo, dtype=self.rdt)
         _lib.check(self._L.fv_sim_set_topo(self._h, topo.shape[0], topo.shape[2], _lib.ptr(topo), 0))
@@ -294,6 +299,8 @@ class GPUSimulationEngine(SimulationEngine):
         use_feed: str = "x",
         catalog_device=None,
         reference_compat: bool = True,
+        astrom: np.ndarray = None,
+        device_astrometry: bool = False,
     ) -> np.ndarray:
         """Simulate visibilities on the GPU.
 
@@ -310,6 +317,14 @@ class GPUSimulationEngine(SimulationEngine):
           block at a time; a caller-built manager can be handed over as ``coord_mgr`` (extra).  The
           mean-sidereal rotation of ``core/coords.py`` (no precession / nutation / aberration: ~0.35 deg off
           ICRS positions at 2025 epochs) runs only when asked for by name, ``coord_method="SiderealRotation"``;
+        * ``astrom`` / ``device_astrometry`` (extra; SURVEY section 8 f3 -- the coordinate manager on the device):
+          ``astrom`` = (ntimes, 31) float64, one ERFA ``eraASTROM`` context per time (``erfa.apco13`` / astropy's
+          ``erfa_astrom.apco`` fill it in microseconds); the device applies it to every source -- light deflection,
+          aberration, bias-precession-nutation, Earth rotation, polar motion, diurnal aberration, horizon frame,
+          refraction (``fv_sim_set_astrom``) -- so no (ntimes, 3, nsrc) vectors are computed or streamed on the host.
+          ``device_astrometry=True`` builds the contexts here with astropy (the context astropy's own ICRS -> AltAz
+          uses; raises ValueError without astropy) instead of building the matvis manager.  Default off: the
+          reference's manager stays the default route.  Unpinned against ERFA in this pipeline (DESIGN.md section 5);
         * ``nchunks`` splits the source axis exactly like the reference's chunk loop
           (cpu_simulate.py:939,1024,1069): every time step processes the catalog in ``nchunks`` pieces
           whose visibilities accumulate on the device; ``source_buffer`` sizes the above-horizon
@@ -349,7 +364,17 @@ class GPUSimulationEngine(SimulationEngine):
             raise ValueError("nchunks must be >= 1")
         if not 0.0 < float(source_buffer) <= 1.0:
             raise ValueError("source_buffer must be in (0, 1]")
-        if coord_mgr is None and coord_method != "SiderealRotation" and catalog_device is not None:
+        if astrom is None and device_astrometry and coord_mgr is None and coord_method != "SiderealRotation":
+            from ..core.coords import erfa_astrom_context
+
+            astrom = erfa_astrom_context(times, telescope_loc)
+        if astrom is not None:
+            astrom = np.ascontiguousarray(astrom, dtype=np.float64)
+            if astrom.ndim != 2 or astrom.shape[1] != 31 or astrom.shape[0] != len(julian_dates(times)):
+                raise ValueError("astrom must have shape (ntimes, 31): one eraASTROM context per time")
+            if coord_mgr is not None:
+                raise ValueError("pass either astrom= (device astrometry) or coord_mgr=, not both")
+        if coord_mgr is None and astrom is None and coord_method != "SiderealRotation" and catalog_device is not None:
             raise ValueError(
                 "a device-resident catalog carries no ra / dec for a matvis coordinate manager: pass coord_mgr= "
                 "or coord_method='SiderealRotation'")
@@ -385,7 +410,7 @@ class GPUSimulationEngine(SimulationEngine):
         else:
             _check_device_catalog(catalog_device, nfreqs, polarized, precision, self.device)
 
-        if coord_mgr is None and coord_method != "SiderealRotation":
+        if coord_mgr is None and astrom is None and coord_method != "SiderealRotation":
             # the reference's own call (wrapper.py:308-336 passes no manager): build matvis' manager exactly
             # as the CPU engine does (cpu_simulate.py:686-709) and stream its vectors like a caller's
             coord_mgr = build_coord_mgr(coord_method, coord_method_params, coherency.astype(complex_dtype, copy=False),
@@ -428,7 +453,9 @@ class GPUSimulationEngine(SimulationEngine):
             else:
                 h.set_sources_device(nsrc, nfreqs, catalog_device.eq.data_ptr(), catalog_device.flux.data_ptr(),
                                      catalog_device.polarized_sky)
-            if coord_mgr is None:
+            if astrom is not None:
+                h.set_astrom(astrom)
+            elif coord_mgr is None:
                 h.set_times(SiderealRotation(times, telescope_loc).matrices())
             h.set_freqs(freqs.astype(float))
             if is_gridded:

@@ -97,6 +97,8 @@ def simulate_vis(
     device: int = 0,
     coord_mgr=None,
     reference_compat: bool = True,
+    astrom: np.ndarray = None,
+    device_astrometry: bool = False,
 ) -> np.ndarray:
     """Visibilities (nfreqs, ntimes, nbls) or (nfreqs, ntimes, 2, 2, nbls); arguments as the
     reference's ``simulate_vis`` (wrapper.py:85-238).
@@ -108,7 +110,8 @@ def simulate_vis(
     defaults to the reference's "CoordinateRotationERFA": the engine builds matvis' manager for it as the CPU
     engine does (cpu_simulate.py:686-709; matvis / astropy imported on first use) unless a ready one is passed
     as ``coord_mgr=``; ``reference_compat=False`` (extra) replaces the reference's forms for flipped two-beam
-    baselines and the eigenbeam (l, k) term by the exact ones; see ``GPUSimulationEngine.simulate``."""
+    baselines and the eigenbeam (l, k) term by the exact ones; ``astrom=`` / ``device_astrometry=True`` (extra) run
+    the per-source astrometry on the device from per-time ERFA contexts; see ``GPUSimulationEngine.simulate``."""
     if eps is None:
         eps = default_accuracy_dict[precision]  # wrapper.py:241-242
     ants = {k: np.array(v) for k, v in ants.items()}
@@ -133,4 +136,5 @@ def simulate_vis(
         force_use_type3=force_use_type3, force_use_ray=force_use_ray, trace_mem=trace_mem,
         nchunks=nchunks, source_buffer=source_buffer, beam_coefs=beam_coefs,
         coord_mgr=coord_mgr, use_feed=use_feed, reference_compat=reference_compat,
+        astrom=astrom, device_astrometry=device_astrometry,
     )

@@ -78,6 +78,10 @@ int fv_beam_eval(int device, int precision, int polarized, int kind, double diam
 int fv_apparent_coherency(int device, int precision, int variant, int64_t n, const void *beam_i,
                           const void *beam_j, const void *flux, void *out);
 int fv_inplace_rot(int device, int precision, const double *rot, void *b, int64_t n);
+/* fv_astrom_topo: one time step of the device-side coordinate manager (see fv_sim_set_astrom): eq (3, n) ICRS unit
+ * vectors -> topo (3, n) topocentric (east, north, up) unit vectors under one 31-double context -- what matvis'
+ * CoordinateRotationERFA.rotate(t) leaves in all_coords_topo (cpu_simulate.py:937).                      */
+int fv_astrom_topo(int device, int precision, const double *astrom, int64_t n, const void *eq, void *topo);
 
 /* ---- fused simulator (the hot loop) ---------------------------------------------------------
  * One handle = one GPU context: streams, FFT twiddle / deconvolution tables, device-resident catalog / baselines /
@@ -116,6 +120,20 @@ int fv_sim_set_times(fv_sim *h, int ntimes, const double *rot_eq2enu);
  * (ntimes, 3, nsrc) real of the handle's precision -- what coord_mgr.rotate(ti) produces at
  * cpu_simulate.py:937 before the horizon cut.  Call after fv_sim_set_sources.                 */
 int fv_sim_set_topo(fv_sim *h, int ntimes, int64_t nsrc, const void *topo, int on_device);
+
+/* The coordinate manager on the device (the matvis manager the CPU engine builds at
+ * cpu_simulate.py:693-709 and rotates per time at :937): instead of per-source vectors the caller hands over the
+ * SOURCE-INDEPENDENT context of each time, astrom (ntimes, 31) float64 = one eraASTROM per time in ERFA's field order
+ *   pmt, eb[3], eh[3] (Sun -> observer unit vector), em (au), v[3] (observer barycentric velocity / c), bm1,
+ *   bpn[3][3] (row-major), along, phi, xpl, ypl, sphi, cphi, diurab, eral, refa, refb
+ * -- what erfa.apco13 / astropy's erfa_astrom.apco fills in microseconds -- and the library applies it to every
+ * catalog source in front of the horizon cut: light deflection by the Sun, annual aberration, bias-precession-
+ * nutation, Earth rotation angle + longitude (eral), polar motion, diurnal aberration, rotation to the horizon,
+ * refraction (refa = refb = 0: none) -- the published eraAtciqz / eraAtioq algorithms.  No (ntimes, 3, nsrc)
+ * host stream (1.4 GB per 60 times at 1e6 sources).  A context with bpn = identity, v = 0, em huge, xpl = ypl =
+ * diurab = refa = refb = 0 and eral = local sidereal angle is exactly fv_sim_set_times' rotation.
+ * Replaces fv_sim_set_times / fv_sim_set_topo.  Parity versus ERFA itself is unpinned in this pipeline.    */
+int fv_sim_set_astrom(fv_sim *h, int ntimes, const double *astrom);
 
 /* Frequencies (Hz), float64 (nfreq). (cpu_simulate.py:969-973) */
 int fv_sim_set_freqs(fv_sim *h, int nfreq, const double *freqs);

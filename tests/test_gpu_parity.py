@@ -1003,3 +1003,52 @@ def test_reference_compat_off_gives_the_exact_symmetries(gpu):
                                             fluxes=fl4), reference_compat=False)
     assert rel_l2(ex, direct) < 4 * TOL
     assert rel_l2(fftvis_amd.simulate_vis(**bas), direct) > 1e-3  # the reference's shortcut is not exact here
+
+
+def test_device_astrometry_from_per_time_contexts(gpu):
+    """SURVEY section 8 f3 / VERDICT r2 next #7: the coordinate manager on the device.  (a) ``fv_astrom_topo`` -- one
+    time step: every catalog source under a 31-double ERFA context (deflection, aberration, BPN, Earth rotation, polar
+    motion, diurnal aberration, horizon frame, refraction) -- equals the numpy restatement in oracle/astrometry.py to
+    1e-12 for contexts with every term switched on, fp64 and fp32 catalogs; (b) under the trivial context it IS the
+    sidereal rotation; (c) end to end: a simulation driven by contexts (``astrom=``) equals the one whose per-source
+    vectors were computed on the host by the oracle and streamed in through ``coord_mgr=``, with source chunks and
+    time blocks; (d) ``sidereal_astrom_context`` reproduces ``coord_method="SiderealRotation"`` exactly.
+    Unpinned against ERFA itself (not in this pipeline)."""
+    from fftvis_amd.core.coords import sidereal_astrom_context
+    from fftvis_amd.gpu.utils import astrom_topo
+    from oracle import astrometry as oa
+
+    cfg = synth.make_config("C2", nsrc=5000, nfreq=3, ntimes=4)
+    eq = orc.eq_unit_vectors(cfg["ra"], cfg["dec"])
+    for seed in range(3):
+        ctx = oa.plausible_context(seed)
+        want = oa.icrs_to_enu(eq, ctx)
+        got = astrom_topo(eq, ctx)
+        assert np.abs(got - want).max() < 1e-12 and np.abs(np.linalg.norm(got, axis=0) - 1).max() < 1e-12
+        assert np.abs(astrom_topo(eq.astype(np.float32), ctx) - want).max() < 5e-7
+    lst, lat = 2.1, synth.HERA_LAT
+    assert np.abs(astrom_topo(eq, oa.sidereal_context(lst, lat)) - orc.eq_to_enu_matrix(lst, lat) @ eq).max() < 1e-14
+    # (c) contexts on the device == the same astrometry on the host, streamed as vectors
+    ctxs = np.stack([oa.plausible_context(10 + t, synth.HERA_LAT) for t in range(4)])
+
+    class Mgr:  # the slice of matvis' manager the engine consumes
+        def setup(self):
+            pass
+
+        def rotate(self, ti):
+            self.all_coords_topo = oa.icrs_to_enu(eq, ctxs[ti])
+
+    kw = {k: v for k, v in cfg.items() if k != "coord_method"}
+    host = fftvis_amd.simulate_vis(**kw, coord_method="CoordinateRotationERFA", coord_mgr=Mgr())
+    for extra in ({}, {"min_chunks": 3}):
+        dev = fftvis_amd.simulate_vis(**kw, coord_method="CoordinateRotationERFA", astrom=ctxs, **extra)
+        assert rel_l2(dev, host) < 1e-11, extra
+    assert rel_l2(dev, fftvis_amd.simulate_vis(**cfg)) > 1e-3  # and it is not the sidereal answer
+    # (d) the trivial contexts are the named approximation
+    triv = fftvis_amd.simulate_vis(**kw, coord_method="CoordinateRotationERFA",
+                                   astrom=sidereal_astrom_context(cfg["times"], cfg["telescope_loc"]))
+    assert rel_l2(triv, fftvis_amd.simulate_vis(**cfg)) < 1e-12
+    with pytest.raises(ValueError, match="shape .ntimes, 31."):
+        fftvis_amd.simulate_vis(**kw, astrom=ctxs[:2])
+    with pytest.raises(ValueError, match="needs astropy"):
+        fftvis_amd.simulate_vis(**kw, device_astrometry=True)

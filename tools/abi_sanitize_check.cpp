@@ -54,6 +54,8 @@ int main() {
     EXPECT(fv_sim_set_basis(nullptr, 1, 1, 1, d9, i2, i2) == FV_ERR_ARG);
     EXPECT(fv_sim_set_chunking(nullptr, 1, 1.0) == FV_ERR_ARG);
     EXPECT(fv_sim_set_reference_compat(nullptr, 0) == FV_ERR_ARG);
+    EXPECT(fv_sim_set_astrom(nullptr, 1, d9) == FV_ERR_ARG);
+    EXPECT(fv_astrom_topo(0, 9, d9, 1, d9, v) == FV_ERR_ARG);
     EXPECT(fv_sim_set_beam_airy_scaled(nullptr, 0, 14.0, d9, 1.0) == FV_ERR_ARG);
     EXPECT(fv_sim_run(nullptr, 0, 1, 0, 1, v, 0) == FV_ERR_ARG);
     EXPECT(fv_sim_sync(nullptr) == FV_ERR_ARG);
