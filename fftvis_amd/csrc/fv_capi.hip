@@ -569,3 +569,18 @@ int fv_sim_enable_timing(fv_sim *h, int on) { FV_SIM_CALL(h->impl->enable_timing
 int fv_sim_timing(fv_sim *h, double *ms, int n) { FV_SIM_CALL(h->impl->timing(ms, n)); }
 
 }  // extern "C"
+
+#ifdef FV_FFT_STAMPS
+// diagnostic builds only (see fv_nufft.h): copies out up to max_waves records of 10 values and resets the counter
+extern "C" int fv_debug_stamps(unsigned long long *out, int max_waves) {
+    unsigned int n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(fv::fv_stamp_count), sizeof(n)) != hipSuccess) return -1;
+    if (n > (1u << 18)) n = 1u << 18;
+    if ((int)n > max_waves) n = (unsigned)max_waves;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(fv::fv_stamps), sizeof(unsigned long long) * 10 * (size_t)n) != hipSuccess) return -1;
+    const unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fv::fv_stamp_count), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif

@@ -1007,6 +1007,26 @@ template <bool COL>
 struct StPlan<12, COL> {
     static constexpr int R1 = 16, R2 = 16, R3 = 16, TPR = 256, A = 258, B = 16, ROW = 4128;
 };
+// FV_FFT_STAMPS (diagnostic builds only): every wave of k_rowfft_st leaves s_memrealtime stamps (100 MHz) at its phase
+// boundaries in a device array that fv_debug_stamps() copies out -- where a job's time goes (load, three radix passes,
+// two exchanges, stores).  Never defined in the product build.
+#ifdef FV_FFT_STAMPS
+__device__ unsigned long long fv_stamps[(size_t)10 << 18];  // 7 realtime stamps, tag, shader-clock count at start / end
+__device__ unsigned int fv_stamp_count;
+#define FV_STAMP(slot)                                                                          \
+    do {                                                                                         \
+        if ((threadIdx.x & 63) == 0 && stamp_idx < (1u << 18)) {                                 \
+            fv_stamps[(size_t)stamp_idx * 10 + (slot)] = __builtin_amdgcn_s_memrealtime();         \
+            if ((slot) == 0) fv_stamps[(size_t)stamp_idx * 10 + 8] = __builtin_amdgcn_s_memtime(); \
+            if ((slot) == 6) fv_stamps[(size_t)stamp_idx * 10 + 9] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                        \
+    } while (0)
+#else
+#define FV_STAMP(slot)
+#endif
+#ifndef FV_PAIR_DEFAULT
+#define FV_PAIR_DEFAULT 1
+#endif
 #ifndef FV_ST_MINW12
 #define FV_ST_MINW12 3  // waves per SIMD targeted by the register allocation of the Q = 4096 kernels
 #endif
@@ -1015,7 +1035,10 @@ constexpr int ST_THREADS_COL = 512;  // column mode
 #ifndef FV_COL11_THREADS
 #define FV_COL11_THREADS 512
 #endif
-constexpr int st_threads(int logq, bool col) { return !col ? ST_THREADS : logq == 12 ? 1024 : logq == 11 ? FV_COL11_THREADS : ST_THREADS_COL; }
+constexpr int st_threads(int logq, bool col, bool pair = false) {
+    // PAIR (two residues per job, see k_rowfft_st): a column-mode workgroup keeps its columns and doubles its threads
+    return (!col ? ST_THREADS : logq == 12 ? 1024 : logq == 11 ? FV_COL11_THREADS : ST_THREADS_COL) * (col && pair ? 2 : 1);
+}
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v / 2); }
 
 // A pointer every lane of the wave holds the same value of, moved to scalar registers: global loads /
@@ -1043,7 +1066,11 @@ struct RowBuf {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx<T> *>(b), 0, bytes, 0x00020000);
     }
     __device__ cplx<T> load(int idx) const {
+#if defined(FV_ABL) && (FV_ABL & 2)  // diagnostic build: every load reads element 0 (cached): what the input traffic costs
+        const uint32_t off = idx < 0 ? 0xfffffff0u : 0u;
+#else
         const uint32_t off = (uint32_t)idx * (uint32_t)sizeof(cplx<T>);
+#endif
         if constexpr (sizeof(T) == 8) {
             using v4 = unsigned int __attribute__((ext_vector_type(4)));
             const v4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
@@ -1055,7 +1082,11 @@ struct RowBuf {
         }
     }
     __device__ void store(int idx, cplx<T> v) const {
+#if defined(FV_ABL) && (FV_ABL & 1)  // diagnostic build: outputs are computed, kept alive, and dropped by the range check
+        const uint32_t off = 0xfffffff0u | ((uint32_t)idx & 0u);
+#else
         const uint32_t off = (uint32_t)idx * (uint32_t)sizeof(cplx<T>);
+#endif
         if constexpr (sizeof(T) == 8) {
             using v4 = unsigned int __attribute__((ext_vector_type(4)));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4, v), rsrc, off, 0, 0);
@@ -1209,20 +1240,34 @@ __global__ void k_fg_build(int64_t N, int nfg, const T *__restrict__ btx, const 
 // uniform complex factor per sweep (none for p = 0), one per-slot twiddle at the end.
 // INB (column mode): 0 = plain row-major input plane; 1 = column blocks of 2^in_blk elements (RowDifArgs::in_blk);
 // 2 = column blocks exactly as wide as the workgroup's RPW columns.
-template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false, bool FOLD = false, int INB = 0>
-__global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_MINW12 : 4) void k_rowfft_st(
+// PAIR (folded rows, P >= 2): a job computes TWO residues (2 jp, 2 jp + 1) of its rows from ONE pass over their inputs.
+// Why: the P residue jobs of a row all read the whole row, and although those re-reads hit in L2 it is the L2 / load
+// path, not HBM and not the fp64 pipe, that bounds these kernels (in-kernel stamps: 50-63 % of a wave's life is the fold's
+// load round trips at ~3 us each, the three butterflies together 5 %; VALU busy 45-50 %; C3's x-pass with P = 3 instead of
+// 5 runs 40 % faster).  A thread has registers for ONE residue's 16 slots, so during the fold the two thread groups that
+// will transform the two residues (g = 0, 1; same u) each take HALF of the slots and accumulate them for BOTH residues
+// -- 8 + 8 accumulators, every loaded element used twice, half the loads per thread -- then hand the partner its
+// residue's 8 slots through LDS (the exchange buffer is idle until pass 1) and continue, each with its own residue, exactly
+// as an unpaired job.  Row mode: a workgroup's exchange rows are (row, residue) pairs; column mode: the workgroup keeps
+// its columns (one 64-byte block) and doubles its threads.  Odd P: the last job's second group has no residue (it still
+// folds its half of the slots for its partner, transforms garbage and stores nothing).
+template <typename T, int LOGQ, bool COL, int NLD, bool FUSED = false, bool FOLD = false, int INB = 0, bool PAIR = false>
+__global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? FV_ST_MINW12 : 4) void k_rowfft_st(
     const cplx<T> *__restrict__ in0, cplx<T> *__restrict__ out0, const cplx<T> *__restrict__ tw, RowDifArgs a,
     FusedArgs fz) {
     static_assert(!FUSED || COL, "the fused gather rides on the column-mode last pass");
     static_assert(!FOLD || (!FUSED && NLD == (1 << (LOGQ == 9 ? 3 : 4))), "folding runs on full pass-1 operands");
     static_assert(!INB || COL, "blocked input planes are read by the column pass");
+    static_assert(!PAIR || (FOLD && !FUSED && LOGQ >= 10), "paired residues: folded rows of Q >= 1024");
     // gang launch: blockIdx.y = 1 runs the same transform on a second pair of buffers
     const cplx<T> *__restrict__ in = blockIdx.y ? static_cast<const cplx<T> *>(a.in1) : in0;
     cplx<T> *__restrict__ out = blockIdx.y ? static_cast<cplx<T> *>(a.out1) : out0;
     using PL = StPlan<LOGQ, COL>;
     constexpr int R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, TPR = PL::TPR, A = PL::A, B = PL::B;
-    constexpr int THREADS = st_threads(LOGQ, COL);
+    constexpr int THREADS = st_threads(LOGQ, COL, PAIR);
     constexpr int Q = 1 << LOGQ, S1 = R2 * R3, RPW = THREADS / TPR, ROW = PL::ROW;
+    constexpr int NL = PAIR ? RPW / 2 : RPW;  // data lines (rows / columns) of a workgroup; RPW = its exchange rows
+    static_assert(!PAIR || (RPW >= 2 && RPW % 2 == 0), "paired residues need an even number of exchange rows");
     static_assert(ROW >= R1 * A && A >= R2 * B && B >= R3, "LDS layout");
     constexpr int NI2 = R1 * R3 / TPR, NI3 = R1 * R2 / TPR;
     constexpr int L1 = ilog2_c(R1), L2 = ilog2_c(R2), L3 = ilog2_c(R3);
@@ -1236,32 +1281,47 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
 
     const int tid = threadIdx.x;
     const int vb = blockIdx.x;
-    const int r = COL ? tid % RPW : tid / TPR;
-    const int u = COL ? tid / RPW : tid % TPR;
+    // line = the data row / column of this thread inside the workgroup, g = its residue group (PAIR), r = its exchange row
+    const int line = COL ? tid % NL : (PAIR ? (tid / TPR) >> 1 : tid / TPR);
+    const int u = COL ? (tid / NL) % TPR : tid % TPR;
+    const int g = !PAIR ? 0 : __builtin_amdgcn_readfirstlane(COL ? tid / (NL * TPR) : (tid / TPR) & 1);  // wave-uniform
+    const int r = PAIR ? (COL ? g * NL + line : tid / TPR) : line;
+#ifdef FV_FFT_STAMPS
+    unsigned stamp_idx = 0xffffffffu;
+    if ((tid & 63) == 0 && (FV_FFT_STAMPS != 2 || COL)) {  // FV_FFT_STAMPS = 2: column-mode kernels only
+        stamp_idx = atomicAdd(&fv_stamp_count, 1u);
+        if (stamp_idx < (1u << 18)) fv_stamps[(size_t)stamp_idx * 10 + 7] = ((unsigned long long)LOGQ << 8) | (COL ? 2 : 0) | (FOLD ? 1 : 0) | ((unsigned long long)(sizeof(T) == 8) << 2) | (PAIR ? 8 : 0);
+    }
+    FV_STAMP(0);
+#endif
+    const int PJ = PAIR ? (a.P + 1) >> 1 : a.P;  // jobs per line group
     int p;
     int64_t row0, row;
     if constexpr (COL) {
-        // column mode: a workgroup owns RPW adjacent columns and one residue; the P jobs of a column group get
+        // column mode: a workgroup owns NL adjacent columns and one residue (PAIR: two); the jobs of a column group get
         // block ids 8 apart (same XCD, back to back)
         const int tt = vb >> 3;
-        p = tt % a.P;
-        row0 = ((int64_t)(tt / a.P) * 8 + (vb & 7)) * RPW;
+        p = tt % PJ;
+        row0 = ((int64_t)(tt / PJ) * 8 + (vb & 7)) * NL;
         if (row0 >= a.nrows) return;  // workgroup-uniform
-        row = row0 + r;
+        row = row0 + line;
     } else {
         // row mode: XCD x (= block id mod 8) takes the x-th eighth of the rows, a CONTIGUOUS range -- neighbouring rows
         // write neighbouring 64-byte pieces of the blocked output, which then meet in one L2 (interleaving the row
         // groups over the XCDs cost the Q = 4096 x-pass 10 %) -- and within it jobs run row group by row group, the
-        // P residues of a group back to back.  (The RPW wave groups of a workgroup take different rows, never two
+        // jobs of a group back to back.  (Unpaired: the wave groups of a workgroup take different rows, never two
         // residues of one row: simultaneous requests for a line stall each other in the CU's L1 -- 1 506 vs 1 425 us.)
-        const int i = vb >> 3, g = i / a.P;
-        p = i - g * a.P;
-        row0 = (int64_t)(vb & 7) * a.jobs_per_xcd + (int64_t)g * RPW;  // jobs_per_xcd: rows per XCD here
-        if (g * RPW >= a.jobs_per_xcd || row0 >= a.nrows) return;  // workgroup-uniform
-        row = row0 + r;
+        const int i = vb >> 3, gq = i / PJ;
+        p = i - gq * PJ;
+        row0 = (int64_t)(vb & 7) * a.jobs_per_xcd + (int64_t)gq * NL;  // jobs_per_xcd: rows per XCD here
+        if (gq * NL >= a.jobs_per_xcd || row0 >= a.nrows) return;  // workgroup-uniform
+        row = row0 + line;
     }
+    const int p_other = PAIR ? 2 * p + 1 - g : 0;  // the partner group's residue (may be P: no such residue)
+    if constexpr (PAIR) p = 2 * p + g;             // this thread's residue from here on (wave-uniform); may be P
     const int64_t rplane = row / a.rpp, rk = row % a.rpp;
-    const bool ok = row < a.nrows && rk < a.rpp_valid;
+    const bool ok_line = row < a.nrows && rk < a.rpp_valid;  // the line exists: its inputs are read
+    const bool ok = ok_line && p < a.P;                      // ... and so does this thread's residue: outputs are stored
     const int n2 = a.n2;
     T *rb = smem + r * ROW;
     T *rbi = DUAL ? rb + RPW * ROW : rb;
@@ -1306,35 +1366,118 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
     // stored.  Otherwise one compare + select per element (the bound is 0 for a lane without a column), a shift or a
     // 24-bit multiply for the index -- no 32-bit integer multiplies (quarter rate) and no exec-mask regions.
     constexpr bool INBLK = INB != 0, ONEBLK = INB == 2;
-    constexpr int BLK1 = ilog2_c(RPW);  // the block width of INB = 2
+    constexpr int BLK1 = ilog2_c(NL);  // the block width of INB = 2
     const int blk = ONEBLK ? BLK1 : a.in_blk;
     const int64_t plane0 = (row0 / a.rpp) * a.in_plane;
     const int64_t in_base = ONEBLK ? plane0 + ((((row0 % a.rpp) >> BLK1) * (int64_t)a.n_in) << BLK1)
                             : INBLK ? plane0
                             : COL   ? plane0 + (row0 % a.rpp) * a.in_row
-                                    : (ok ? rplane * a.in_plane + rk * a.in_row : 0);
-    const RowBuf<T> rowin(in + in_base, ONEBLK ? ((int64_t)a.n_in << BLK1) : COL ? -1 : (ok ? a.n_in : 0));
-    const int lane_in = ONEBLK ? r
+                                    : (ok_line ? rplane * a.in_plane + rk * a.in_row : 0);
+    const RowBuf<T> rowin(in + in_base, ONEBLK ? ((int64_t)a.n_in << BLK1) : COL ? -1 : (ok_line ? a.n_in : 0));
+    const int lane_in = ONEBLK ? line
                         : INBLK ? (int)((rplane - row0 / a.rpp) * a.in_plane) + ((((int)rk >> blk) * a.n_in) << blk) +
                                       ((int)rk & ((1 << blk) - 1))
                         : COL   ? (int)(rplane * a.in_plane + rk * a.in_row - in_base)
                                 : 0;
     const int in_elem = (int)a.in_elem;
-    const unsigned nin_lane = ok ? (unsigned)a.n_in : 0u;
-    auto load_in = [&](int ia) -> cplx<T> {
+    const unsigned nin_lane = ok_line ? (unsigned)a.n_in : 0u;
+    auto in_index = [&](int ia) -> int {  // element index for the descriptor; out of its range where the row has no element
         if constexpr (ONEBLK)
-            return rowin.load((ia << BLK1) + lane_in);
+            return (ia << BLK1) + lane_in;
         else if constexpr (INBLK)
-            return rowin.load((unsigned)ia < nin_lane ? lane_in + (ia << blk) : -1);
+            return (unsigned)ia < nin_lane ? lane_in + (ia << blk) : -1;
         else if constexpr (COL)
-            return rowin.load((unsigned)ia < nin_lane ? lane_in + mul24(ia, in_elem) : -1);
+            return (unsigned)ia < nin_lane ? lane_in + mul24(ia, in_elem) : -1;
         else
-            return rowin.load(ia);  // zero outside [0, n_in)
+            return ia;  // zero outside [0, n_in)
     };
+    auto load_in = [&](int ia) -> cplx<T> { return rowin.load(in_index(ia)); };
     // Residue twiddle of slot q = u + k S1:  w^{q p} = w^{u p} (this thread's, one vector load) x w^{k S1 p} (uniform:
     // scalar loads).  Only the uniform part is applied to the inputs; w^{u p} is common to the thread's R1 slots, commutes
     // with their butterfly and rides on the pass-1 twiddle below (loaded there: no registers held across the loads and the butterfly).
-    if constexpr (FOLD) {
+    if constexpr (FOLD && PAIR) {
+        static_assert(R1 == 16, "paired residues: 16 pass-1 slots per thread");
+        const int nlo = a.n_in - hshift;                      // elements with s >= 0
+        const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
+        const int mmax = (nlo - 1) / Q;
+        constexpr int CH = 4, HALF = R1 / 2;
+        const int P = a.P;
+        auto mod_p = [&](int v) {  // v mod P for v >= 0 (v < 4 P here)
+            while (v >= P) v -= P;
+            return v;
+        };
+        int mpm_min = (mmin * p) % P, mpo_min = (mmin * p_other) % P;  // (mmin p) mod P, mmin <= 0
+        if (mpm_min < 0) mpm_min += P;
+        if (mpo_min < 0) mpo_min += P;
+        cplx<T> mine[HALF], theirs[HALF];  // this group's slots 8 g .. 8 g + 7, for its own residue and for the partner's
+#pragma unroll
+        for (int hh = 0; hh < HALF; hh += CH) {
+            const int h = HALF * g + hh;  // first slot of the chunk (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) mine[hh + j] = theirs[hh + j] = {T(0), T(0)};
+            const int m_lo = mmax - mmin < 2 ? mmin : max(mmin, (-hshift - ((h + CH) * S1 - 1)) / Q);
+            const int m_hi = mmax - mmin < 2 ? mmax : min(mmax, (nlo - 1 - h * S1) / Q);
+            int mpm = mod_p(mpm_min + (m_lo - mmin) * mod_p(p)), mpo = mod_p(mpo_min + (m_lo - mmin) * mod_p(p_other));
+            for (int m = m_lo; m <= m_hi; m += 2) {
+                cplx<T> x[2][CH];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int off = (m + t) * Q + hshift;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) x[t][j] = load_in(m + t <= m_hi ? u + (h + j) * S1 + off : -1);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    // c^m of either residue (tw[0] = 1 exactly: no special case for a zero exponent)
+                    const cplx<T> cm = tw[mpm * Q], co = tw[mpo * Q];
+                    mpm = mod_p(mpm + mod_p(p));
+                    mpo = mod_p(mpo + mod_p(p_other));
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        mine[hh + j].re += x[t][j].re * cm.re - x[t][j].im * cm.im;
+                        mine[hh + j].im += x[t][j].re * cm.im + x[t][j].im * cm.re;
+                        theirs[hh + j].re += x[t][j].re * co.re - x[t][j].im * co.im;
+                        theirs[hh + j].im += x[t][j].re * co.im + x[t][j].im * co.re;
+                    }
+                }
+            }
+            // the uniform part of the slot twiddle, w^{k S1 p}, k = h + j (k S1 p < n2 also for p = P)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                mine[hh + j] = cmul(mine[hh + j], tw[(h + j) * S1 * p]);
+                theirs[hh + j] = cmul(theirs[hh + j], tw[(h + j) * S1 * p_other]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // hand the partner group (same line, same u, other residue) its 8 slots through the idle exchange buffer:
+        // [exchange row][slot][u] complex, lanes contiguous (column mode: [group][slot][u][column])
+        {
+            cplx<T> *xb = reinterpret_cast<cplx<T> *>(smem);
+            static_assert(HALF * TPR * 2 <= ROW, "partner hand-over fits the exchange rows");
+            const int mybase = COL ? (g * HALF * TPR + u) * NL + line : (r * HALF) * TPR + u;
+            const int pabase = COL ? ((1 - g) * HALF * TPR + u) * NL + line : ((r ^ 1) * HALF) * TPR + u;
+            constexpr int KS = COL ? TPR * NL : TPR;  // stride of a slot
+#pragma unroll
+            for (int kk = 0; kk < HALF; ++kk) xb[mybase + kk * KS] = theirs[kk];
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < HALF; ++kk) theirs[kk] = xb[pabase + kk * KS];  // now: the partner's slots of MY residue
+            __syncthreads();  // read before the exchanges overwrite it
+        }
+        if (g == 0) {  // wave-uniform: slots 0..7 are mine, 8..15 came from the partner
+#pragma unroll
+            for (int kk = 0; kk < HALF; ++kk) {
+                va[kk] = mine[kk];
+                va[HALF + kk] = theirs[kk];
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < HALF; ++kk) {
+                va[HALF + kk] = mine[kk];
+                va[kk] = theirs[kk];
+            }
+        }
+    } else if constexpr (FOLD) {
         const int nlo = a.n_in - hshift;                      // elements with s >= 0
         const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
         const int mmax = (nlo - 1) / Q;
@@ -1352,9 +1495,33 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
             // (rows of two sweeps have nothing to skip, and their loop runs 4 % faster on the plain bounds)
             const int m_lo = mmax - mmin < 2 ? mmin : max(mmin, (-hshift - ((h + CH) * S1 - 1)) / Q);  // ceil of a negative quotient
             const int m_hi = mmax - mmin < 2 ? mmax : min(mmax, (nlo - 1 - h * S1) / Q);               // numerator >= 0 there
-            // two sweeps per round trip: 8 loads in flight (a sweep beyond m_hi asks for index -1: zero, no access)
+            // two sweeps per round trip: 8 loads in flight (a sweep beyond m_hi asks for index -1: zero, no access).
+            // (Two more sweeps per trip by LDS-DMA into the idle exchange buffer -- no registers -- were measured to
+            // change nothing: the job is bound by the throughput of the L2 / load path that serves the P re-reads of
+            // every row, not by its latency; see PAIR below.)
             int mpw = mp_min + (m_lo - mmin) * p;  // (m_lo p) mod P: m_lo - mmin is 0 or 1
             while (mpw >= a.P) mpw -= a.P;
+            auto accumulate = [&](const cplx<T> *xs) {
+                // c^m = w^{(m Q p) mod n2}: m Q p is a multiple of Q, so the index is ((m p) mod P) Q -- walked
+                // incrementally (a modulo by a run-time P is a dozen scalar instructions, and this is per sweep)
+                const int mp = mpw;
+                mpw += p;
+                if (mpw >= a.P) mpw -= a.P;
+                if (mp) {  // uniform
+                    const cplx<T> cm = tw[mp * Q];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        acc[j].re += xs[j].re * cm.re - xs[j].im * cm.im;
+                        acc[j].im += xs[j].re * cm.im + xs[j].im * cm.re;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        acc[j].re += xs[j].re;
+                        acc[j].im += xs[j].im;
+                    }
+                }
+            };
             for (int m = m_lo; m <= m_hi; m += 2) {
                 cplx<T> x[2][CH];
 #pragma unroll
@@ -1363,28 +1530,8 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
 #pragma unroll
                     for (int j = 0; j < CH; ++j) x[t][j] = load_in(m + t <= m_hi ? u + (h + j) * S1 + off : -1);
                 }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    // c^m = w^{(m Q p) mod n2}: m Q p is a multiple of Q, so the index is ((m p) mod P) Q -- walked
-                    // incrementally (a modulo by a run-time P is a dozen scalar instructions, and this is per sweep)
-                    const int mp = mpw;
-                    mpw += p;
-                    if (mpw >= a.P) mpw -= a.P;
-                    if (mp) {  // uniform
-                        const cplx<T> cm = tw[mp * Q];
-#pragma unroll
-                        for (int j = 0; j < CH; ++j) {
-                            acc[j].re += x[t][j].re * cm.re - x[t][j].im * cm.im;
-                            acc[j].im += x[t][j].re * cm.im + x[t][j].im * cm.re;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < CH; ++j) {
-                            acc[j].re += x[t][j].re;
-                            acc[j].im += x[t][j].im;
-                        }
-                    }
-                }
+                accumulate(x[0]);
+                accumulate(x[1]);
             }
             if (p) {
                 // the uniform part of the slot twiddle, w^{k S1 p} (k = 0: one)
@@ -1477,6 +1624,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
             for (int n1 = NH; n1 < R1 - NH; ++n1) va[n1] = {T(0), T(0)};
         }
     }
+    FV_STAMP(1);  // inputs loaded (and folded)
     dif_regs<T, R1>(va);
     st_twiddle_from<T, R1>(va, tw[mul24(u, p)], tw[mul24(u, a.P)]);  // w^{u p} w_Q^{u k1}, w_Q = w_{n2}^P; u p < n2 (p = 0: tw[0] = 1)
     const int s1 = (u / R3) * B + (u % R3);
@@ -1494,6 +1642,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
     }
 
     // ---- exchange 1 -> pass 2 -------------------------------------------------------------------
+    FV_STAMP(2);  // pass 1 done
     cplx<T> vb2[NI2][R2];
 #pragma unroll
     for (int k = 0; k < R1; ++k) rb[s1 + k * A] = va[bitrev_small(k, L1)].re;
@@ -1519,6 +1668,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
 #pragma unroll
         for (int n = 0; n < R2; ++n) vb2[i][n].im = rbi[base2[i] + n * B];
 
+    FV_STAMP(3);  // exchange 1 done
 #pragma unroll
     for (int i = 0; i < NI2; ++i) {
         const int j3 = (u + i * TPR) / R1;
@@ -1527,6 +1677,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
     }
 
     // ---- exchange 2 -> pass 3 (pass-2 items write back to the slots they read: no sync before) --
+    FV_STAMP(4);  // pass 2 done
     cplx<T> vc[NI3][R3];
 #pragma unroll
     for (int i = 0; i < NI2; ++i)
@@ -1557,6 +1708,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
         for (int n = 0; n < R3; ++n) vc[i][n].im = rbi[base3[i] + n];
 
     // ---- pass 3 and this residue's outputs: k' = v + k3 Q/R3, l = P k' + p (mod n2, signed) ------
+    FV_STAMP(5);  // exchange 2 done
     if (!FUSED && !ok) return;
     const int half_n = a.n_out / 2;
     // residue-major storage: l = P ks + p sits at ((p + half_n) mod P) cnt + (p + half_n) / P + ks
@@ -1595,11 +1747,21 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
         // and kept alive from there they cost 16 registers for three passes (recomputing is one add each)
         asm volatile("" : "+v"(v));
         dif_regs<T, R3>(vc[i]);
+        // Only about half of a residue's Q outputs are wanted (|l| <= n_out / 2): for most (wave, k) the whole store would
+        // be dropped by the range check -- after being issued.  The wave's lanes hold consecutive v, so whether ANY lane's
+        // output k is wanted is a scalar test: the dead stores (a third of the FFT passes' time went into stores) are
+        // branched over.
+        const int v_first = __builtin_amdgcn_readfirstlane(v), v_span = COL ? 64 / NL - 1 : 63;
+        const int want = ks_hi - ks_lo;  // uniform
 #pragma unroll
         for (int k = 0; k < R3; ++k) {
             const int kk = v + k * (Q / R3);
             const int ks = kk < Q / 2 ? kk : kk - Q;
             const int l = a.P * ks + p;
+            if constexpr (!FUSED && !(COL && LOGQ == 12)) {  // (the 1024-thread column kernel has no register to spare)
+                const int rel_first = (v_first - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
+                if (rel_first + v_span < 0 || rel_first >= want) continue;  // wave-uniform
+            }
             if constexpr (FUSED) {
                 if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
             } else if constexpr (COL) {
@@ -1623,6 +1785,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL), LOGQ == 12 && !COL ? FV_ST_M
             }
         }
     }
+    FV_STAMP(6);  // pass 3 done, stores issued
     if constexpr (FUSED) {
         // ---- gather from the tile: 8 lanes (one per column) per item, 64 items in flight -----------
         __syncthreads();
@@ -2111,6 +2274,12 @@ class Nufft3 {
         buf0.reserve(sizeof(cplx<T>) * (size_t)cells);
         buf1.reserve(sizeof(cplx<T>) * (size_t)cells);
         for (int d = 0; d < dim; ++d) {
+            // growing a table frees its contents: forget the geometry they were built for, so that set_geometry
+            // rebuilds them instead of trusting an unchanged (na, n2)
+            if (sizeof(T) * (size_t)na_max[d] > dec[d].cap || sizeof(cplx<T>) * (size_t)n2_max[d] > tw[d].cap) {
+                geo.d[d].na = -1;
+                geo.d[d].n2 = -1;
+            }
             dec[d].reserve(sizeof(T) * (size_t)na_max[d]);
             tw[d].reserve(sizeof(cplx<T>) * (size_t)n2_max[d]);
         }
@@ -2486,11 +2655,19 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     if (rowfft_uses_st(g, a.colmode != 0) && (a.colmode || in_blk || out_blk))
         FV_REQUIRE(std::max(in_plane, a.rpp_valid * a.out_pitch) * (int64_t)sizeof(cplx<T>) < (int64_t(1) << 32),
                    "grid planes of 4 GiB and more per transform are not supported by the column pass");
-    const int64_t ngroups8 = cdiv(cdiv(a.nrows, a.rpw), 8);  // row groups, in eights (one per XCD)
+    // PAIR: two residues per job (k_rowfft_st) for folded rows of Q = 1024 / 2048 -- FFTVIS_HIP_PAIR = 0 off, 1 row mode
+    // only, 2 row and column mode
+    static const int pair_mode = std::getenv("FFTVIS_HIP_PAIR") ? std::atoi(std::getenv("FFTVIS_HIP_PAIR")) : FV_PAIR_DEFAULT;
+    const bool st = rowfft_uses_st(g, a.colmode != 0);
+    const bool pair = st && !fused && a.n_in > g.Q && g.P >= 2 && (g.logQ == 10 || g.logQ == 11) &&
+                      (a.colmode ? pair_mode >= 2 : (pair_mode >= 1 && a.rpw >= 2));
+    const int nl = pair && !a.colmode ? a.rpw / 2 : a.rpw;   // data lines per workgroup
+    const int pj = pair ? (g.P + 1) / 2 : g.P;               // jobs per line group
+    const int64_t ngroups8 = cdiv(cdiv(a.nrows, nl), 8);  // line groups, in eights (one per XCD)
     if (std::getenv("FFTVIS_HIP_DEBUG_FFT"))
-        std::fprintf(stderr, "rowfft col=%d n_in=%d n_out=%d n2=%d P=%d Q=%d nrows=%lld rpw=%d wgs=%lld\n", a.colmode, a.n_in,
-                     a.n_out, a.n2, a.P, a.Q, (long long)a.nrows, a.rpw, (long long)(ngroups8 * 8 * g.P));
-    if (in1 && !rowfft_uses_st(g, a.colmode != 0)) {  // no gang variant of the LDS kernel: two launches
+        std::fprintf(stderr, "rowfft col=%d n_in=%d n_out=%d n2=%d P=%d Q=%d nrows=%lld rpw=%d pair=%d wgs=%lld\n", a.colmode, a.n_in,
+                     a.n_out, a.n2, a.P, a.Q, (long long)a.nrows, a.rpw, (int)pair, (long long)(ngroups8 * 8 * pj));
+    if (in1 && !st) {  // no gang variant of the LDS kernel: two launches
         rowfft(in, out, g, twd, nplanes, rpp, in_plane, in_row, in_elem, out_pitch, rpp_valid, fused);
         FusedArgs f1{};
         if (fused) {
@@ -2502,12 +2679,12 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     }
     a.in1 = in1;
     a.out1 = out1;
-    dim3 jobs((unsigned)(ngroups8 * 8 * g.P), in1 ? 2 : 1);
+    dim3 jobs((unsigned)(ngroups8 * 8 * pj), in1 ? 2 : 1);
     a.jobs_per_xcd = 0;
-    if (rowfft_uses_st(g, a.colmode != 0) && !a.colmode) {
+    if (st && !a.colmode) {
         FV_REQUIRE(a.nrows < (int64_t(1) << 30), "row FFT: too many rows");
-        a.jobs_per_xcd = (int)(cdiv(cdiv(a.nrows, 8), a.rpw) * a.rpw);           // rows per XCD, whole workgroups
-        jobs.x = (unsigned)(8 * (a.jobs_per_xcd / a.rpw) * g.P);
+        a.jobs_per_xcd = (int)(cdiv(cdiv(a.nrows, 8), nl) * nl);           // rows per XCD, whole workgroups
+        jobs.x = (unsigned)(8 * (a.jobs_per_xcd / nl) * pj);
     }
     if (rowfft_uses_st(g, a.colmode != 0)) {
         const int s1 = g.Q / (g.logQ == 9 ? 8 : 16);       // stride of the first radix pass
@@ -2517,16 +2694,31 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
         const int nld = need <= 4 ? 4 : need <= 8 ? 8 : 16;
         const bool col = a.colmode != 0;
         FV_REQUIRE(!col || in_elem < (1 << 23), "column pass: row pitch beyond the 24-bit index multiply");
+#define FV_ST_LAUNCH1(LQ, COLM, NLD, FUSEDV, FOLDV, INBV, PAIRV, FZ)                                     \
+    hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, INBV, PAIRV>), jobs,              \
+                       dim3(st_threads(LQ, COLM, PAIRV)), 0, stream, in, out, twd, a, FZ);
 #define FV_ST_LAUNCH(LQ, COLM, NLD, FUSEDV, FOLDV, FZ)                                                  \
-    if (COLM && in_blk && (1 << in_blk) == a.rpw) {                                                    \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, COLM ? 2 : 0>), jobs,         \
-                           dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FZ);                \
-    } else if (COLM && in_blk) {                                                                       \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, COLM ? 1 : 0>), jobs,         \
-                           dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FZ);                \
-    } else {                                                                                           \
-        hipLaunchKernelGGL((k_rowfft_st<T, LQ, COLM, NLD, FUSEDV, FOLDV, 0>), jobs,                    \
-                           dim3(st_threads(LQ, COLM)), 0, stream, in, out, twd, a, FZ);                \
+    {                                                                                                  \
+        constexpr bool PAIRABLE = FOLDV && !FUSEDV && (LQ == 10 || LQ == 11);                          \
+        if (COLM && in_blk && (1 << in_blk) == nl) {                                                   \
+            if (PAIRABLE && pair) {                                                                    \
+                FV_ST_LAUNCH1(LQ, COLM, NLD, FUSEDV, FOLDV, (COLM ? 2 : 0), PAIRABLE, FZ)              \
+            } else {                                                                                   \
+                FV_ST_LAUNCH1(LQ, COLM, NLD, FUSEDV, FOLDV, (COLM ? 2 : 0), false, FZ)                 \
+            }                                                                                          \
+        } else if (COLM && in_blk) {                                                                   \
+            if (PAIRABLE && pair) {                                                                    \
+                FV_ST_LAUNCH1(LQ, COLM, NLD, FUSEDV, FOLDV, (COLM ? 1 : 0), PAIRABLE, FZ)              \
+            } else {                                                                                   \
+                FV_ST_LAUNCH1(LQ, COLM, NLD, FUSEDV, FOLDV, (COLM ? 1 : 0), false, FZ)                 \
+            }                                                                                          \
+        } else {                                                                                       \
+            if (PAIRABLE && pair) {                                                                    \
+                FV_ST_LAUNCH1(LQ, COLM, NLD, FUSEDV, FOLDV, 0, PAIRABLE, FZ)                           \
+            } else {                                                                                   \
+                FV_ST_LAUNCH1(LQ, COLM, NLD, FUSEDV, FOLDV, 0, false, FZ)                              \
+            }                                                                                          \
+        }                                                                                              \
     }
 #define FV_ST_GO(LQ, COLM, NLD)                                                                        \
     if (a.n_in > g.Q && NLD == (LQ == 9 ? 8 : 16)) {                                                   \
@@ -2563,6 +2755,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
 #undef FV_ST_NLD
 #undef FV_ST_GO
 #undef FV_ST_LAUNCH
+#undef FV_ST_LAUNCH1
         return;
     }
     const size_t smem = sizeof(cplx<T>) * (size_t)a.lds_row * a.rpw;
