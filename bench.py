@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-PMC_FILE = os.path.join("profiles", "r02_hbm_traffic_pmc.json")
+PMC_FILE = os.path.join("profiles", "r03_hbm_traffic_pmc.json")
 
 
 def parse():

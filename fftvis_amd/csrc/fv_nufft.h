@@ -1102,6 +1102,12 @@ __host__ __device__ inline int ceil_div_signed(int a, int b) {  // ceil(a / b), 
 
 template <bool WAVE>
 __device__ inline void st_sync() {
+#if defined(FV_ABL) && (FV_ABL & 4)  // diagnostic build: no barriers between the passes (wrong results; what they cost)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return;
+#endif
     if constexpr (WAVE) {  // the row lives in one wavefront: LDS is in order, only the compiler must not reorder
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -21,5 +21,15 @@ def problem():
     return x, y, c, s, t
 
 
+def problem_folded():
+    """C3's widest grid, 10240 x 8192 = (5 x 2048) x (4 x 2048): both passes folded, odd and even residue counts."""
+    rng = np.random.default_rng(18)
+    M, N = 500, 300
+    x, y = rng.uniform(-3, 3, (2, M))
+    c = rng.normal(size=(3, M)) + 1j * rng.normal(size=(3, M))
+    return x, y, c, rng.uniform(-1300, 1300, N), rng.uniform(-1040, 1040, N)
+
+
 if __name__ == "__main__":
-    np.save(sys.argv[1], gpu_nufft2d(*problem(), 1e-9))
+    which = problem_folded if len(sys.argv) > 2 and sys.argv[2] == "folded" else problem
+    np.save(sys.argv[1], gpu_nufft2d(*which(), 1e-9))

@@ -438,3 +438,25 @@ def test_fft_layout_switches_leave_the_result_bit_identical(gpu, tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert np.array_equal(np.load(out), ref)
+
+
+def test_paired_residue_jobs_leave_the_result_unchanged(gpu, tmp_path):
+    """The folded row FFT can compute two residues per job from one pass over a row's inputs (k_rowfft_st<.., PAIR>;
+    default: row mode).  Off (FFTVIS_HIP_PAIR=0), row mode only (1) and row + column mode (2) agree to rounding on a
+    grid whose two passes are both folded (5 and 4 residues: an odd count leaves a job with one residue), and meet the
+    tolerance against the exact sum.  (The switch is read once per process, hence the worker.)"""
+    from oracle import nudft
+    from tests.nufft_worker import problem_folded
+
+    x, y, c, s, t = problem_folded()
+    exact = nudft.nudft_type3([x, y], c, [s, t])
+    res = {}
+    for mode in ("0", "1", "2"):
+        out = tmp_path / f"pair{mode}.npy"
+        env = dict(os.environ, PYTHONPATH=ROOT, FFTVIS_HIP_PAIR=mode)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nufft_worker.py"), str(out), "folded"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        res[mode] = np.load(out)
+        assert rel_l2(res[mode], exact) < 5e-9, mode
+    assert rel_l2(res["1"], res["0"]) < 1e-13 and rel_l2(res["2"], res["0"]) < 1e-13

@@ -6,24 +6,25 @@ O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 B="python3 $R/bench.py"
 # ---- bench lines: the default (driver) workload C3, then the others, clearly named -----------------------
 $B > $O/bench_c3.json 2>$O/bench_c3.err &&
-$B --upsample 0 --no-cpu-baseline > $O/bench_c3_auto.json 2>/dev/null &&
+$B --upsample 0 --no-cpu-baseline --no-e2e > $O/bench_c3_auto.json 2>/dev/null &&
 $B --path type1 --no-cpu-baseline > $O/bench_c3_type1.json 2>/dev/null &&
-FFTVIS_HIP_NO_HERMITIAN=1 $B --steps 2 --no-cpu-baseline > $O/bench_c3_four_transforms.json 2>/dev/null &&
-$B --workload C2 > $O/bench_c2.json 2>/dev/null &&
-$B --workload C5 --ntimes 2 --steps 2 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null &&
-$B --workload C4 --nfreq 32 --ntimes 2 --steps 2 --no-cpu-baseline > $O/bench_c4slice.json 2>/dev/null &&
-$B --workload C4 --steps 1 --warmup 0 --no-cpu-baseline --no-breakdown > $O/bench_c4_full.json 2>/dev/null &&
-$B --workload C5 --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $O/bench_c5_full.json 2>/dev/null
+FFTVIS_HIP_NO_HERMITIAN=1 $B --steps 2 --no-cpu-baseline --no-e2e > $O/bench_c3_four_transforms.json 2>/dev/null &&
+$B --workload C2 --no-e2e > $O/bench_c2.json 2>/dev/null &&
+$B --workload C5 --ntimes 2 --steps 2 --no-cpu-baseline --no-e2e > $O/bench_c5.json 2>/dev/null &&
+$B --workload C4 --nfreq 32 --ntimes 2 --steps 2 --no-cpu-baseline --no-e2e > $O/bench_c4slice.json 2>/dev/null &&
+$B --workload C4 --steps 1 --warmup 0 --no-cpu-baseline --no-breakdown --no-e2e > $O/bench_c4_full.json 2>/dev/null &&
+$B --workload C5 --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown --no-e2e > $O/bench_c5_full.json 2>/dev/null &&
+FFTVIS_BENCH_BACKEND=gloo FFTVIS_BENCH_SHARE_GPU=1 $B --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c3_two_ranks_one_gpu.json 2>/dev/null
 echo bench rc=$?
 # ---- what an 8-rank job's ranks would each do, one block shape at a time on this one GPU (strong scaling) --
 for w in C3 C4; do for r in 0 1; do
-  $B --workload $w --as-rank $r --of-ranks 8 --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown > $O/bench_${w}_rank${r}of8.json 2>/dev/null
+  $B --workload $w --as-rank $r --of-ranks 8 --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-e2e > $O/bench_${w}_rank${r}of8.json 2>/dev/null
 done; done
 echo rank-blocks rc=$?
 # ---- rocprofv3 kernel stats of the same commands (no breakdown step: only launches shaped like the timed region) --
 prof() { # tag, bench args...
   t=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$t -- python3 $R/bench.py "$@" --no-cpu-baseline --no-breakdown > $O/prof_$t.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$t -- python3 $R/bench.py "$@" --no-cpu-baseline --no-breakdown --no-e2e > $O/prof_$t.log 2>&1
 }
 prof c3 --steps 2 --warmup 1 && prof c2 --workload C2 && prof c4slice --workload C4 --nfreq 32 --ntimes 2 --steps 1 --warmup 1 &&
 prof c3type1 --path type1 --steps 1 --warmup 1
@@ -31,7 +32,7 @@ echo prof rc=$?
 # ---- HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (kernel trace only), full-size launches ----
 pmc() { # tag, counter, bench args...
   t=$1; c=$2; shift; shift
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_$t -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown > $O/pmc_${c}_$t.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_$t -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-breakdown --no-e2e > $O/pmc_${c}_$t.log 2>&1
 }
 for c in FETCH_SIZE WRITE_SIZE; do
   pmc c3 $c --ntimes 1 && pmc c2 $c --workload C2 && pmc c4slice $c --workload C4 --nfreq 32 --ntimes 1 && pmc c3type1 $c --path type1 --ntimes 1

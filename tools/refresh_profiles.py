@@ -1,12 +1,13 @@
 """Copies the outputs of tools/collect_profiles.sh (gpurun_out/final) into profiles/ under the round's names,
-rebuilds the PMC traffic summary and prints the numbers DESIGN.md quotes.  usage: python tools/refresh_profiles.py r02"""
+rebuilds the PMC traffic summary and prints the numbers DESIGN.md quotes.  usage: python tools/refresh_profiles.py r03"""
 import collections, csv, glob, json, os, re, shutil, sys
 
-tagr = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tagr = sys.argv[1] if len(sys.argv) > 1 else "r03"
 O = "gpurun_out/final"
 names = {"bench_c3": "c3_bench", "bench_c3_auto": "c3_bench_upsample_auto", "bench_c3_type1": "c3_bench_type1",
          "bench_c3_four_transforms": "c3_bench_four_transforms", "bench_c2": "c2_bench", "bench_c5": "c5_bench",
-         "bench_c4slice": "c4slice_bench", "bench_c4_full": "c4_full_one_gpu_bench", "bench_c5_full": "c5_full_one_gpu_bench"}
+         "bench_c4slice": "c4slice_bench", "bench_c4_full": "c4_full_one_gpu_bench", "bench_c5_full": "c5_full_one_gpu_bench",
+         "bench_c3_two_ranks_one_gpu": "c3_two_ranks_on_one_gpu_rehearsal_bench"}
 for w in ("C3", "C4"):
     for r in (0, 1):
         names[f"bench_{w}_rank{r}of8"] = f"{w.lower()}_rank{r}_of_8_block_bench"
