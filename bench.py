@@ -212,7 +212,13 @@ def spawn_ranks(n: int) -> int:
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # the ranks' stdout carries rank 0's JSON line -- and, under gloo, the transport's connection chatter: only the JSON
+    # line goes to our stdout (the contract is ONE line), everything else to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
