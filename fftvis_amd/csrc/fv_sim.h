@@ -1473,6 +1473,11 @@ class Sim : public SimBase {
             dout = d_out.as<cplx<T>>();
         }
         FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
+        // host output: the lattice path computes a C3 block in 65 ms, so the 10-GB copy IS the call -- the caller's array
+        // is touched in parallel and pinned while the kernels run (HostPin), then one copy at PCIe rate (0.72 -> 0.3 s)
+        const bool drain = !out_on_device && out_bytes >= drain_min_bytes();
+        HostPin pin;
+        if (drain) pin.start(device, out, out_bytes);
         const double sigma = this->sigma == 0.0 ? 2.0 : this->sigma;  // "auto" is a type-3 matter
         sigma_run = sigma;
         if (!t1fft) t1fft.reset(new Nufft3<T>(2, eps, sigma, stream));
@@ -1668,7 +1673,10 @@ class Sim : public SimBase {
             }
         }
         if (!out_on_device) {
-            FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
+            if (drain && pin.wait())
+                copy_block_pinned(out, dout, out_bytes, stream);
+            else
+                FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
             FV_HIP(hipStreamSynchronize(stream));
             if (timing_level) ev_collect();
             check_errors();
@@ -1732,7 +1740,7 @@ class Sim : public SimBase {
     // ---- host output, overlapped (reference cpu_simulate.py:843-854 returns a host array) ---------------------
     // A block of visibilities is 10 GB at C3.  Copied after the last kernel into fresh pageable memory it moves at
     // ~16 GB/s (first touch of every page included: 0.6 s after 1.6 s of compute).  Instead a helper thread pins
-    // the caller's array in place (hipHostRegister: 22 GB/s measured, CPU work) while this thread queues the run,
+    // the caller's array in place (HostPin: parallel first touch, then hipHostRegister) while this thread queues the run,
     // every time step's last kernel records an event, and as soon as the array is pinned
     // the queueing thread issues, on a separate stream, one asynchronous copy per (channel, finished time step)
     // behind that step's event (53 GB/s, PCIe Gen5).  Only the last step's copy (0.5 GB, 10 ms) is left when the
@@ -1759,15 +1767,35 @@ class Sim : public SimBase {
         double t_pinned = 0;  // seconds after start() (FFTVIS_HIP_DEBUG_DRAIN)
         std::chrono::steady_clock::time_point t0;
         double since() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-        // In pieces cut at the multiples of 256 MiB of the address space (no page is registered twice; a copy is split
-        // at the same addresses, drain_flush): the driver serialises a registration with other memory calls, and a cold
-        // handle still allocates its tables while the first time step is being queued -- behind ONE 10-GB registration
-        // (0.42 s) that thread, and with it the GPU, sat idle.
+        // Pinning a FRESH array is slow because every page is touched for the first time inside the call, by one thread
+        // (22 GB/s; 16.6 GB/s for a plain memset) -- the same pages touched by 16 threads first take 175-230 GB/s, and
+        // registering touched memory 480 GB/s (measured, 4 GB).  So: a pool of threads writes one byte into every page
+        // of the caller's array (its content is about to be overwritten by the block anyway), then the array is
+        // registered in pieces cut at the multiples of 256 MiB of the address space (no page is registered twice; a copy
+        // is split at the same addresses, drain_flush; short calls, so that a cold handle's allocations are not held up
+        // behind the driver lock).  10 GB: pinned 0.08 s after the start instead of 0.45 s.
         static constexpr uintptr_t PIECE = (uintptr_t)256 << 20;
+        static int touch_threads() {
+            const unsigned hw = std::thread::hardware_concurrency();
+            return (int)std::max(1u, std::min(16u, hw / 4));
+        }
         void start(int device, void *ptr, size_t bytes) {
+            t0 = std::chrono::steady_clock::now();
             th = std::thread([this, device, ptr, bytes] {
                 (void)hipSetDevice(device);
                 char *p = static_cast<char *>(ptr), *end = p + bytes;
+                {  // first touch, in parallel
+                    const int nt = touch_threads();
+                    std::vector<std::thread> pool;
+                    const size_t share = (bytes + nt - 1) / nt;
+                    for (int i = 0; i < nt; ++i)
+                        pool.emplace_back([=] {
+                            volatile char *q = p + std::min(bytes, share * i);
+                            volatile char *stop = p + std::min(bytes, share * (i + 1));
+                            for (; q < stop; q += 4096) *q = 0;
+                        });
+                    for (std::thread &t : pool) t.join();
+                }
                 bool ok = true;
                 while (ok && p < end) {
                     const uintptr_t stop = (reinterpret_cast<uintptr_t>(p) / PIECE + 1) * PIECE;
@@ -1820,6 +1848,20 @@ class Sim : public SimBase {
         }
     }
 
+    // one asynchronous copy of a whole block into a pinned caller array, split where the pinned pieces meet
+    void copy_block_pinned(void *out, const void *dout, size_t bytes, hipStream_t on) {
+        char *dst = static_cast<char *>(out);
+        const char *src = static_cast<const char *>(dout);
+        while (bytes) {
+            const uintptr_t stop = (reinterpret_cast<uintptr_t>(dst) / HostPin::PIECE + 1) * HostPin::PIECE;
+            const size_t n = std::min<size_t>(bytes, stop - reinterpret_cast<uintptr_t>(dst));
+            FV_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, on));
+            dst += n;
+            src += n;
+            bytes -= n;
+        }
+    }
+
     void run(int t0, int t1, int f0, int f1, void *out, int out_on_device) override {
         FV_HIP(hipSetDevice(device));
         FV_REQUIRE(nsrc >= 0 && !rots.empty() && !freqs.empty() && nbls > 0 && !pairs.empty(),
@@ -1850,10 +1892,8 @@ class Sim : public SimBase {
         const bool drain = !out_on_device && out_bytes >= drain_min_bytes();
         std::vector<DrainItem> drain_items;
         size_t drained = 0;
-        HostPin pin;  // started once the first unit is queued: a cold handle's first-use allocations would otherwise
-                      // wait on the registration (the driver serialises them) while the GPU has nothing to do yet
-        bool pin_started = false;
-        pin.t0 = std::chrono::steady_clock::now();
+        HostPin pin;
+        if (drain) pin.start(device, out, out_bytes);
 
         double xc[3], X[3];
         source_box(xc, X);
@@ -2235,13 +2275,7 @@ class Sim : public SimBase {
                 L0.heavy_pending = true;
             }
             close_time();
-            if (drain && !pin_started) {
-                if (std::getenv("FFTVIS_HIP_DEBUG_DRAIN")) std::fprintf(stderr, "drain: first unit queued %.3f s\n", pin.since());
-                pin.start(device, out, out_bytes);
-                pin_started = true;
-            }
         }
-        if (drain && !pin_started) pin.start(device, out, out_bytes);
         if (nlanes > 1 && !pipe) {  // join: everything queued on the main stream afterwards sees both lanes
             FV_HIP(hipEventRecord(lanes[1].done, lanes[1].stream));
             FV_HIP(hipStreamWaitEvent(stream, lanes[1].done, 0));
