@@ -146,7 +146,14 @@ inline void cap_column_q(DimGeom &g) {
     }
 }
 
-inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
+// How much of the rounding slack of n2 goes into a finer source grid (0 = none, 1 = all of it): see set_dim_geom.
+inline double geom_slack_share() {
+    static const double v = std::getenv("FFTVIS_HIP_GRID_SLACK") ? std::atof(std::getenv("FFTVIS_HIP_GRID_SLACK")) : 1.0;
+    return std::min(1.0, std::max(0.0, v));
+}
+
+// last_dim: the dimension the gather reads contiguously (transformed by the last pass).
+inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max, bool last_dim = true) {
     g.S = std::fabs(scale_max) * g.B;
     double Xs = g.X, Ss = g.S;
     if (Xs == 0) {
@@ -159,16 +166,36 @@ inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max) {
         Ss = std::max(Ss, 1.0 / Xs);
     int n1 = (int)std::ceil(2.0 * sigma * Ss * Xs / M_PI + w + 1);
     n1 += n1 % 2;
-    g.n1 = n1;
-    g.na = (int)cdiv(n1, 1 << BINLOG) << BINLOG;  // whole source bins
     // the gather's footprints reach |eta| <= n2 / (2 sigma) + w / 2 and must stay inside the n2 outputs
     // (no periodic wrap there): n2 (1 - 1 / sigma) >= w + 4.  Only tiny grids at sigma = 1.25 are affected
     // (they lost up to 250 eps at tight tolerances before).
     const int nwrap = (int)std::ceil((w + 4) / (1.0 - 1.0 / sigma));
-    choose_pq(std::max({g.na, (int)std::ceil(sigma * n1), nwrap}), g);
-    g.h = M_PI / (sigma * Ss);
-    // targets sit at |eta| <= n2/(2 sigma) (in transform cells); keep the footprint around them
-    g.no = 2 * ((int)std::ceil(0.5 * g.n2 / sigma) + w / 2 + 2);
+    choose_pq(std::max({(int)cdiv(n1, 1 << BINLOG) << BINLOG, (int)std::ceil(sigma * n1), nwrap}), g);
+    // n2 = P 2^b is rounded up, by up to a third (6144, 8192, 10240 ...), and the transform itself only needs
+    // n2 >= sigma n1.  The slack goes into a FINER source grid: spacing h = pi / (so S) with so >= sigma -- the
+    // outer step more oversampled than asked, never less accurate -- grown until sigma n1(so) reaches n2.  The
+    // sources then touch more cells (n1 up), but the targets span fewer transform outputs, |eta| <= n2 / (2 so),
+    // so every LATER pass has fewer lines to transform and the gather's grid shrinks (C3, x: na 4688 -> 5120, no
+    // 5132 -> 4700 at n2 = 10240).  Not in the last dimension, which has no later pass to gain from it.
+    double so = sigma;
+    if (!last_dim && geom_slack_share() > 0.0) {
+        const double so_max = ((double)g.n2 / sigma - w - 3.0) * M_PI / (2.0 * Ss * Xs);
+        if (so_max > sigma) {
+            const double so_try = sigma + geom_slack_share() * (so_max - sigma);
+            int n1s = (int)std::ceil(2.0 * so_try * Ss * Xs / M_PI + w + 1);
+            n1s += n1s % 2;
+            const int nas = (int)cdiv(n1s, 1 << BINLOG) << BINLOG;
+            if (n1s >= n1 && (double)n1s * sigma <= (double)g.n2 && nas <= g.n2) {
+                so = so_try;
+                n1 = n1s;
+            }
+        }
+    }
+    g.n1 = n1;
+    g.na = (int)cdiv(n1, 1 << BINLOG) << BINLOG;  // whole source bins
+    g.h = M_PI / (so * Ss);
+    // targets sit at |eta| <= n2/(2 so) (in transform cells); keep the footprint around them
+    g.no = 2 * ((int)std::ceil(0.5 * g.n2 / so) + w / 2 + 2);
     g.no = std::min(g.no, g.n2);
 }
 
@@ -1732,7 +1759,11 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     // Column mode: base = the first column's run, lanes add their own row's offset and mask by the index -1.
     const int ks_lo = ceil_div_signed(-half_n - p, a.P), ks_hi = ceil_div_signed(a.n_out - half_n - p, a.P);
     const int64_t res_off = (a.cnt ? ((p + half_n) % a.P) * a.cnt + (p + half_n) / a.P : p + half_n) + (int64_t)ks_lo * ostep;
+#if defined(FV_ABL) && (FV_ABL & 8)  // diagnostic build: the x-pass stores contiguous runs (the y-pass then reads garbage)
+    const bool out_blocked = false;
+#else
     const bool out_blocked = !COL && !FUSED && a.out_blk;
+#endif
     const int64_t out_base = out_blocked ? rplane * a.rpp_valid * a.out_pitch + (rk << a.out_blk)
                              : COL       ? ((row0 / a.rpp) * a.rpp_valid + row0 % a.rpp) * a.out_pitch + res_off
                                          : (rplane * a.rpp_valid + rk) * a.out_pitch + res_off;
@@ -1905,7 +1936,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const T *__restrict__ bt1, const T *__restrict__ bt2, const int *__restrict__ bl_idx,
     const signed char *__restrict__ flip, const double *__restrict__ scale, InterpArgs a,
     KerParams ker, cplx<T> *__restrict__ out, const cplx<T> *__restrict__ coef,
-    const int *__restrict__ ant1, const int *__restrict__ ant2) {
+    const int *__restrict__ ant1, const int *__restrict__ ant2, const int *__restrict__ ustart) {
     const int tid = threadIdx.x;
     const int g = tid & (GROUP - 1);
     const int lane_base = (tid & 63) & ~(GROUP - 1);
@@ -1917,7 +1948,13 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const int64_t item = (int64_t)(blockIdx.x & 7) * per_xcd + (int64_t)(blockIdx.x >> 3) * IPW + tid / GROUP;
     if ((int64_t)(blockIdx.x >> 3) * IPW + tid / GROUP >= per_xcd || item >= N * a.nfg) return;  // whole group exits together
     const int fg = (int)(item / N);
-    const int64_t kl = item % N;
+    // Redundant baselines (ustart != nullptr): N counts the DISTINCT target vectors of the caller's list, entries
+    // [ustart[i], ustart[i + 1]) of the (u, v)-ordered list share target i -- the same point of the transform -- so it
+    // is gathered once, at the first member's coordinates, and the 16 lanes then write every member's output slot
+    // (each with its own conjugation / feed transposition / eigenbeam coefficients).
+    const int64_t ui = item % N;
+    const int64_t m0 = ustart ? ustart[ui] : ui, m1 = ustart ? ustart[ui + 1] : ui + 1;
+    const int64_t kl = m0;
     const int64_t k = bl_idx ? bl_idx[kl] : kl;
     const double sg = ((flip && flip[kl]) != (a.negate_all != 0)) ? -1.0 : 1.0;
     const double sc = scale[fg];
@@ -2037,45 +2074,47 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                 vim[side][r] = vi;
                 continue;
             }
-            if (g != 0) continue;
-            if (sg < 0) vi = -vi;  // conj for flipped baselines (cpu_simulate.py:298)
-            const int rt = a.transpose_flipped && sg < 0 && a.tpol == 4 ? (r & 1) * 2 + (r >> 1) : r;
-            const int64_t po = rt < 16 ? a.out_pol_off[rt] : (int64_t)rt * a.out_pol_off[1];
-            cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + k * a.out_k_stride;
-            cplx<T> *o = ob + po;
-            if (a.basis) {
-                const int f = a.f_first + fg;
-                const int64_t cs1 = (int64_t)ant1[k] * a.nbasis, cs2 = (int64_t)ant2[k] * a.nbasis;
-                const cplx<T> c1k = coef[(cs1 + a.kk) * a.ncoef_freq + f];
-                const cplx<T> c2l = coef[(cs2 + a.ll) * a.ncoef_freq + f];
-                const cplx<double> w1 = cmul(cplx<double>{(double)c1k.re, -(double)c1k.im},
-                                             cplx<double>{(double)c2l.re, (double)c2l.im});
-                const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
-                if (a.basis_part != 2) {
-                    o->re += (T)v1.re;
-                    o->im += (T)v1.im;
+            for (int64_t m = m0 + g; m < m1; m += GROUP) {  // the target's members, dealt over the 16 lanes (no list: lane 0)
+                const int64_t km = bl_idx ? bl_idx[m] : m;
+                const bool neg = (flip && flip[m]) != (a.negate_all != 0);
+                const double vim_ = neg ? -vi : vi;  // conj for flipped baselines (cpu_simulate.py:298)
+                const int rt = a.transpose_flipped && neg && a.tpol == 4 ? (r & 1) * 2 + (r >> 1) : r;
+                const int64_t po = rt < 16 ? a.out_pol_off[rt] : (int64_t)rt * a.out_pol_off[1];
+                cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + km * a.out_k_stride;
+                cplx<T> *o = ob + po;
+                if (a.basis) {
+                    const int f = a.f_first + fg;
+                    const int64_t cs1 = (int64_t)ant1[km] * a.nbasis, cs2 = (int64_t)ant2[km] * a.nbasis;
+                    const cplx<T> c1k = coef[(cs1 + a.kk) * a.ncoef_freq + f];
+                    const cplx<T> c2l = coef[(cs2 + a.ll) * a.ncoef_freq + f];
+                    const cplx<double> w1 = cmul(cplx<double>{(double)c1k.re, -(double)c1k.im},
+                                                 cplx<double>{(double)c2l.re, (double)c2l.im});
+                    const cplx<double> v1 = cmul(w1, cplx<double>{vr, vim_});
+                    if (a.basis_part != 2) {
+                        o->re += (T)v1.re;
+                        o->im += (T)v1.im;
+                    }
+                    if (a.kk != a.ll && a.basis_part != 1) {
+                        const cplx<T> c1l = coef[(cs1 + a.ll) * a.ncoef_freq + f];
+                        const cplx<T> c2k = coef[(cs2 + a.kk) * a.ncoef_freq + f];
+                        const cplx<double> w2 = cmul(cplx<double>{(double)c1l.re, -(double)c1l.im},
+                                                     cplx<double>{(double)c2k.re, (double)c2k.im});
+                        const cplx<double> v2 = cmul(w2, cplx<double>{vr, vim_});
+                        const int rs = (r & 1) * 2 + (r >> 1);  // feed-transposed slot (V.swapaxes(1, 2))
+                        cplx<T> *o2 = ob + a.out_pol_off[rs];
+                        o2->re += (T)v2.re;
+                        o2->im += (T)v2.im;
+                    }
+                } else if (a.accumulate) {
+                    o->re += (T)vr;
+                    o->im += (T)vim_;
+                } else {
+                    *o = {(T)vr, (T)vim_};
                 }
-                if (a.kk != a.ll && a.basis_part != 1) {
-                    const cplx<T> c1l = coef[(cs1 + a.ll) * a.ncoef_freq + f];
-                    const cplx<T> c2k = coef[(cs2 + a.kk) * a.ncoef_freq + f];
-                    const cplx<double> w2 = cmul(cplx<double>{(double)c1l.re, -(double)c1l.im},
-                                                 cplx<double>{(double)c2k.re, (double)c2k.im});
-                    const cplx<double> v2 = cmul(w2, cplx<double>{vr, vi});
-                    const int rs = (r & 1) * 2 + (r >> 1);  // feed-transposed slot (V.swapaxes(1, 2))
-                    cplx<T> *o2 = ob + a.out_pol_off[rs];
-                    o2->re += (T)v2.re;
-                    o2->im += (T)v2.im;
-                }
-            } else if (a.accumulate) {
-                o->re += (T)vr;
-                o->im += (T)vi;
-            } else {
-                *o = {(T)vr, (T)vi};
             }
         }
     }
     if constexpr (HERM) {
-        if (g != 0) return;
         // P = T1(s), M = T1(-s), C = T2(s), D = T2(-s)
         const double Pr = vre[0][0], Pi = vim[0][0], Mr = vre[1][0], Mi = vim[1][0];
         double o_re[4], o_im[4];
@@ -2095,39 +2134,43 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
             o_re[2] = Dr;   // conj D
             o_im[2] = -Di;
         }
-        cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + k * a.out_k_stride;
-        cplx<double> w1 = {1.0, 0.0}, w2 = {0.0, 0.0};
-        if (a.basis) {  // eigenbeam term (k, l): vis += conj(C[a1,k]) C[a2,l] V  (+ the transposed (l, k) term)
-            const int f = a.f_first + fg;
-            const int64_t cs1 = (int64_t)ant1[k] * a.nbasis, cs2 = (int64_t)ant2[k] * a.nbasis;
-            const cplx<T> c1k = coef[(cs1 + a.kk) * a.ncoef_freq + f];
-            const cplx<T> c2l = coef[(cs2 + a.ll) * a.ncoef_freq + f];
-            w1 = cmul(cplx<double>{(double)c1k.re, -(double)c1k.im}, cplx<double>{(double)c2l.re, (double)c2l.im});
-            if (a.kk != a.ll) {  // cpu_simulate.py:464-468
-                const cplx<T> c1l = coef[(cs1 + a.ll) * a.ncoef_freq + f];
-                const cplx<T> c2k = coef[(cs2 + a.kk) * a.ncoef_freq + f];
-                w2 = cmul(cplx<double>{(double)c1l.re, -(double)c1l.im}, cplx<double>{(double)c2k.re, (double)c2k.im});
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double vr = o_re[r], vi = sg < 0 ? -o_im[r] : o_im[r];  // conj for flipped baselines
-            cplx<T> *o = ob + a.out_pol_off[a.transpose_flipped && sg < 0 ? (r & 1) * 2 + (r >> 1) : r];
-            if (a.basis) {
-                const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
-                o->re += (T)v1.re;
-                o->im += (T)v1.im;
-                if (a.kk != a.ll) {
-                    const cplx<double> v2 = cmul(w2, cplx<double>{vr, vi});
-                    cplx<T> *o2 = ob + a.out_pol_off[(r & 1) * 2 + (r >> 1)];  // feed-transposed slot
-                    o2->re += (T)v2.re;
-                    o2->im += (T)v2.im;
+        for (int64_t m = m0 + g; m < m1; m += GROUP) {  // the target's members, dealt over the 16 lanes (no list: lane 0)
+            const int64_t km = bl_idx ? bl_idx[m] : m;
+            const bool neg = (flip && flip[m]) != (a.negate_all != 0);
+            cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + km * a.out_k_stride;
+            cplx<double> w1 = {1.0, 0.0}, w2 = {0.0, 0.0};
+            if (a.basis) {  // eigenbeam term (k, l): vis += conj(C[a1,k]) C[a2,l] V  (+ the transposed (l, k) term)
+                const int f = a.f_first + fg;
+                const int64_t cs1 = (int64_t)ant1[km] * a.nbasis, cs2 = (int64_t)ant2[km] * a.nbasis;
+                const cplx<T> c1k = coef[(cs1 + a.kk) * a.ncoef_freq + f];
+                const cplx<T> c2l = coef[(cs2 + a.ll) * a.ncoef_freq + f];
+                w1 = cmul(cplx<double>{(double)c1k.re, -(double)c1k.im}, cplx<double>{(double)c2l.re, (double)c2l.im});
+                if (a.kk != a.ll) {  // cpu_simulate.py:464-468
+                    const cplx<T> c1l = coef[(cs1 + a.ll) * a.ncoef_freq + f];
+                    const cplx<T> c2k = coef[(cs2 + a.kk) * a.ncoef_freq + f];
+                    w2 = cmul(cplx<double>{(double)c1l.re, -(double)c1l.im}, cplx<double>{(double)c2k.re, (double)c2k.im});
                 }
-            } else if (a.accumulate) {
-                o->re += (T)vr;
-                o->im += (T)vi;
-            } else {
-                *o = {(T)vr, (T)vi};
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double vr = o_re[r], vi = neg ? -o_im[r] : o_im[r];  // conj for flipped baselines
+                cplx<T> *o = ob + a.out_pol_off[a.transpose_flipped && neg ? (r & 1) * 2 + (r >> 1) : r];
+                if (a.basis) {
+                    const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
+                    o->re += (T)v1.re;
+                    o->im += (T)v1.im;
+                    if (a.kk != a.ll) {
+                        const cplx<double> v2 = cmul(w2, cplx<double>{vr, vi});
+                        cplx<T> *o2 = ob + a.out_pol_off[(r & 1) * 2 + (r >> 1)];  // feed-transposed slot
+                        o2->re += (T)v2.re;
+                        o2->im += (T)v2.im;
+                    }
+                } else if (a.accumulate) {
+                    o->re += (T)vr;
+                    o->im += (T)vi;
+                } else {
+                    *o = {(T)vr, (T)vi};
+                }
             }
         }
     }
@@ -2265,7 +2308,7 @@ class Nufft3 {
         for (int d = 0; d < dim; ++d) {
             g[d].X = X[d];
             g[d].B = B[d];
-            set_dim_geom(g[d], sigma, ker.w, scale_max);
+            set_dim_geom(g[d], sigma, ker.w, scale_max, d == dim - 1);
             if (d > 0) cap_column_q(g[d]);
             g[d].rm = d != dim - 1 && !debug_switch_natural_order();
             if (na_max) na_max[d] = std::max(na_max[d], g[d].na);
@@ -2301,7 +2344,7 @@ class Nufft3 {
             geo.d[d].X = X[d];
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
-            set_dim_geom(geo.d[d], sigma, ker.w, scale_max);
+            set_dim_geom(geo.d[d], sigma, ker.w, scale_max, d == dim - 1);
             if (d > 0) cap_column_q(geo.d[d]);
             // (residue-major storage of the last dimension as well: C3's FFT passes -2.5 %, its gather +41 %)
             geo.d[d].rm = d != dim - 1 && !debug_switch_natural_order();
@@ -2477,7 +2520,7 @@ class Nufft3 {
                 const signed char *flip, const double *scale_dev, int nfg, int tpol,
                 cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                 const int64_t *out_pol_off, bool accumulate, const struct BasisTerm *basis = nullptr,
-                int herm = 0);
+                int herm = 0, const int *ustart = nullptr, int64_t nuniq = 0);
 
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
@@ -2929,8 +2972,10 @@ template <typename T>
 void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
                        const signed char *flip, const double *scale_dev, int nfg, int tpol,
                        cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
-                       const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis, int herm) {
+                       const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis, int herm,
+                       const int *ustart, int64_t nuniq) {
     if (N == 0 || nfg == 0) return;
+    if (ustart) N = nuniq;  // items are the distinct targets; bl_idx / flip stay the caller's full list
     FV_REQUIRE(!herm || (tpol == 2 && (herm == 2 || !basis || basis->kk == basis->ll)),
                "packed gather: two transforms per frequency; off-diagonal eigenbeam terms only with real strengths");
     for (int d = 0; d < dim && herm; ++d) FV_REQUIRE(geo.d[d].btc == 0.0, "packed gather needs a box symmetric about 0");
@@ -2989,7 +3034,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
                          : (herm ? (r9 ? k_interp<T, 3, true, 9> : k_interp<T, 3, true, 16>)
                                  : (r9 ? k_interp<T, 3, false, 9> : k_interp<T, 3, false, 16>));
     hipLaunchKernelGGL(kern, grid, dim3(INTERP_THREADS), 0, stream, (const cplx<T> *)grid_out, N, bt[0], bt[1], bt[2],
-                       bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2);
+                       bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2, ustart);
 }
 
 }  // namespace fv

@@ -997,6 +997,13 @@ class Sim : public SimBase {
         int64_t n;
         bool trivial;  // all baselines in order, nothing flipped
         std::unique_ptr<DevBuf> idx, flip;
+        // Redundant baselines: runs of the (u, v)-ordered list whose sign-adjusted vectors agree (build_unique) are ONE
+        // target of the gather.  h_idx / h_flip: the list as visited (host copy); ustart: nu + 1 run starts (device).
+        std::vector<int> h_idx;
+        std::vector<signed char> h_flip;
+        std::unique_ptr<DevBuf> ustart;
+        int64_t nu = 0;
+        double utol = -1.0;
         double btc[3], B[3];   // tight box of its (sign-adjusted) baselines: centre, half-width [s]
         double Bs[3];          // half-width of the box made symmetric about 0
         int herm = 0;          // this run packs its strengths into two transforms: 1 Hermitian, 2 all real (per run)
@@ -1368,8 +1375,43 @@ class Sim : public SimBase {
                 upload(*pr.idx, ix, sizeof(int) * pr.n, 0);
                 upload(*pr.flip, fl, pr.n, 0);
             }
+            if (!keep_order && order_pairs && pr.n > 1) {
+                pr.h_idx = std::move(six);
+                pr.h_flip = std::move(sfl);
+            }
             pairs.push_back(std::move(pr));
         }
+    }
+
+    // Redundant baselines are one target.  A regular array repeats most of its baseline vectors (HERA-350: 61 075
+    // baselines, 7 957 distinct vectors), the visibility of a (beam pair, baseline vector) does not depend on WHICH
+    // antennas form it, and the list is already visited in (u, v) order: runs of entries whose sign-adjusted vectors
+    // agree to `tol` seconds in every component -- tol = what moves the phase 2 pi nu b . x by at most 1e-3 eps at the
+    // run's highest frequency, i.e. far below the transform's own error; exact duplicates always qualify -- are gathered
+    // once (k_interp walks the run for the output slots).  Compared with the run's FIRST entry, so runs cannot drift.
+    // FFTVIS_HIP_NO_TARGET_DEDUP=1 turns it off.
+    void build_unique(Pair &p, double tol) {
+        const bool off = std::getenv("FFTVIS_HIP_NO_TARGET_DEDUP") != nullptr;  // read per run: tests flip it
+        if (off) tol = -2.0;
+        if (p.utol == tol) return;
+        p.utol = tol;
+        p.ustart.reset();
+        p.nu = p.n;
+        if (off || p.h_idx.empty()) return;
+        std::vector<int> st(1, 0);
+        auto comp = [&](int64_t k, int d) { return (p.h_flip[k] ? -1.0 : 1.0) * h_bls[(size_t)d * nbls + p.h_idx[k]]; };
+        for (int64_t k = 1; k < p.n; ++k) {
+            const int64_t k0 = st.back();
+            bool same = true;
+            for (int d = 0; d < 3 && same; ++d) same = std::fabs(comp(k, d) - comp(k0, d)) <= tol;
+            if (!same) st.push_back((int)k);
+        }
+        st.push_back((int)p.n);
+        const int64_t nu = (int64_t)st.size() - 1;
+        if (nu * 10 > p.n * 9) return;  // (almost) nothing repeats: the plain list
+        p.ustart.reset(new DevBuf());
+        upload(*p.ustart, st.data(), sizeof(int) * st.size(), 0);
+        p.nu = nu;
     }
 
     // Eigenbeam mode (cpu_simulate.py:303-470): beams 0..K-1 are basis beams; every (k <= l) term
@@ -1938,8 +1980,8 @@ class Sim : public SimBase {
                     gs.X = gt.X = X[d];
                     gs.B = p.Bs[d];
                     gt.B = p.B[d];
-                    set_dim_geom(gs, 2.0, k2.w, fmax);
-                    set_dim_geom(gt, 2.0, k2.w, fmax);
+                    set_dim_geom(gs, 2.0, k2.w, fmax, d == D - 1);
+                    set_dim_geom(gt, 2.0, k2.w, fmax, d == D - 1);
                     cs *= gs.n2;
                     ct *= gt.n2;
                 }
@@ -1948,6 +1990,12 @@ class Sim : public SimBase {
             // reference_compat off, eigenbeams: an off-diagonal pair that is not packed gathers its (l, k) term
             // at -b: its targets need the symmetric box too
             for (Pair &p : pairs) p.mirror = nbasis && !reference_compat && p.bi != p.bj && !p.herm && p.n > 0;
+            // redundant baselines -> one gather target each; the tolerance follows the engine's eps and the highest
+            // frequency it knows (not the block's: blocks of a sharded run then agree on the runs)
+            double fall = 0;
+            for (double f : freqs) fall = std::max(fall, std::fabs(f));
+            const double tol = 1e-3 * eps / (2.0 * M_PI * std::max(fall, 1.0));
+            for (Pair &p : pairs) build_unique(p, tol);
         }
         int tg_max = 1;  // transforms per frequency on the grid, largest over the pairs
         for (const Pair &p : pairs)
@@ -1965,7 +2013,7 @@ class Sim : public SimBase {
                 double Bm = 0;
                 for (const Pair &p : pairs) Bm = std::max(Bm, p.box_B()[d]);
                 g.B = Bm;
-                set_dim_geom(g, 2.0, k2.w, fmax);
+                set_dim_geom(g, 2.0, k2.w, fmax, d == D - 1);
                 cells2 *= g.n2;
             }
             const double points = 0.5 * (double)nsrc + (double)nmax;
@@ -1997,7 +2045,7 @@ class Sim : public SimBase {
                 double Bm = 0;
                 for (const Pair &p : pairs) Bm = std::max(Bm, p.box_B()[d]);
                 g.B = Bm;
-                set_dim_geom(g, sigma, k.w, fmax);
+                set_dim_geom(g, sigma, k.w, fmax, d == D - 1);
                 na[d] = g.na;
                 no[d] = g.no;
             }
@@ -2260,10 +2308,11 @@ class Sim : public SimBase {
                                       pr.trivial ? nullptr : pr.idx->template as<int>(),
                                       pr.trivial ? nullptr : pr.flip->template as<signed char>(),
                                       d_freqs.as<double>() + fa, nfg, tg, obase + (int64_t)m * per_tf,
-                                      (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr, pr.herm);
+                                      (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr, pr.herm,
+                                      pr.ustart ? pr.ustart->template as<int>() : nullptr, pr.nu);
                             }
                     ev_end(e5, ls);
-                    st[4] += (double)pr.n * ntrans * nm * (pr.herm ? 2 : 1);  // footprints: packed transforms are read at s and -s
+                    st[4] += (double)(pr.ustart ? pr.nu : pr.n) * ntrans * nm * (pr.herm ? 2 : 1);  // footprints gathered: distinct targets; packed transforms are read at s and -s
                     st[6] = nufft->geo.d[0].n2;
                     st[7] = nufft->geo.d[1].n2;
                     st[8] = nufft->geo.d[0].na * 65536.0 + nufft->geo.d[1].na;

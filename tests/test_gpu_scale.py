@@ -409,6 +409,63 @@ def test_hermitian_packing_matches_four_transforms(gpu, monkeypatch):
     monkeypatch.delenv("FFTVIS_HIP_NO_HERMITIAN", raising=False)
 
 
+def test_redundant_baselines_are_gathered_once(gpu, monkeypatch):
+    """A regular array repeats most of its baseline vectors (HERA-350: 61 075 baselines, < 8 000 distinct vectors).
+    The gather evaluates each distinct (beam pair, sign-adjusted vector) once and writes every member's slot, with
+    the member's own conjugation / feed transposition.  Against the run that gathers every baseline by itself
+    (FFTVIS_HIP_NO_TARGET_DEDUP=1) -- packed and four-transform launches, two beams with baselines given
+    "backwards" in both symmetry modes, a non-coplanar array, source chunks, fp32 -- and against the oracle on a
+    subset that holds members of the largest runs; exact duplicates in the caller's list come back bit-equal."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    cfg = synth.make_config("C3", nsrc=20_000, nfreq=3, ntimes=2)
+    nant = len(cfg["ants"])
+    bl = list(cfg["baselines"])
+    rng = np.random.default_rng(5)
+    back = rng.choice(len(bl), 4000, replace=False)
+    for i in back:  # given "backwards": the engine flips them, conjugates (and, exact mode, transposes) on the way out
+        bl[i] = (bl[i][1], bl[i][0])
+    bl += [bl[7], bl[7], (3, 3), (9, 9)]  # exact duplicates and autos (all autos share the vector 0)
+    cfg["baselines"] = bl
+    freqs = cfg["freqs"]
+    other = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, 12.0), freqs)
+    two = dict(cfg, beam=[cfg["beam"], other], beam_idx=np.arange(nant) % 2)
+    tilted = {k: v + np.array([0.0, 0.0, 0.02 * v[0] + 0.3 * np.sin(0.01 * v[1])]) for k, v in cfg["ants"].items()}
+    cases = {"packed": (cfg, {}), "four transforms": (cfg, {"FFTVIS_HIP_NO_HERMITIAN": "1"}),
+             "two beams": (two, {}), "two beams, exact symmetries": (dict(two, reference_compat=False), {}),
+             "non-coplanar": (dict(cfg, ants=tilted, baselines=bl[::7]), {}),
+             "chunks": (dict(cfg, min_chunks=3), {}), "fp32": (dict(cfg, precision=1, eps=1e-4), {})}
+    for name, (c, env) in cases.items():
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        gpu_simulate.release_handles()
+        monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+        monkeypatch.delenv("FFTVIS_HIP_NO_TARGET_DEDUP", raising=False)
+        once = fftvis_amd.simulate_vis(**c)
+        (h,) = gpu_simulate._IDLE_HANDLES.values()
+        items_once = h.stats()["interp_items"]
+        h.reset_stats()
+        monkeypatch.setenv("FFTVIS_HIP_NO_TARGET_DEDUP", "1")
+        each = fftvis_amd.simulate_vis(**c)
+        items_each = h.stats()["interp_items"]
+        monkeypatch.delenv("FFTVIS_HIP_NO_TARGET_DEDUP")
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        # coplanar fp64 lists: > 3x fewer footprints; the tilted array has few repeats and may keep the plain list, and
+        # fp32 baselines carry their own rounding (6e-8 of the longest), far above the merging tolerance: fewer runs
+        lim = {"non-coplanar": 1.0001, "fp32": 0.9}.get(name, 0.3)
+        assert items_once < lim * items_each, (name, items_once, items_each)
+        tol = 1e-6 if name == "fp32" else 1e-3 * 6e-8  # the members' vectors differ by rounding: far below eps
+        assert rel_l2(once, each) < tol, (name, rel_l2(once, each))
+        if name in ("packed", "two beams"):
+            n = len(c["baselines"])
+            assert np.array_equal(once[..., n - 4], once[..., n - 3]) and np.array_equal(once[..., n - 4], once[..., 7])
+            sub = sorted(set(rng.choice(n - 4, 12, replace=False)) | {int(back[0]), int(back[1]), n - 4, n - 2, n - 1})
+            cs = dict(c, baselines=[c["baselines"][i] for i in sub])
+            assert rel_l2(once[..., sub], oracle_simulate(cs)) < TOL, name
+    gpu_simulate.release_handles()
+
+
 def test_nufft2d_planes_of_4_gib_take_the_transpose_path(gpu):
     """A fine grid whose planes pass 4 GiB per transform (36864 x 32768 cells here; the column pass addresses a
     plane with 32-bit byte offsets): the engine falls back to the tile transpose + row pass for such planes and
