@@ -908,6 +908,10 @@ struct RowDifArgs {
     int jobs_per_xcd;  // row mode: rows per XCD (a multiple of the rows per workgroup), see k_rowfft_st
     const void *in1;  // gang launch (grid.y = 2): input / output of the second, identically shaped problem
     void *out1;
+    // Column plan (row mode, blocked output; see Nufft3::arm_columns): ctab[(plane / ctab_tpol) ctab_stride + position]
+    // = 1 + the COMPACT column an output position is stored at, 0 = no target's footprint reads that column: not stored.
+    const int *ctab;
+    int ctab_stride, ctab_tpol;
 };
 
 template <typename T>
@@ -1777,6 +1781,28 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     int col_pos0[NI3];
 #pragma unroll
     for (int i = 0; i < NI3; ++i) col_pos0[i] = lane_out + mul24(u + i * TPR - ks_lo, ostep);
+    // Column plan: the compact column of each of this thread's outputs, requested now -- one 4-byte load per output from
+    // a table row of a few KiB that every row of the transform reads -- so that the answers are back when pass 3 ends.
+    // A descriptor over the table row masks the outputs beyond this residue's run (index -1: zero = "not stored").
+    bool use_ctab = false;
+    int ct[NI3][R3];
+    if constexpr (!COL && !FUSED) {
+        use_ctab = out_blocked && a.ctab != nullptr;
+        if (use_ctab) {
+            const int *trow = wave_uniform_ptr(a.ctab + (int64_t)__builtin_amdgcn_readfirstlane((int)(rplane / a.ctab_tpol)) * a.ctab_stride);
+            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(trow), 0, (uint32_t)a.ctab_stride * 4u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NI3; ++i) {
+                const int v = u + i * TPR;
+#pragma unroll
+                for (int k = 0; k < R3; ++k) {
+                    const int rel = (v - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
+                    const int pos = res0 + mul24(rel, ostep);
+                    ct[i][k] = __builtin_amdgcn_raw_buffer_load_b32(trs, (unsigned)rel < blk_len ? (uint32_t)pos * 4u : 0xfffffffcu, 0, 0);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NI3; ++i) {
         int v = u + i * TPR;
@@ -1812,6 +1838,11 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                     // ks wraps exactly at k = R3 / 2 (v < Q / R3): index and validity are affine in k with
                     // uniform constants -- two adds, a compare and a select per store
                     const int rel = (v - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
+                    if (use_ctab) {  // uniform: compact columns, only those a target reads
+                        const int t = ct[i][k];
+                        rowout.store(t ? mul24((t - 1) >> a.out_blk, blk_rows) + ((t - 1) & blk_mask) : -1, vc[i][bitrev_small(k, L3)]);
+                        continue;
+                    }
                     const int pos0 = res0 + mul24(v - ks_lo, ostep);
                     const int idx = mul24(pos0 >> a.out_blk, blk_rows) + (pos0 & blk_mask) + k * blk_step - (k >= R3 / 2 ? blk_wrap : 0);
                     rowout.store((unsigned)rel < blk_len ? idx : -1, vc[i][bitrev_small(k, L3)]);
@@ -1914,6 +1945,12 @@ struct InterpArgs {
     //   values: with negate_all they are conj(V_kl(-b)), the exact V_lk(b)^T for complex basis beams), 0 = both
     //   from V_kl(b) (cpu_simulate.py:464-468);  negate_all: every target is taken at -s and conjugated.
     int transpose_flipped, basis_part, negate_all;
+    // Column plan (2-D; Nufft3::arm_columns): the slow dimension of the grid holds only the ncc columns some target
+    // reads; ctab[fg ctab_stride + position] = 1 + compact column (0: left out -- never met by a footprint the plan was
+    // built from; counted in *err if it happens).
+    const int *ctab;
+    int ctab_stride, ncc;
+    int *err;
 };
 
 // HERM (Hermitian strengths): the grid holds two transforms per frequency instead of four --
@@ -1996,7 +2033,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     }
 
     const int64_t row_sz = (int64_t)a.P[0] * a.cnt[0];
-    const int64_t slab_sz = row_sz * a.P[1] * a.cnt[1];
+    const int64_t slab_sz = DIM == 2 && a.ctab ? row_sz * a.ncc : row_sz * a.P[1] * a.cnt[1];
     const int64_t plane_sz = DIM == 3 ? slab_sz * a.P[2] * a.cnt[2] : slab_sz;
     const int nouter = DIM == 3 ? w : 1;
     constexpr int NSIDE = HERM ? 2 : 1;   // the target and (HERM) its mirror image
@@ -2026,7 +2063,13 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
             int q1 = j0[1] / P1, r1 = j0[1] - q1 * P1;
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
-                roff[rr] = (r1 * c1 + q1) * (int)row_sz;
+                int posr = r1 * c1 + q1;
+                if (DIM == 2 && a.ctab) {  // uniform
+                    const int t = a.ctab[(int64_t)fg * a.ctab_stride + posr];
+                    if (t == 0 && rr < w && g == 0 && a.err) atomicAdd(a.err, 1);
+                    posr = max(t - 1, 0);
+                }
+                roff[rr] = posr * (int)row_sz;
                 const int inc = rr + 1 < w ? 1 : 0;
                 r1 += inc;
                 const int wrap = r1 == P1 ? 1 : 0;
@@ -2213,6 +2256,23 @@ class Nufft3 {
     } fused_key;
     FusedArgs fused_args{};
     bool fused_active = false, last_fft_fused = false;
+    // Column plan (2-D, blocked B, stand-alone gather): the targets of a regular array read only a fraction of the
+    // transform's columns in the first dimension (HERA-350: a third -- its baselines sit on a lattice); the x-pass
+    // then stores ONLY those, compacted, the y-pass transforms only those, and the gather finds them through the
+    // table.  col_tab[fg * x.nos() + position] = 1 + compact column | 0 (device; built by the caller from its targets,
+    // per frequency of the group: tpol transforms share an entry), col_ncc = compact columns (largest over the
+    // frequencies).  Armed by the caller before fft(); nullptr = every column.
+    const int *col_tab = nullptr;
+    int col_tab_tpol = 1, col_ncc = 0;
+    int *col_err = nullptr;
+    void arm_columns(const int *tab, int tpol, int ncc, int *err = nullptr) {
+        col_tab = tab && dim == 2 && b_block_log() ? tab : nullptr;
+        col_tab_tpol = tpol;
+        col_ncc = ncc;
+        col_err = err;
+    }
+    int xcols() const { return col_tab ? col_ncc : geo.d[0].nos(); }  // columns of B / rows of C per transform
+    bool columns_possible() const { return dim == 2 && b_block_log() != 0 && y_reads_columns() && !fused_possible(); }
     bool fused_possible() const;
     // Arms the fused gather for the next fft() (which then leaves no grid for interp()); false when the
     // configuration does not qualify and the caller must use interp().
@@ -2609,7 +2669,7 @@ int64_t Nufft3<T>::b_pitch() const {
     (void)y;
     // whole 128-B lines per workgroup (8 columns) or per pair of neighbouring workgroups (4 columns each;
     // giving such pairs consecutive slots on one XCD was measured to change nothing: 1.836 vs 1.833 ms)
-    return y_reads_columns() ? (x.nos() + 7) / 8 * 8 : x.nos();
+    return y_reads_columns() ? (xcols() + 7) / 8 * 8 : xcols();
 }
 
 // Column mode needs a kernel that holds >= 2 columns per workgroup and planes below 4 GiB per transform (its
@@ -2699,6 +2759,11 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.cnt = g.sP() > 1 ? g.cnt() : 0;
     a.in_blk = in_blk;
     a.out_blk = out_blk;
+    if (out_blk && col_tab) {  // the x-pass of a column plan
+        a.ctab = col_tab;
+        a.ctab_stride = g.nos();
+        a.ctab_tpol = col_tab_tpol;
+    }
     FV_REQUIRE((!in_blk && !out_blk) || rowfft_uses_st(g, a.colmode != 0), "blocked planes: register-resident passes only");
     // column-mode and blocked accesses are 32-bit byte offsets from a plane's base (buffer descriptors)
     if (rowfft_uses_st(g, a.colmode != 0) && (a.colmode || in_blk || out_blk))
@@ -2822,9 +2887,10 @@ double Nufft3<T>::fft_traffic_cells() const {
     const double zin = dim > 2 ? z.na : 1;
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
-    double c = zin * ((double)x.na * y.na + (double)x.no * y.na);        // x-pass
+    const double xo = col_tab ? (double)col_ncc : (double)x.no;          // columns stored by the x-pass (column plan: those a target reads)
+    double c = zin * ((double)x.na * y.na + xo * y.na);                  // x-pass
     if (!y_reads_columns()) c += zin * 2.0 * x.no * y.na;                 // transpose
-    c += zin * ((double)x.no * y.na + (last_fft_fused ? 0.0 : (double)x.no * y.no));  // y-pass (no C when fused)
+    c += zin * (xo * y.na + (last_fft_fused ? 0.0 : xo * y.no));         // y-pass (no C when fused)
     if (dim > 2) c += (double)x.no * y.no * (z.na + z.no);               // z-pass
     return c;
 }
@@ -2848,6 +2914,7 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
     // x-pass: A [p][na_y][na_x] -> B [p][na_y][xp]   (xp = no_x, padded to 8 for column mode)
     const int64_t xp = b_pitch();
     const int blk = b_block_log();
+    FV_REQUIRE(!col_tab || (blk && y_reads_columns() && !fused_active), "column plan: blocked B, column-mode y-pass, stand-alone gather");
     rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp, 0, nullptr, cur1, oth1, 0, blk);
     std::swap(cur, oth);
     std::swap(cur1, oth1);
@@ -2855,7 +2922,7 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
         // the y-pass reads rpw adjacent columns of B at once (32-128 B segments; neighbouring workgroups share lines),
         // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
         // plane are skipped as rows
-        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, x.nos(),
+        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, xcols(),
                fused_active ? &fused_args : nullptr, cur1, oth1, blk, 0);
         std::swap(cur, oth);
         std::swap(cur1, oth1);
@@ -3016,12 +3083,19 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
         bt[i] = bts[map[i]];
     }
     // the gather addresses a footprint's rows with 32-bit element offsets inside one (x, y) slab of a transform
-    FV_REQUIRE((int64_t)a.P[0] * a.cnt[0] * a.P[1] * a.cnt[1] < ((int64_t)1 << 31),
+    FV_REQUIRE((int64_t)a.P[0] * a.cnt[0] * (col_tab ? (int64_t)col_ncc : (int64_t)a.P[1] * a.cnt[1]) < ((int64_t)1 << 31),
                "transform output slab of 2^31 elements or more: beyond the gather's 32-bit row offsets");
     a.out_fg_stride = out_fg_stride;
     a.out_k_stride = out_k_stride;
     for (int r = 0; r < 16; ++r) a.out_pol_off[r] = out_pol_off ? out_pol_off[r] : 0;
     a.accumulate = accumulate ? 1 : 0;
+    if (col_tab) {
+        FV_REQUIRE(dim == 2, "column plan: 2-D transforms");
+        a.ctab = col_tab;
+        a.ctab_stride = geo.d[0].nos();
+        a.ncc = col_ncc;
+        a.err = col_err;
+    }
     a.herm = herm;
     a.transpose_flipped = transpose_flipped ? 1 : 0;
     const int64_t items = N * nfg;

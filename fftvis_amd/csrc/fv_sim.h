@@ -999,8 +999,9 @@ class Sim : public SimBase {
         std::unique_ptr<DevBuf> idx, flip;
         // Redundant baselines: runs of the (u, v)-ordered list whose sign-adjusted vectors agree (build_unique) are ONE
         // target of the gather.  h_idx / h_flip: the list as visited (host copy); ustart: nu + 1 run starts (device).
-        std::vector<int> h_idx;
+        std::vector<int> h_idx, h_ustart;
         std::vector<signed char> h_flip;
+        bool sorted = false;  // the list is visited in (u, v) order
         std::unique_ptr<DevBuf> ustart;
         int64_t nu = 0;
         double utol = -1.0;
@@ -1058,7 +1059,7 @@ class Sim : public SimBase {
     // sticky device-side error counters, read at every host synchronisation point (check_errors):
     // [0] sources outside the planned box or with NaN coordinates (k_bin_count), [1] type-1 entries
     // dropped because the entry buffers overflowed (k_t1_bin), [2] above-horizon sources that did not
-    // fit source_buffer x chunk size (k_horizon_compact)
+    // fit source_buffer x chunk size (k_horizon_compact), [3] footprint columns missing from a column plan (k_interp)
     DevBuf d_err;
     std::vector<std::pair<int, double>> mhist_log;  // (time index, transforms spread) per processed time
 
@@ -1375,10 +1376,9 @@ class Sim : public SimBase {
                 upload(*pr.idx, ix, sizeof(int) * pr.n, 0);
                 upload(*pr.flip, fl, pr.n, 0);
             }
-            if (!keep_order && order_pairs && pr.n > 1) {
-                pr.h_idx = std::move(six);
-                pr.h_flip = std::move(sfl);
-            }
+            pr.sorted = !keep_order && order_pairs && pr.n > 1;
+            pr.h_idx = std::move(six);
+            pr.h_flip = std::move(sfl);
             pairs.push_back(std::move(pr));
         }
     }
@@ -1396,8 +1396,10 @@ class Sim : public SimBase {
         if (p.utol == tol) return;
         p.utol = tol;
         p.ustart.reset();
+        p.h_ustart.clear();
         p.nu = p.n;
-        if (off || p.h_idx.empty()) return;
+        ++targets_serial;  // column plans were built from the old runs
+        if (off || !p.sorted) return;
         std::vector<int> st(1, 0);
         auto comp = [&](int64_t k, int d) { return (p.h_flip[k] ? -1.0 : 1.0) * h_bls[(size_t)d * nbls + p.h_idx[k]]; };
         for (int64_t k = 1; k < p.n; ++k) {
@@ -1412,6 +1414,71 @@ class Sim : public SimBase {
         p.ustart.reset(new DevBuf());
         upload(*p.ustart, st.data(), sizeof(int) * st.size(), 0);
         p.nu = nu;
+        p.h_ustart = std::move(st);
+    }
+
+    // Column plan (Nufft3::arm_columns): which columns of the transform's first dimension the targets of one (frequency
+    // group, beam pair) read at all, per frequency -- the footprints of the distinct target vectors (and of their
+    // mirror images where the run gathers at -s too), exactly as k_interp places them; a footprint whose first column
+    // is within 1e-6 of a rounding boundary takes both candidates.  Compact numbers follow the residue-major
+    // position order, so that a residue job of the x-pass stores runs of neighbouring compact columns.  Host
+    // arithmetic, once per (targets, group geometry); kept for later runs.  Not used when it would keep more than
+    // 85 % of the columns (arrays without repeated baseline vectors).  FFTVIS_HIP_NO_COLUMN_PLAN=1 turns it off.
+    struct ColPlan {
+        int64_t serial;
+        int pair, fa, fb, nos, sP, cnt, n2, no, w;
+        double h, btc;
+        bool both;
+        DevBuf tab;
+        int ncc = 0;
+        bool use = false;
+    };
+    std::vector<std::unique_ptr<ColPlan>> col_plans;
+    std::vector<ColPlan *> col_plan_of;  // [group * pairs + pair] of the current run
+    ColPlan *column_plan(int pi, const Pair &pr, int fa, int fb, const DimGeom &x, int w) {
+        const bool both = pr.herm || pr.mirror;
+        for (auto &c : col_plans)
+            if (c->serial == targets_serial && c->pair == pi && c->fa == fa && c->fb == fb && c->nos == x.nos() &&
+                c->sP == x.sP() && c->cnt == x.cnt() && c->n2 == x.n2 && c->no == x.no && c->w == w && c->h == x.h &&
+                c->btc == x.btc && c->both == both)
+                return c.get();
+        if (col_plans.size() > 512) col_plans.clear();  // stale versions of earlier target sets
+        std::unique_ptr<ColPlan> c(new ColPlan{targets_serial, pi, fa, fb, x.nos(), x.sP(), x.cnt(), x.n2, x.no, w, x.h, x.btc, both});
+        const int nfg = fb - fa, stride = x.nos(), P = x.sP(), cnt = x.cnt();
+        std::vector<int> tab((size_t)nfg * stride, 0);
+        const int64_t nu = pr.h_ustart.empty() ? pr.n : (int64_t)pr.h_ustart.size() - 1;
+        c->use = true;
+        for (int fg = 0; fg < nfg && c->use; ++fg) {
+            int *row = tab.data() + (size_t)fg * stride;
+            const double sc = freqs[fa + fg];
+            for (int64_t ui = 0; ui < nu; ++ui) {
+                const int64_t kl = pr.h_ustart.empty() ? ui : pr.h_ustart[ui];
+                const int64_t k = pr.h_idx[kl];
+                const double sg = pr.h_flip[kl] ? -1.0 : 1.0;
+                const double sv = sc * sg * (double)(T)h_bls[k];  // as k_interp forms it from the device copy
+                const double th = x.h * (sv - sc * x.btc);
+                for (int side = 0; side < (both ? 2 : 1); ++side) {
+                    const double e = (side ? -1.0 : 1.0) * th * x.n2 * (0.5 / M_PI) + 0.5 * x.no;
+                    const double t = e - 0.5 * w, jc = std::ceil(t);
+                    const bool amb = jc - t < 1e-6 || jc - t > 1.0 - 1e-6;
+                    int lo = std::max(0, std::min(x.no - w, (int)jc)), hi = lo + w - 1;
+                    if (amb) {
+                        lo = std::max(0, lo - 1);
+                        hi = std::min(x.no - 1, hi + 1);
+                    }
+                    for (int i = lo; i <= hi; ++i) row[out_pos(i, P, cnt)] = 1;
+                }
+            }
+            int run = 0;
+            for (int i = 0; i < stride; ++i)
+                if (row[i]) row[i] = ++run;
+            c->ncc = std::max(c->ncc, run);
+            if (run * 100 > x.no * 85) c->use = false;  // nothing to gain (decided on the first frequency already)
+        }
+        c->ncc = (c->ncc + 7) / 8 * 8;
+        if (c->use) upload(c->tab, tab.data(), sizeof(int) * tab.size(), 0);
+        col_plans.push_back(std::move(c));
+        return col_plans.back().get();
     }
 
     // Eigenbeam mode (cpu_simulate.py:303-470): beams 0..K-1 are basis beams; every (k <= l) term
@@ -2126,6 +2193,24 @@ class Sim : public SimBase {
                 lanes[li].nufft->reserve_buffers(need, na_max, n2_max);
                 lanes[li].nufft->strengths_buffer_reserve(cap, (int)need_str);
             }
+            // column plans of every (group, pair), from the geometry the run will set (large 2-D grids only)
+            col_plan_of.assign(groups.size() * pairs.size(), nullptr);
+            if (D == 2 && !std::getenv("FFTVIS_HIP_NO_COLUMN_PLAN")) {
+                Nufft3<T> *n0 = lanes[0].nufft.get();
+                for (size_t gi = 0; gi < groups.size(); ++gi) {
+                    double smax = 0;
+                    for (int f = groups[gi].first; f < groups[gi].second; ++f) smax = std::max(smax, std::fabs(freqs[f]));
+                    for (size_t pi = 0; pi < pairs.size(); ++pi) {
+                        const Pair &pr = pairs[pi];
+                        if (pr.n == 0) continue;
+                        n0->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
+                        if (!n0->columns_possible() || n0->geo.cells_o() < 4000000) continue;
+                        col_plan_of[gi * pairs.size() + pi] =
+                            column_plan((int)pi, pr, groups[gi].first, groups[gi].second, n0->geo.d[0], n0->ker.w);
+                    }
+                }
+                FV_HIP(hipStreamSynchronize(n0->stream));  // the table kernels of these set_geometry calls are done before the run's own
+            }
         }
         if (nlanes > 1 && !pipe) {  // lane 1 starts after the output memset queued on the main stream
             FV_HIP(hipEventRecord(ev_start, stream));
@@ -2254,6 +2339,12 @@ class Sim : public SimBase {
                             launch_strengths(L, pr, fa, nfg, M, Mps[m], ls);
                     }
                     // ---- NUFFT ----------------------------------------------------------
+                    {
+                        ColPlan *cp = col_plan_of[(size_t)(&grp - groups.data()) * pairs.size() + (size_t)(&pr - pairs.data())];
+                        const bool on = cp && cp->use;
+                        for (int m = 0; m < nm; ++m)
+                            Ls[m]->nufft->arm_columns(on ? cp->tab.template as<int>() : nullptr, tg, on ? cp->ncc : 0, d_err.as<int>() + 3);
+                    }
                     {
                     RoctxRange rr("spread");
                     if (timing_level >= 2 || (timing_level == 1 && sampled)) {  // 2 and 3: every launch
@@ -2416,8 +2507,11 @@ class Sim : public SimBase {
         int e[4] = {0, 0, 0, 0};
         FV_HIP(hipMemcpyAsync(e, d_err.p, sizeof(e), hipMemcpyDeviceToHost, stream));
         FV_HIP(hipStreamSynchronize(stream));
-        if (!e[0] && !e[1] && !e[2]) return;
+        if (!e[0] && !e[1] && !e[2] && !e[3]) return;
         FV_HIP(hipMemsetAsync(d_err.p, 0, sizeof(e), stream));
+        if (e[3])
+            throw Error(FV_ERR_INTERNAL, "the gather met " + std::to_string(e[3]) + " transform columns its column plan had left "
+                                         "out: the visibilities of this run are invalid (FFTVIS_HIP_NO_COLUMN_PLAN=1 avoids the plan)");
         if (e[2])
             throw Error(FV_ERR_ARG, "more sources above the horizon than source_buffer allows (" +
                                         std::to_string(e[2]) + " did not fit): increase source_buffer");

@@ -466,6 +466,62 @@ def test_redundant_baselines_are_gathered_once(gpu, monkeypatch):
     gpu_simulate.release_handles()
 
 
+def test_column_plan_stores_only_the_columns_targets_read(gpu, monkeypatch):
+    """The baselines of a regular array sit on a lattice, so their gather footprints meet only a fraction of the
+    transform's columns in the first dimension (HERA-350: about a third).  The engine plans those columns per
+    (frequency group, beam pair) on the host, the x-pass stores only them (compacted), the y-pass transforms only
+    them and the gather finds them through the plan's table.  Same arithmetic on fewer columns: against the run
+    without a plan (FFTVIS_HIP_NO_COLUMN_PLAN=1) the block must agree to rounding -- packed and four-transform
+    launches, two beams with flipped baselines (exact symmetries: transposed slots), eigenbeams with the mirror
+    gather, source chunks, gang launches over 3 time steps, fp32 -- with fewer FFT cells moved; a random layout
+    (no repeated vectors) keeps every column and runs unplanned."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    cfg = synth.make_config("C3", nsrc=20_000, nfreq=3, ntimes=3)
+    nant = len(cfg["ants"])
+    bl = list(cfg["baselines"])
+    rng = np.random.default_rng(6)
+    for i in rng.choice(len(bl), 3000, replace=False):
+        bl[i] = (bl[i][1], bl[i][0])
+    cfg["baselines"] = bl
+    freqs = cfg["freqs"]
+    other = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, 12.0), freqs)
+    two = dict(cfg, beam=[cfg["beam"], other], beam_idx=np.arange(nant) % 2, reference_compat=False)
+    c5 = synth.make_config("C5", nsrc=20_000, nfreq=2, ntimes=1)
+    c5x = dict(c5, beam=[fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(c5["freqs"], 14.0 * (1 + 0.05 * i), nza=91, naz=180), c5["freqs"])
+                         for i in range(synth.C5_NBASIS)], reference_compat=False)  # complex basis beams: mirror gather
+    scattered = {k: np.append(rng.uniform(-430, 430, 2), 0.0) for k in cfg["ants"]}  # no lattice: every column is read
+    cases = {"packed": (cfg, {}, True), "four transforms": (cfg, {"FFTVIS_HIP_NO_HERMITIAN": "1"}, True),
+             "two beams, exact symmetries": (two, {}, True), "eigenbeams": (c5, {}, True),
+             "eigenbeams, mirror gather": (c5x, {}, True),
+             "chunks": (dict(cfg, min_chunks=3), {}, True), "fp32": (dict(cfg, precision=1, eps=1e-4), {}, True),
+             "scattered antennas": (dict(cfg, ants=scattered), {}, False)}
+    for name, (c, env, planned) in cases.items():
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        gpu_simulate.release_handles()
+        monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+        monkeypatch.delenv("FFTVIS_HIP_NO_COLUMN_PLAN", raising=False)
+        some = fftvis_amd.simulate_vis(**c)
+        (h,) = gpu_simulate._IDLE_HANDLES.values()
+        cells_some = h.stats()["fft_cells"]
+        h.reset_stats()
+        monkeypatch.setenv("FFTVIS_HIP_NO_COLUMN_PLAN", "1")
+        every = fftvis_amd.simulate_vis(**c)
+        cells_every = h.stats()["fft_cells"]
+        monkeypatch.delenv("FFTVIS_HIP_NO_COLUMN_PLAN")
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert np.isfinite(some).all()
+        if planned:
+            assert cells_some < 0.8 * cells_every, (name, cells_some, cells_every)
+        else:
+            assert cells_some == cells_every, (name, cells_some, cells_every)
+        d = rel_l2(some, every)
+        assert d < (1e-6 if c.get("precision") == 1 else 1e-13), (name, d)
+    gpu_simulate.release_handles()
+
+
 def test_nufft2d_planes_of_4_gib_take_the_transpose_path(gpu):
     """A fine grid whose planes pass 4 GiB per transform (36864 x 32768 cells here; the column pass addresses a
     plane with 32-bit byte offsets): the engine falls back to the tile transpose + row pass for such planes and
