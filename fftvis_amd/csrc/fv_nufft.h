@@ -153,7 +153,8 @@ inline double geom_slack_share() {
 }
 
 // last_dim: the dimension the gather reads contiguously (transformed by the last pass).
-inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max, bool last_dim = true) {
+inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max, bool last_dim = true, double slack_share = -1.0) {
+    if (slack_share < 0.0) slack_share = geom_slack_share();
     g.S = std::fabs(scale_max) * g.B;
     double Xs = g.X, Ss = g.S;
     if (Xs == 0) {
@@ -176,12 +177,14 @@ inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max, bool
     // outer step more oversampled than asked, never less accurate -- grown until sigma n1(so) reaches n2.  The
     // sources then touch more cells (n1 up), but the targets span fewer transform outputs, |eta| <= n2 / (2 so),
     // so every LATER pass has fewer lines to transform and the gather's grid shrinks (C3, x: na 4688 -> 5120, no
-    // 5132 -> 4700 at n2 = 10240).  Not in the last dimension, which has no later pass to gain from it.
+    // 5132 -> 4700 at n2 = 10240).  Not in the last dimension, which has no later pass to gain from it, and not under a
+    // column plan (Nufft3::arm_columns), which keeps only the columns the targets read however finely they are sampled:
+    // the caller then passes slack_share = 0 (Nufft3::grid_slack).
     double so = sigma;
-    if (!last_dim && geom_slack_share() > 0.0) {
+    if (!last_dim && slack_share > 0.0) {
         const double so_max = ((double)g.n2 / sigma - w - 3.0) * M_PI / (2.0 * Ss * Xs);
         if (so_max > sigma) {
-            const double so_try = sigma + geom_slack_share() * (so_max - sigma);
+            const double so_try = sigma + slack_share * (so_max - sigma);
             int n1s = (int)std::ceil(2.0 * so_try * Ss * Xs / M_PI + w + 1);
             n1s += n1s % 2;
             const int nas = (int)cdiv(n1s, 1 << BINLOG) << BINLOG;
@@ -2264,6 +2267,7 @@ class Nufft3 {
     // frequencies).  Armed by the caller before fft(); nullptr = every column.
     const int *col_tab = nullptr;
     int col_tab_tpol = 1, col_ncc = 0;
+    double grid_slack = -1.0;  // set_dim_geom's slack_share for the next set_geometry / plan_buffer_cells (-1: the default)
     int *col_err = nullptr;
     void arm_columns(const int *tab, int tpol, int ncc, int *err = nullptr) {
         col_tab = tab && dim == 2 && b_block_log() ? tab : nullptr;
@@ -2368,7 +2372,7 @@ class Nufft3 {
         for (int d = 0; d < dim; ++d) {
             g[d].X = X[d];
             g[d].B = B[d];
-            set_dim_geom(g[d], sigma, ker.w, scale_max, d == dim - 1);
+            set_dim_geom(g[d], sigma, ker.w, scale_max, d == dim - 1, grid_slack);
             if (d > 0) cap_column_q(g[d]);
             g[d].rm = d != dim - 1 && !debug_switch_natural_order();
             if (na_max) na_max[d] = std::max(na_max[d], g[d].na);
@@ -2404,7 +2408,7 @@ class Nufft3 {
             geo.d[d].X = X[d];
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
-            set_dim_geom(geo.d[d], sigma, ker.w, scale_max, d == dim - 1);
+            set_dim_geom(geo.d[d], sigma, ker.w, scale_max, d == dim - 1, grid_slack);
             if (d > 0) cap_column_q(geo.d[d]);
             // (residue-major storage of the last dimension as well: C3's FFT passes -2.5 %, its gather +41 %)
             geo.d[d].rm = d != dim - 1 && !debug_switch_natural_order();

@@ -2185,7 +2185,10 @@ class Sim : public SimBase {
                 for (const Pair &pr : pairs) {
                     if (pr.n == 0) continue;
                     const int ntrans = (grp.second - grp.first) * (pr.herm ? 2 : tpol);
-                    need = std::max(need, lanes[0].nufft->plan_buffer_cells(X, pr.box_B(), smax, na_max, n2_max) * ntrans);
+                    for (double sl : {0.0, -1.0}) {  // with and without a column plan (its geometry takes no grid slack)
+                        lanes[0].nufft->grid_slack = sl;
+                        need = std::max(need, lanes[0].nufft->plan_buffer_cells(X, pr.box_B(), smax, na_max, n2_max) * ntrans);
+                    }
                     need_str = std::max<int64_t>(need_str, ntrans);
                 }
             }
@@ -2203,6 +2206,7 @@ class Sim : public SimBase {
                     for (size_t pi = 0; pi < pairs.size(); ++pi) {
                         const Pair &pr = pairs[pi];
                         if (pr.n == 0) continue;
+                        n0->grid_slack = 0.0;  // a plan's geometry: no grid slack (set_dim_geom)
                         n0->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
                         if (!n0->columns_possible() || n0->geo.cells_o() < 4000000) continue;
                         col_plan_of[gi * pairs.size() + pi] =
@@ -2288,6 +2292,10 @@ class Sim : public SimBase {
                         double smax0 = 0;
                         for (int f = groups[0].first; f < groups[0].second; ++f)
                             smax0 = std::max(smax0, std::fabs(freqs[f]));
+                        {
+                            const ColPlan *cpq = col_plan_of[(size_t)(&pr - pairs.data())];  // group 0
+                            nufft->grid_slack = cpq && cpq->use ? 0.0 : -1.0;
+                        }
                         nufft->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax0);
                         nufft->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
                                            D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mps[m]);
@@ -2326,6 +2334,10 @@ class Sim : public SimBase {
                         // ---- geometry + bin sort (skipped when unchanged since last set) -------
                         RoctxRange rr("prep");
                         size_t e1 = ev_begin(TM_PREP, ls);
+                        {
+                            const ColPlan *cpq = col_plan_of[(size_t)(&grp - groups.data()) * pairs.size() + (size_t)(&pr - pairs.data())];
+                            nf_->grid_slack = cpq && cpq->use ? 0.0 : -1.0;
+                        }
                         nf_->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
                         if (L.binned_ti != (tu + m) * nch + chunk || L.binned_serial != nf_->geom_serial || nf_->M != M) {
                             nf_->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
