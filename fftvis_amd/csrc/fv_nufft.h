@@ -38,6 +38,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <array>
 #include <map>
 #include <memory>
 
@@ -148,8 +149,8 @@ inline void cap_column_q(DimGeom &g) {
 
 // How much of the rounding slack of n2 goes into a finer source grid (0 = none, 1 = all of it): see set_dim_geom.
 inline double geom_slack_share() {
-    static const double v = std::getenv("FFTVIS_HIP_GRID_SLACK") ? std::atof(std::getenv("FFTVIS_HIP_GRID_SLACK")) : 1.0;
-    return std::min(1.0, std::max(0.0, v));
+    const char *e = std::getenv("FFTVIS_HIP_GRID_SLACK");  // read per geometry: tests flip it
+    return e ? std::min(1.0, std::max(0.0, std::atof(e))) : 1.0;
 }
 
 // last_dim: the dimension the gather reads contiguously (transformed by the last pass).
@@ -210,6 +211,7 @@ struct BinArgs {
     double xc[3], invh[3];
     int na[3], nbin[3];
     int w, dim;
+    double r2max;  // > 0 (2-D): the sources lie in the disc x^2 + y^2 <= r2max (Nufft3::disc_radius); outside = out of box
 };
 
 // Footprint start cell i0 = ceil(p - w/2) in buffer-A coordinates and first kernel argument
@@ -238,6 +240,16 @@ __global__ void k_bin_count(int64_t M, const int *__restrict__ Mp, const T *__re
         i0u[(int64_t)d * M + j] = i0;
         fu[(int64_t)d * M + j] = (T)((double)i0 - p);
         tl[d] = i0 >> BINLOG;
+    }
+    if (a.r2max > 0.0) {  // blocks outside the disc are neither written by the spread nor read by the x-pass
+        const double sx = (double)src[0][j], sy = (double)src[1][j];
+        if (!(sx * sx + sy * sy <= a.r2max)) {
+            oob = true;
+            tl[0] = a.nbin[0] / 2;  // counted as an error; parked in a block that exists
+            tl[1] = a.nbin[1] / 2;
+            i0u[j] = tl[0] << BINLOG;
+            i0u[M + j] = tl[1] << BINLOG;
+        }
     }
     if (oob) atomicAdd(n_oob, 1);
     int t = (tl[2] * a.nbin[1] + tl[1]) * a.nbin[0] + tl[0];
@@ -915,6 +927,9 @@ struct RowDifArgs {
     // = 1 + the COMPACT column an output position is stored at, 0 = no target's footprint reads that column: not stored.
     const int *ctab;
     int ctab_stride, ctab_tpol;
+    // Row extents (row mode, first pass of a 2-D transform whose sources lie in a disc; Nufft3::disc_radius): the input
+    // row k of a plane is non-zero -- and was written by the spread -- only in [row_ext[2 (k >> 3)], row_ext[2 (k >> 3) + 1]).
+    const int *row_ext;
 };
 
 template <typename T>
@@ -1413,7 +1428,18 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                             : INBLK ? plane0
                             : COL   ? plane0 + (row0 % a.rpp) * a.in_row
                                     : (ok_line ? rplane * a.in_plane + rk * a.in_row : 0);
-    const RowBuf<T> rowin(in + in_base, ONEBLK ? ((int64_t)a.n_in << BLK1) : COL ? -1 : (ok_line ? a.n_in : 0));
+    // Row extents (row mode; RowDifArgs::row_ext): the row is non-zero, and was written, only in [xe0, xe1) -- the
+    // descriptor covers exactly that piece (requests outside it return zero without touching memory) and the fold
+    // below only makes the sweeps that can meet it.
+    int xe0 = 0, xe1 = a.n_in;
+    if constexpr (!COL) {
+        if (a.row_ext) {
+            const int eb = __builtin_amdgcn_readfirstlane((int)(rk >> 3)) * 2;
+            xe0 = a.row_ext[eb];
+            xe1 = a.row_ext[eb + 1];
+        }
+    }
+    const RowBuf<T> rowin(in + in_base + (COL ? 0 : xe0), ONEBLK ? ((int64_t)a.n_in << BLK1) : COL ? -1 : (ok_line ? xe1 - xe0 : 0));
     const int lane_in = ONEBLK ? line
                         : INBLK ? (int)((rplane - row0 / a.rpp) * a.in_plane) + ((((int)rk >> blk) * a.n_in) << blk) +
                                       ((int)rk & ((1 << blk) - 1))
@@ -1429,7 +1455,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
         else if constexpr (COL)
             return (unsigned)ia < nin_lane ? lane_in + mul24(ia, in_elem) : -1;
         else
-            return ia;  // zero outside [0, n_in)
+            return ia - xe0;  // zero outside [xe0, xe1)
     };
     auto load_in = [&](int ia) -> cplx<T> { return rowin.load(in_index(ia)); };
     // Residue twiddle of slot q = u + k S1:  w^{q p} = w^{u p} (this thread's, one vector load) x w^{k S1 p} (uniform:
@@ -1437,9 +1463,9 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     // with their butterfly and rides on the pass-1 twiddle below (loaded there: no registers held across the loads and the butterfly).
     if constexpr (FOLD && PAIR) {
         static_assert(R1 == 16, "paired residues: 16 pass-1 slots per thread");
-        const int nlo = a.n_in - hshift;                      // elements with s >= 0
-        const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
-        const int mmax = (nlo - 1) / Q;
+        const int lo_s = xe0 - hshift, nlo = xe1 - hshift;    // the row's elements sit at s in [lo_s, nlo)
+        const int mmin = lo_s >> LOGQ;                        // floor(lo_s / Q)
+        const int mmax = (nlo - 1) >> LOGQ;
         constexpr int CH = 4, HALF = R1 / 2;
         const int P = a.P;
         auto mod_p = [&](int v) {  // v mod P for v >= 0 (v < 4 P here)
@@ -1455,8 +1481,8 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
             const int h = HALF * g + hh;  // first slot of the chunk (wave-uniform)
 #pragma unroll
             for (int j = 0; j < CH; ++j) mine[hh + j] = theirs[hh + j] = {T(0), T(0)};
-            const int m_lo = mmax - mmin < 2 ? mmin : max(mmin, (-hshift - ((h + CH) * S1 - 1)) / Q);
-            const int m_hi = mmax - mmin < 2 ? mmax : min(mmax, (nlo - 1 - h * S1) / Q);
+            const int m_lo = mmax - mmin < 2 ? mmin : max(mmin, -((((h + CH) * S1 - 1) - lo_s) >> LOGQ));  // ceil((lo_s - last slot) / Q)
+            const int m_hi = mmax - mmin < 2 ? mmax : min(mmax, (nlo - 1 - h * S1) >> LOGQ);
             int mpm = mod_p(mpm_min + (m_lo - mmin) * mod_p(p)), mpo = mod_p(mpo_min + (m_lo - mmin) * mod_p(p_other));
             for (int m = m_lo; m <= m_hi; m += 2) {
                 cplx<T> x[2][CH];
@@ -1518,9 +1544,9 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
             }
         }
     } else if constexpr (FOLD) {
-        const int nlo = a.n_in - hshift;                      // elements with s >= 0
-        const int mmin = -((hshift + Q - 1) / Q);             // floor(-hshift / Q)
-        const int mmax = (nlo - 1) / Q;
+        const int lo_s = (COL ? 0 : xe0) - hshift, nlo = (COL ? a.n_in : xe1) - hshift;  // the row's elements sit at s in [lo_s, nlo)
+        const int mmin = lo_s >> LOGQ;                        // floor(lo_s / Q)
+        const int mmax = (nlo - 1) >> LOGQ;
         constexpr int CH = 4;  // slots per chunk: 4 accumulators + 2 sweeps x 4 operands in flight beside va
         int mp_min = (mmin * p) % a.P;  // (mmin p) mod P, mmin <= 0
         if (mp_min < 0) mp_min += a.P;
@@ -1533,8 +1559,8 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
             // threads): the outermost sweeps only reach the first / last chunk -- uniform bounds, so the others
             // neither load nor accumulate them (n_in = 4688, Q = 2048: 3, 2, 2, 3 sweeps instead of 4 each)
             // (rows of two sweeps have nothing to skip, and their loop runs 4 % faster on the plain bounds)
-            const int m_lo = mmax - mmin < 2 ? mmin : max(mmin, (-hshift - ((h + CH) * S1 - 1)) / Q);  // ceil of a negative quotient
-            const int m_hi = mmax - mmin < 2 ? mmax : min(mmax, (nlo - 1 - h * S1) / Q);               // numerator >= 0 there
+            const int m_lo = mmax - mmin < 2 ? mmin : max(mmin, -((((h + CH) * S1 - 1) - lo_s) >> LOGQ));  // ceil((lo_s - last slot) / Q)
+            const int m_hi = mmax - mmin < 2 ? mmax : min(mmax, (nlo - 1 - h * S1) >> LOGQ);
             // two sweeps per round trip: 8 loads in flight (a sweep beyond m_hi asks for index -1: zero, no access).
             // (Two more sweeps per trip by LDS-DMA into the idle exchange buffer -- no registers -- were measured to
             // change nothing: the job is bound by the throughput of the L2 / load path that serves the P re-reads of
@@ -2233,6 +2259,8 @@ struct BasisTerm {
     int part = 0, negate = 0;  // InterpArgs::basis_part / negate_all
 };
 
+inline bool rowfft_uses_st(const DimGeom &g, bool col);
+
 template <typename T>
 class Nufft3 {
    public:
@@ -2267,6 +2295,7 @@ class Nufft3 {
     // frequencies).  Armed by the caller before fft(); nullptr = every column.
     const int *col_tab = nullptr;
     int col_tab_tpol = 1, col_ncc = 0;
+    const int *first_pass_ext = nullptr;  // RowDifArgs::row_ext of the rowfft call in flight (fft())
     double grid_slack = -1.0;  // set_dim_geom's slack_share for the next set_geometry / plan_buffer_cells (-1: the default)
     int *col_err = nullptr;
     void arm_columns(const int *tab, int tpol, int ncc, int *err = nullptr) {
@@ -2320,27 +2349,80 @@ class Nufft3 {
     // (Shared between the plans of one simulator -- its lanes cycle through the same geometries -- and filled by a
     // blocking copy that does not involve the plans' streams: a cold handle met 23 grid sizes x 4 lanes in its first
     // two time steps, each a weight table of 10^5 entries, a sort and a stream synchronisation: 0.4 s of a 2 s C3 call.)
-    using OrderCache = std::map<std::pair<int, int>, std::unique_ptr<DevBuf>>;
+    // Disc (disc_radius > 0, 2-D): the caller's sources are projections of unit vectors, x^2 + y^2 <= disc_radius^2 in the
+    // source coordinates whatever the box -- a fifth of a square grid's blocks can then never be touched.  Those blocks
+    // leave the launch list (nobody writes them), and the x-pass reads every row only over the extent the disc allows:
+    // row_ext[2 by], row_ext[2 by + 1] = first / one-past-last cell of the 8 rows of block row by, in whole 4-block
+    // groups; k_bin_count counts a source outside the disc as out of the box (the run fails).
+    struct OrderEntry {
+        DevBuf buf;  // n_groups launch entries, then (disc) 2 nby extents
+        int n_groups = 0;
+        bool ext = false;
+        int64_t cells = 0;  // cells of A the launch list writes = cells the x-pass reads
+    };
+    using OrderKey = std::array<double, 9>;
+    using OrderCache = std::map<OrderKey, std::unique_ptr<OrderEntry>>;
     std::shared_ptr<OrderCache> order_cache = std::make_shared<OrderCache>();
-    const int *order_ptr = nullptr;
+    const int *order_ptr = nullptr, *row_ext_ptr = nullptr;
+    int order_n = 0;
+    int64_t order_cells = 0;  // cells of A per transform that the spread writes and the first pass reads (2-D)
+    double disc_radius = 0.0;
+    static constexpr double disc_margin() { return sizeof(T) == 4 ? 1e-5 : 1e-9; }  // rounding of the callers' unit vectors
     void build_block_order() {
         const int nbx = geo.nbin[0], nby = geo.nbin[1], ngx = (int)cdiv(nbx, 4);
-        auto hit = order_cache->find({nbx, nby});
+        const bool disc = disc_radius > 0.0 && dim == 2 && rowfft_uses_st(geo.d[0], false);  // (the LDS kernel reads whole rows)
+        OrderKey key{(double)nbx, (double)nby, 0, 0, 0, 0, 0, 0, 0};
+        if (disc) key = {(double)nbx, (double)nby, geo.d[0].xc, geo.d[1].xc, geo.d[0].h, geo.d[1].h, (double)geo.d[0].na, (double)ker.w, disc_radius};
+        auto hit = order_cache->find(key);
         if (hit != order_cache->end()) {
-            order_ptr = hit->second->template as<int>();
+            order_ptr = hit->second->buf.template as<int>();
+            order_n = hit->second->n_groups;
+            order_cells = hit->second->cells;
+            row_ext_ptr = hit->second->ext ? order_ptr + order_n : nullptr;
             return;
         }
-        std::vector<int> order_host((size_t)ngx * nby);
-        if (order_host.size() > 16384) {
+        // extents of the block rows (cells; all of the row without a disc)
+        std::vector<int> ext(2 * (size_t)nby);
+        for (int by = 0; by < nby; ++by) {
+            int x0 = 0, x1 = geo.d[0].na;
+            if (disc) {
+                const int w = ker.w;
+                const DimGeom &gx = geo.d[0], &gy = geo.d[1];
+                // a source at grid position p (cells) touches the cells in [p - w/2, p + w/2]: the block row's cells
+                // 8 by .. 8 by + 7 are reached from p in (8 by - w/2, 8 by + 7 + w/2]; one more cell either side for rounding
+                const double pl = 8.0 * by - 0.5 * w - 1.0, ph = 8.0 * by + 7.0 + 0.5 * w + 1.0;
+                const double yl = (pl - 0.5 * gy.na) * gy.h + gy.xc, yh = (ph - 0.5 * gy.na) * gy.h + gy.xc;
+                const double ymin = yl > 0 ? yl : yh < 0 ? -yh : 0.0;  // smallest |y| in the interval
+                const double R = disc_radius * (1.0 + disc_margin());
+                if (ymin >= R) {
+                    x0 = x1 = 0;
+                } else {
+                    const double xm = std::sqrt(R * R - ymin * ymin);
+                    const double pxl = (-xm - gx.xc) / gx.h + 0.5 * gx.na, pxh = (xm - gx.xc) / gx.h + 0.5 * gx.na;
+                    const int c0 = (int)std::floor(pxl - 0.5 * w) - 1, c1 = (int)std::ceil(pxh + 0.5 * w) + 2;
+                    x0 = std::max(0, c0) / 32 * 32;
+                    x1 = std::min(gx.na, (std::max(c1, 0) + 31) / 32 * 32);
+                    if (x1 <= x0) x0 = x1 = 0;
+                }
+            }
+            ext[2 * (size_t)by] = x0;
+            ext[2 * (size_t)by + 1] = x1;
+        }
+        auto kept = [&](int by, int gx) { return 32 * gx < ext[2 * (size_t)by + 1] && 32 * gx + 32 > ext[2 * (size_t)by]; };
+        std::vector<int> order_host;
+        order_host.reserve((size_t)ngx * nby + 2 * (size_t)nby);
+        if ((size_t)ngx * nby > 16384) {
             // huge grids are HBM-bound and have thousands of groups per CU: raster order keeps their
             // writes local and the tail is negligible there
             for (int by = 0; by < nby; ++by)
-                for (int gx = 0; gx < ngx; ++gx) order_host[(size_t)by * ngx + gx] = (by << 16) | gx;
+                for (int gx = 0; gx < ngx; ++gx)
+                    if (kept(by, gx)) order_host.push_back((by << 16) | gx);
         } else {
-            std::vector<std::pair<float, int>> wg((size_t)ngx * nby);
+            std::vector<std::pair<float, int>> wg;
             for (int by = 0; by < nby; ++by) {
                 const double ry = ((by + 0.5) * (1 << BINLOG) - 0.5 * geo.d[1].na) / (0.5 * geo.d[1].na);
                 for (int gx = 0; gx < ngx; ++gx) {
+                    if (!kept(by, gx)) continue;
                     double wsum = 0;
                     for (int k = 0; k < 4; ++k) {
                         const int bx = gx * 4 + k;
@@ -2349,17 +2431,24 @@ class Nufft3 {
                         const double r2 = rx * rx + ry * ry;
                         wsum += r2 < 1.0 ? 1.0 / std::sqrt(std::max(1.0 - r2, 0.02)) : 0.05;
                     }
-                    wg[(size_t)by * ngx + gx] = {(float)wsum, (by << 16) | gx};
+                    wg.push_back({(float)wsum, (by << 16) | gx});
                 }
             }
             std::stable_sort(wg.begin(), wg.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-            for (size_t i = 0; i < wg.size(); ++i) order_host[i] = wg[i].second;
+            for (size_t i = 0; i < wg.size(); ++i) order_host.push_back(wg[i].second);
         }
-        std::unique_ptr<DevBuf> buf(new DevBuf);
-        buf->reserve(sizeof(int) * order_host.size());
-        FV_HIP(hipMemcpy(buf->p, order_host.data(), sizeof(int) * order_host.size(), hipMemcpyHostToDevice));
-        order_ptr = buf->template as<int>();
-        (*order_cache)[{nbx, nby}] = std::move(buf);
+        std::unique_ptr<OrderEntry> e(new OrderEntry);
+        e->n_groups = (int)order_host.size();
+        e->ext = disc;
+        for (int og : order_host) e->cells += (int64_t)std::min(4, nbx - (og & 0xffff) * 4) * 64;
+        order_host.insert(order_host.end(), ext.begin(), ext.end());
+        e->buf.reserve(sizeof(int) * order_host.size());
+        FV_HIP(hipMemcpy(e->buf.p, order_host.data(), sizeof(int) * order_host.size(), hipMemcpyHostToDevice));
+        order_ptr = e->buf.template as<int>();
+        order_n = e->n_groups;
+        order_cells = e->cells;
+        row_ext_ptr = disc ? order_ptr + order_n : nullptr;
+        (*order_cache)[key] = std::move(e);
     }
 
     // Upper bound (cells per transform) of the grid buffers a geometry will need: the same grid sizing as
@@ -2415,7 +2504,7 @@ class Nufft3 {
             geo.nbin[d] = geo.d[d].na >> BINLOG;
         for (int d = dim; d < 3; ++d) geo.nbin[d] = 1;
         }
-        if (first || old.nbin[0] != geo.nbin[0] || old.nbin[1] != geo.nbin[1]) build_block_order();
+        if (first || old.nbin[0] != geo.nbin[0] || old.nbin[1] != geo.nbin[1] || disc_radius > 0.0) build_block_order();
         for (int d = 0; d < dim; ++d) {
             const DimGeom &g = geo.d[d];
             if (old.d[d].na == g.na && old.d[d].n2 == g.n2 && dec[d].p && !first) continue;
@@ -2462,6 +2551,7 @@ class Nufft3 {
         BinArgs a{};
         a.w = ker.w;
         a.dim = dim;
+        a.r2max = row_ext_ptr ? disc_radius * disc_radius * (1.0 + 2.0 * disc_margin()) : 0.0;  // only where the disc is used (build_block_order)
         for (int d = 0; d < 3; ++d) {
             a.xc[d] = geo.d[d].xc;
             a.invh[d] = 1.0 / geo.d[d].h;
@@ -2578,6 +2668,7 @@ class Nufft3 {
         return ok;
     }
     double fft_traffic_cells() const;  // cells read + written by all FFT passes, per transform
+    int64_t spread_cells() const { return dim == 2 ? order_cells : geo.cells_a(); }  // cells of A the spread writes, per transform
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
     // index list / flip flags of length N, per-group scale (device, nfg doubles).
     void interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
@@ -2608,7 +2699,7 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
     hipEvent_t es = tbegin == 0 ? e0 : nullptr;
     hipEvent_t ee = tbegin + nchunk * TCH == ntrans ? e1 : nullptr;
     if (dim == 2) {
-        dim3 g((unsigned)(cdiv(geo.nbin[0], 4) * geo.nbin[1] * nchunk), mate ? 2 : 1);
+        dim3 g((unsigned)((int64_t)order_n * nchunk), mate ? 2 : 1);  // the launch list: every 4-block group (inside the disc)
         SpreadMate sm{};
         if (mate) {
             sm.i0s = mate->i0s.template as<int>();
@@ -2763,6 +2854,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.cnt = g.sP() > 1 ? g.cnt() : 0;
     a.in_blk = in_blk;
     a.out_blk = out_blk;
+    if (first_pass_ext) a.row_ext = first_pass_ext;  // (row mode, register-resident kernels: fft() only sets it there)
     if (out_blk && col_tab) {  // the x-pass of a column plan
         a.ctab = col_tab;
         a.ctab_stride = g.nos();
@@ -2892,7 +2984,8 @@ double Nufft3<T>::fft_traffic_cells() const {
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
     const double xo = col_tab ? (double)col_ncc : (double)x.no;          // columns stored by the x-pass (column plan: those a target reads)
-    double c = zin * ((double)x.na * y.na + xo * y.na);                  // x-pass
+    const double ain = dim == 2 && row_ext_ptr ? (double)order_cells : (double)x.na * y.na;  // cells of A inside the source disc
+    double c = zin * (ain + xo * y.na);                                  // x-pass
     if (!y_reads_columns()) c += zin * 2.0 * x.no * y.na;                 // transpose
     c += zin * (xo * y.na + (last_fft_fused ? 0.0 : xo * y.no));         // y-pass (no C when fused)
     if (dim > 2) c += (double)x.no * y.no * (z.na + z.no);               // z-pass
@@ -2919,7 +3012,9 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
     const int64_t xp = b_pitch();
     const int blk = b_block_log();
     FV_REQUIRE(!col_tab || (blk && y_reads_columns() && !fused_active), "column plan: blocked B, column-mode y-pass, stand-alone gather");
+    first_pass_ext = row_ext_ptr;  // the spread left the blocks outside the disc unwritten (build_block_order)
     rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp, 0, nullptr, cur1, oth1, 0, blk);
+    first_pass_ext = nullptr;
     std::swap(cur, oth);
     std::swap(cur1, oth1);
     if (y_reads_columns()) {

@@ -2163,6 +2163,8 @@ class Sim : public SimBase {
             if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma)
                 L.nufft.reset(new Nufft3<T>(D, eps, sigma, li < 2 ? L.stream : stream));
             L.nufft->err_oob = d_err.as<int>();
+            // the sources are 2 pi x (projections of unit vectors onto the array plane): inside a disc whatever the box
+            L.nufft->disc_radius = D == 2 && !std::getenv("FFTVIS_HIP_NO_DISC") ? 2.0 * M_PI : 0.0;
             L.nufft->transpose_flipped = !reference_compat;
             if (li > 0) L.nufft->order_cache = lanes[0].nufft->order_cache;  // one table per grid size for all lanes
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
@@ -2374,7 +2376,7 @@ class Sim : public SimBase {
                     }
                     }
                     st[0] += nm;  // launches are counted per (time, frequency group, beam pair)
-                    st[1] += (double)nufft->geo.cells_a() * ntrans * nm;
+                    st[1] += (double)nufft->spread_cells() * ntrans * nm;  // cells written (2-D: the blocks inside the source disc)
                     for (int m = 0; m < nm; ++m) mhist_log[hist_slot[m]].second += ntrans;
                     cplx<T> *obase = dout + ((int64_t)(fa - f0) * nt + (tu - t0)) * per_tf;
                     // small 2-D grids: the last FFT pass serves the targets from its LDS tiles (no C

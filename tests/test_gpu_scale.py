@@ -501,6 +501,7 @@ def test_column_plan_stores_only_the_columns_targets_read(gpu, monkeypatch):
             monkeypatch.setenv(k_, v_)
         gpu_simulate.release_handles()
         monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+        monkeypatch.setenv("FFTVIS_HIP_GRID_SLACK", "0")  # one geometry for both runs (a plan's geometry takes no grid slack)
         monkeypatch.delenv("FFTVIS_HIP_NO_COLUMN_PLAN", raising=False)
         some = fftvis_amd.simulate_vis(**c)
         (h,) = gpu_simulate._IDLE_HANDLES.values()
@@ -510,6 +511,7 @@ def test_column_plan_stores_only_the_columns_targets_read(gpu, monkeypatch):
         every = fftvis_amd.simulate_vis(**c)
         cells_every = h.stats()["fft_cells"]
         monkeypatch.delenv("FFTVIS_HIP_NO_COLUMN_PLAN")
+        monkeypatch.delenv("FFTVIS_HIP_GRID_SLACK")
         for k_ in env:
             monkeypatch.delenv(k_)
         assert np.isfinite(some).all()
@@ -518,6 +520,36 @@ def test_column_plan_stores_only_the_columns_targets_read(gpu, monkeypatch):
         else:
             assert cells_some == cells_every, (name, cells_some, cells_every)
         d = rel_l2(some, every)
+        assert d < (1e-6 if c.get("precision") == 1 else 1e-13), (name, d)
+    gpu_simulate.release_handles()
+
+
+def test_source_disc_prunes_spread_blocks_and_row_loads(gpu, monkeypatch):
+    """Sources are projections of unit vectors onto the array plane: inside the disc |x| <= 2 pi whatever the box.
+    The spread then launches only the blocks the disc can reach and the x-pass reads each row over the disc's
+    chord only.  Nothing but never-touched zeros is left out: the block must equal the run without the disc
+    (FFTVIS_HIP_NO_DISC=1) to rounding -- HERA-350 geometry (folded rows, paired residues), a band whose x-pass
+    runs Q = 4096 rows, C2 (small grids, fused gather), a planar array on a slope (rotated plane: the disc is
+    off-centre in the box), fp32."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    cfg = synth.make_config("C3", nsrc=20_000, nfreq=3, ntimes=2)
+    cfg["baselines"] = cfg["baselines"][::5]
+    mid = dict(cfg, freqs=np.linspace(140e6, 142e6, 3))
+    mid["beam"] = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(mid["freqs"]), mid["freqs"])
+    slope = {k: v + np.array([0.0, 0.0, 0.05 * v[0] - 0.02 * v[1]]) for k, v in cfg["ants"].items()}
+    c2 = synth.make_config("C2", nfreq=8, ntimes=2)
+    cases = {"C3": cfg, "Q = 4096 rows": mid, "C2": c2, "slope": dict(cfg, ants=slope), "fp32": dict(cfg, precision=1, eps=1e-4)}
+    for name, c in cases.items():
+        gpu_simulate.release_handles()
+        monkeypatch.delenv("FFTVIS_HIP_NO_DISC", raising=False)
+        pruned = fftvis_amd.simulate_vis(**c)
+        gpu_simulate.release_handles()
+        monkeypatch.setenv("FFTVIS_HIP_NO_DISC", "1")
+        full = fftvis_amd.simulate_vis(**c)
+        monkeypatch.delenv("FFTVIS_HIP_NO_DISC")
+        assert np.isfinite(pruned).all()
+        d = rel_l2(pruned, full)
         assert d < (1e-6 if c.get("precision") == 1 else 1e-13), (name, d)
     gpu_simulate.release_handles()
 
