@@ -930,6 +930,11 @@ struct RowDifArgs {
     // Row extents (row mode, first pass of a 2-D transform whose sources lie in a disc; Nufft3::disc_radius): the input
     // row k of a plane is non-zero -- and was written by the spread -- only in [row_ext[2 (k >> 3)], row_ext[2 (k >> 3) + 1]).
     const int *row_ext;
+    // Output mask (column mode under a column plan): bit c of omask[(((plane / omask_tpol) omask_nblk + column block) P +
+    // residue) words + c / 64] says whether ANY target reads one of the block's outputs k' in [16 c, 16 c + 16) of that
+    // residue; the stores of the other chunks -- most of them: footprints are w cells high -- are branched over.
+    const unsigned long long *omask;
+    int omask_tpol, omask_nblk;
 };
 
 template <typename T>
@@ -1530,6 +1535,9 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
             for (int kk = 0; kk < HALF; ++kk) theirs[kk] = xb[pabase + kk * KS];  // now: the partner's slots of MY residue
             __syncthreads();  // read before the exchanges overwrite it
         }
+        // odd P: the last job's second group has folded its half for the partner and has no residue of its own --
+        // its waves end here (whole waves: a barrier counts the waves still running)
+        if (p >= a.P) return;
         if (g == 0) {  // wave-uniform: slots 0..7 are mine, 8..15 came from the partner
 #pragma unroll
             for (int kk = 0; kk < HALF; ++kk) {
@@ -1806,6 +1814,16 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     const int blk_step = (((Q / R3) * ostep) >> a.out_blk) * blk_rows, blk_wrap = ((Q * ostep) >> a.out_blk) * blk_rows;
     const unsigned blk_len = ok && ks_hi > ks_lo ? (unsigned)(ks_hi - ks_lo) : 0u;
     const int lane_out = COL ? (int)((rplane * a.rpp_valid + rk) * a.out_pitch + res_off - out_base) : 0;
+    unsigned long long om_lo = ~0ull, om_hi = ~0ull;  // output mask of this (frequency, column block, residue): uniform
+    if constexpr (COL && !FUSED && LOGQ <= 11) {
+        if (a.omask) {
+            constexpr int NW = Q > 1024 ? Q / 1024 : 1;
+            const int64_t fgi = (row0 / a.rpp) / a.omask_tpol, bi = (row0 % a.rpp) / NL;
+            const unsigned long long *mp = a.omask + ((fgi * a.omask_nblk + bi) * a.P + p) * NW;
+            om_lo = mp[0];
+            om_hi = NW > 1 ? mp[NW - 1] : 0ull;
+        }
+    }
     const int col_step = (Q / R3) * ostep, col_wrap = Q * ostep;  // uniform
     int col_pos0[NI3];
 #pragma unroll
@@ -1853,6 +1871,10 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
             if constexpr (!FUSED && !(COL && LOGQ == 12)) {  // (the 1024-thread column kernel has no register to spare)
                 const int rel_first = (v_first - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
                 if (rel_first + v_span < 0 || rel_first >= want) continue;  // wave-uniform
+                if constexpr (COL && LOGQ <= 11) {  // column plan: chunks of 16 outputs no target reads
+                    const int c = (v_first + k * (Q / R3)) >> 4;
+                    if (!(((c < 64 ? om_lo : om_hi) >> (c & 63)) & 1ull)) continue;  // wave-uniform
+                }
             }
             if constexpr (FUSED) {
                 if (l >= -half_n && l < a.n_out - half_n) rout[ks * ostep] = vc[i][bitrev_small(k, L3)];
@@ -2248,6 +2270,64 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     }
 }
 
+// Output mask of a column plan's y-pass (RowDifArgs::omask): every distinct target (and its mirror image where the
+// run gathers there too) marks, for the compact column blocks its footprint columns fall in, the 16-output chunks of
+// each residue that hold one of its footprint rows.  Footprints are placed as k_interp places them; one whose first
+// cell is within 1e-6 of a rounding boundary marks a cell more on either side.
+struct RowMaskArgs {
+    int w, nfg, sides;
+    int n2x, nox, Px, cntx, n2y, noy, Py, Qy;
+    double hx, btcx, hy, btcy;
+    int blk_log, nblk, nw, ctab_stride;
+};
+template <typename T>
+__global__ void k_plan_rowmask(int64_t NU, const T *__restrict__ btx, const T *__restrict__ bty,
+                               const int *__restrict__ bl_idx, const signed char *__restrict__ flip,
+                               const int *__restrict__ ustart, const double *__restrict__ scale, RowMaskArgs a,
+                               const int *__restrict__ ctab, unsigned long long *__restrict__ mask) {
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= NU * a.nfg * a.sides) return;
+    const int side = (int)(item % a.sides);
+    const int64_t rest = item / a.sides;
+    const int fg = (int)(rest / NU);
+    const int64_t ui = rest % NU;
+    const int64_t kl = ustart ? ustart[ui] : ui;
+    const int64_t k = bl_idx ? bl_idx[kl] : kl;
+    const double sg = (flip && flip[kl]) ? -1.0 : 1.0, sgn = side ? -1.0 : 1.0, sc = scale[fg];
+    int lo[2], hi[2];
+    const double hh[2] = {a.hx, a.hy}, bc[2] = {a.btcx, a.btcy};
+    const int n2[2] = {a.n2x, a.n2y}, no[2] = {a.nox, a.noy};
+    const double b[2] = {(double)btx[k], (double)bty[k]};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const double sv = sc * sg * b[d];
+        const double th = hh[d] * (sv - sc * bc[d]);
+        const double e = sgn * th * n2[d] * (0.5 / M_PI) + 0.5 * no[d];
+        const double t = e - 0.5 * a.w, jc = ceil(t);
+        const bool amb = jc - t < 1e-6 || jc - t > 1.0 - 1e-6;
+        lo[d] = max(0, min(no[d] - a.w, (int)jc));
+        hi[d] = lo[d] + a.w - 1;
+        if (amb) {
+            lo[d] = max(0, lo[d] - 1);
+            hi[d] = min(no[d] - 1, hi[d] + 1);
+        }
+    }
+    const int half = a.noy / 2;
+    for (int cx = lo[0]; cx <= hi[0]; ++cx) {
+        const int t = ctab[(int64_t)fg * a.ctab_stride + out_pos(cx, a.Px, a.cntx)];
+        if (!t) continue;  // (only a cell added for rounding here and not by the host's plan)
+        const int64_t blk = (t - 1) >> a.blk_log;
+        for (int cy = lo[1]; cy <= hi[1]; ++cy) {
+            const int l = cy - half;
+            int pp = l % a.Py;
+            if (pp < 0) pp += a.Py;
+            const int ks = (l - pp) / a.Py;
+            const int c = (ks < 0 ? ks + a.Qy : ks) >> 4;
+            atomicOr(&mask[(((int64_t)fg * a.nblk + blk) * a.Py + pp) * a.nw + (c >> 6)], 1ull << (c & 63));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host-side plan
 // ---------------------------------------------------------------------------------------------
@@ -2260,6 +2340,7 @@ struct BasisTerm {
 };
 
 inline bool rowfft_uses_st(const DimGeom &g, bool col);
+inline void rowfft_shape(const DimGeom &g, bool col, int &tpr, int &rpw);
 
 template <typename T>
 class Nufft3 {
@@ -2298,11 +2379,44 @@ class Nufft3 {
     const int *first_pass_ext = nullptr;  // RowDifArgs::row_ext of the rowfft call in flight (fft())
     double grid_slack = -1.0;  // set_dim_geom's slack_share for the next set_geometry / plan_buffer_cells (-1: the default)
     int *col_err = nullptr;
-    void arm_columns(const int *tab, int tpol, int ncc, int *err = nullptr) {
+    const unsigned long long *col_omask = nullptr;  // RowDifArgs::omask of the y-pass (k_plan_rowmask), or nullptr
+    int col_omask_nblk = 0;
+    double col_out_cells = 0;  // cells of C per transform the masked y-pass stores (0: all)
+    void arm_columns(const int *tab, int tpol, int ncc, int *err = nullptr, const unsigned long long *omask = nullptr,
+                     int omask_nblk = 0) {
         col_tab = tab && dim == 2 && b_block_log() ? tab : nullptr;
         col_tab_tpol = tpol;
         col_ncc = ncc;
         col_err = err;
+        col_omask = col_tab ? omask : nullptr;
+        col_omask_nblk = omask_nblk;
+        col_out_cells = 0;
+    }
+    int ypass_cols_log() const {  // log2 of the columns a y-pass workgroup owns (column mode)
+        int tpr, rpw;
+        rowfft_shape(geo.d[1], true, tpr, rpw);
+        return ilog2_c(rpw);
+    }
+    // builds the y-pass output mask of a column plan from the plan's targets (device arrays) on `stream`
+    void build_rowmask(int64_t NU, const T *btx, const T *bty, const int *bl_idx, const signed char *flip, const int *ustart,
+                       const double *scale_dev, int nfg, bool both, const int *ctab, int ncc, unsigned long long *mask,
+                       int nblk, int nw) const {
+        const DimGeom &x = geo.d[0], &y = geo.d[1];
+        RowMaskArgs a{};
+        a.w = ker.w;
+        a.nfg = nfg;
+        a.sides = both ? 2 : 1;
+        a.n2x = x.n2; a.nox = x.no; a.Px = x.sP(); a.cntx = x.cnt(); a.hx = x.h; a.btcx = x.btc;
+        a.n2y = y.n2; a.noy = y.no; a.Py = y.P; a.Qy = y.Q; a.hy = y.h; a.btcy = y.btc;
+        a.blk_log = ypass_cols_log();
+        a.nblk = nblk;
+        a.nw = nw;
+        a.ctab_stride = x.nos();
+        (void)ncc;
+        const int64_t items = NU * nfg * a.sides;
+        if (items == 0) return;
+        hipLaunchKernelGGL(k_plan_rowmask<T>, dim3((unsigned)cdiv(items, 256)), dim3(256), 0, stream, NU, btx, bty, bl_idx,
+                           flip, ustart, scale_dev, a, ctab, mask);
     }
     int xcols() const { return col_tab ? col_ncc : geo.d[0].nos(); }  // columns of B / rows of C per transform
     bool columns_possible() const { return dim == 2 && b_block_log() != 0 && y_reads_columns() && !fused_possible(); }
@@ -2854,6 +2968,11 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.cnt = g.sP() > 1 ? g.cnt() : 0;
     a.in_blk = in_blk;
     a.out_blk = out_blk;
+    if (a.colmode && in_blk && col_tab && col_omask && !fused && g.logQ <= 11) {  // the y-pass of a column plan
+        a.omask = col_omask;
+        a.omask_tpol = col_tab_tpol;
+        a.omask_nblk = col_omask_nblk;
+    }
     if (first_pass_ext) a.row_ext = first_pass_ext;  // (row mode, register-resident kernels: fft() only sets it there)
     if (out_blk && col_tab) {  // the x-pass of a column plan
         a.ctab = col_tab;
@@ -2987,7 +3106,7 @@ double Nufft3<T>::fft_traffic_cells() const {
     const double ain = dim == 2 && row_ext_ptr ? (double)order_cells : (double)x.na * y.na;  // cells of A inside the source disc
     double c = zin * (ain + xo * y.na);                                  // x-pass
     if (!y_reads_columns()) c += zin * 2.0 * x.no * y.na;                 // transpose
-    c += zin * (xo * y.na + (last_fft_fused ? 0.0 : xo * y.no));         // y-pass (no C when fused)
+    c += zin * (xo * y.na + (last_fft_fused ? 0.0 : col_tab && col_omask && col_out_cells > 0 ? col_out_cells : xo * y.no));  // y-pass (no C when fused)
     if (dim > 2) c += (double)x.no * y.no * (z.na + z.no);               // z-pass
     return c;
 }

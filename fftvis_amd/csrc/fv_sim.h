@@ -1432,15 +1432,24 @@ class Sim : public SimBase {
         DevBuf tab;
         int ncc = 0;
         bool use = false;
+        // y-pass output mask (k_plan_rowmask): which 16-output chunks of each (column block, residue) hold a footprint row
+        int yn2 = 0, yno = 0, yP = 0, yQ = 0;
+        double yh = 0, ybtc = 0;
+        DevBuf omask;
+        int nblk = 0;
+        double out_cells = 0;  // cells of C per transform the masked y-pass stores
     };
     std::vector<std::unique_ptr<ColPlan>> col_plans;
     std::vector<ColPlan *> col_plan_of;  // [group * pairs + pair] of the current run
-    ColPlan *column_plan(int pi, const Pair &pr, int fa, int fb, const DimGeom &x, int w) {
+    ColPlan *column_plan(int pi, const Pair &pr, int fa, int fb, Nufft3<T> *n0) {
+        const DimGeom &x = n0->geo.d[0], &y = n0->geo.d[1];
+        const int w = n0->ker.w;
         const bool both = pr.herm || pr.mirror;
         for (auto &c : col_plans)
             if (c->serial == targets_serial && c->pair == pi && c->fa == fa && c->fb == fb && c->nos == x.nos() &&
                 c->sP == x.sP() && c->cnt == x.cnt() && c->n2 == x.n2 && c->no == x.no && c->w == w && c->h == x.h &&
-                c->btc == x.btc && c->both == both)
+                c->btc == x.btc && c->both == both && c->yn2 == y.n2 && c->yno == y.no && c->yP == y.P && c->yQ == y.Q &&
+                c->yh == y.h && c->ybtc == y.btc)
                 return c.get();
         if (col_plans.size() > 512) col_plans.clear();  // stale versions of earlier target sets
         std::unique_ptr<ColPlan> c(new ColPlan{targets_serial, pi, fa, fb, x.nos(), x.sP(), x.cnt(), x.n2, x.no, w, x.h, x.btc, both});
@@ -1476,7 +1485,31 @@ class Sim : public SimBase {
             if (run * 100 > x.no * 85) c->use = false;  // nothing to gain (decided on the first frequency already)
         }
         c->ncc = (c->ncc + 7) / 8 * 8;
-        if (c->use) upload(c->tab, tab.data(), sizeof(int) * tab.size(), 0);
+        c->yn2 = y.n2; c->yno = y.no; c->yP = y.P; c->yQ = y.Q; c->yh = y.h; c->ybtc = y.btc;
+        if (c->use) {
+            upload(c->tab, tab.data(), sizeof(int) * tab.size(), 0);
+            // the y-pass output mask, on the device from the same targets
+            if (y.logQ >= 9 && y.logQ <= 11 && !std::getenv("FFTVIS_HIP_NO_OUTPUT_MASK")) {
+                const int bl = n0->ypass_cols_log(), nw = y.Q > 1024 ? y.Q / 1024 : 1;
+                c->nblk = (c->ncc + (1 << bl) - 1) >> bl;
+                const size_t words = (size_t)nfg * c->nblk * y.P * nw;
+                c->omask.reserve(sizeof(unsigned long long) * words);
+                FV_HIP(hipMemsetAsync(c->omask.p, 0, sizeof(unsigned long long) * words, stream));
+                hipStream_t keep = n0->stream;
+                n0->stream = stream;
+                n0->build_rowmask(nu, d_bls.as<T>(), d_bls.as<T>() + nbls, pr.trivial ? nullptr : pr.idx->template as<int>(),
+                                  pr.trivial ? nullptr : pr.flip->template as<signed char>(),
+                                  pr.ustart ? pr.ustart->template as<int>() : nullptr, d_freqs.as<double>() + fa, nfg, both,
+                                  c->tab.template as<int>(), c->ncc, c->omask.template as<unsigned long long>(), c->nblk, nw);
+                n0->stream = keep;
+                std::vector<unsigned long long> hm(words);
+                FV_HIP(hipMemcpyAsync(hm.data(), c->omask.p, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, stream));
+                FV_HIP(hipStreamSynchronize(stream));
+                double bits = 0;
+                for (unsigned long long v : hm) bits += __builtin_popcountll(v);
+                c->out_cells = bits * 16.0 * (1 << bl) / nfg;
+            }
+        }
         col_plans.push_back(std::move(c));
         return col_plans.back().get();
     }
@@ -2211,8 +2244,7 @@ class Sim : public SimBase {
                         n0->grid_slack = 0.0;  // a plan's geometry: no grid slack (set_dim_geom)
                         n0->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
                         if (!n0->columns_possible() || n0->geo.cells_o() < 4000000) continue;
-                        col_plan_of[gi * pairs.size() + pi] =
-                            column_plan((int)pi, pr, groups[gi].first, groups[gi].second, n0->geo.d[0], n0->ker.w);
+                        col_plan_of[gi * pairs.size() + pi] = column_plan((int)pi, pr, groups[gi].first, groups[gi].second, n0);
                     }
                 }
                 FV_HIP(hipStreamSynchronize(n0->stream));  // the table kernels of these set_geometry calls are done before the run's own
@@ -2356,8 +2388,12 @@ class Sim : public SimBase {
                     {
                         ColPlan *cp = col_plan_of[(size_t)(&grp - groups.data()) * pairs.size() + (size_t)(&pr - pairs.data())];
                         const bool on = cp && cp->use;
-                        for (int m = 0; m < nm; ++m)
-                            Ls[m]->nufft->arm_columns(on ? cp->tab.template as<int>() : nullptr, tg, on ? cp->ncc : 0, d_err.as<int>() + 3);
+                        for (int m = 0; m < nm; ++m) {
+                            Ls[m]->nufft->arm_columns(on ? cp->tab.template as<int>() : nullptr, tg, on ? cp->ncc : 0, d_err.as<int>() + 3,
+                                                      on && cp->omask.p ? cp->omask.template as<unsigned long long>() : nullptr,
+                                                      on ? cp->nblk : 0);
+                            Ls[m]->nufft->col_out_cells = on && cp->omask.p ? cp->out_cells : 0.0;
+                        }
                     }
                     {
                     RoctxRange rr("spread");
