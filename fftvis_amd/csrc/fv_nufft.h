@@ -2377,7 +2377,21 @@ class Nufft3 {
     const int *col_tab = nullptr;
     int col_tab_tpol = 1, col_ncc = 0;
     const int *first_pass_ext = nullptr;  // RowDifArgs::row_ext of the rowfft call in flight (fft())
-    double grid_slack = -1.0;  // set_dim_geom's slack_share for the next set_geometry / plan_buffer_cells (-1: the default)
+    double grid_slack = -1.0;
+    // the slack share a geometry takes: the caller's, else the default on HBM-bound grids (>= 4e6 fine-grid cells) and
+    // none on small ones (latency-bound: C2 runs 2 % faster on the tight grid)
+    double slack_for(const double *X, const double *B, double scale_max) const {
+        if (grid_slack >= 0.0) return grid_slack;
+        double cells = 1.0;
+        for (int d = 0; d < dim; ++d) {
+            DimGeom g;
+            g.X = X[d];
+            g.B = B[d];
+            set_dim_geom(g, sigma, ker.w, scale_max, true, 0.0);
+            cells *= g.n2;
+        }
+        return cells >= 4.0e6 ? -1.0 : 0.0;
+    }  // set_dim_geom's slack_share for the next set_geometry / plan_buffer_cells (-1: the default)
     int *col_err = nullptr;
     const unsigned long long *col_omask = nullptr;  // RowDifArgs::omask of the y-pass (k_plan_rowmask), or nullptr
     int col_omask_nblk = 0;
@@ -2435,7 +2449,16 @@ class Nufft3 {
     const int *Mp = nullptr;   // device-side live source count (optional)
     int *oob_ptr = nullptr;
     int *err_oob = nullptr;    // owner's sticky counter of clamped / NaN sources (else the plan's own, reset per sort)
-    DevBuf dec[3], tw[3];
+    DevBuf dec[3], tw[3];  // (set_fft_geometry's twiddles; set_geometry keeps its tables in tab_cache)
+    // Deconvolution / twiddle tables of a dimension depend on (na, n2) only and a run cycles through the same two dozen
+    // geometries every time step: built once each and kept (they were 1.3 % of a C3 step, rebuilt 46 times per time
+    // step), and a table is never rewritten while an earlier launch may still read it.
+    struct DimTables {
+        DevBuf dec, tw;
+    };
+    std::map<std::pair<int, int>, std::unique_ptr<DimTables>> tab_cache[3];
+    const T *dec_cur[3] = {nullptr, nullptr, nullptr};
+    const cplx<T> *tw_cur[3] = {nullptr, nullptr, nullptr};
     DevBuf buf0, buf1;  // ping-pong: A -> (x-pass) B -> (transpose) Bt -> (y-pass) Ct
     DevBuf strengths;   // [M][ntrans] sorted order
 
@@ -2572,10 +2595,11 @@ class Nufft3 {
     int64_t plan_buffer_cells(const double *X, const double *B, double scale_max, int *na_max = nullptr,
                               int *n2_max = nullptr) const {
         DimGeom g[3];
+        const double slack = slack_for(X, B, scale_max);
         for (int d = 0; d < dim; ++d) {
             g[d].X = X[d];
             g[d].B = B[d];
-            set_dim_geom(g[d], sigma, ker.w, scale_max, d == dim - 1, grid_slack);
+            set_dim_geom(g[d], sigma, ker.w, scale_max, d == dim - 1, slack);
             if (d > 0) cap_column_q(g[d]);
             g[d].rm = d != dim - 1 && !debug_switch_natural_order();
             if (na_max) na_max[d] = std::max(na_max[d], g[d].na);
@@ -2589,16 +2613,8 @@ class Nufft3 {
     void reserve_buffers(int64_t cells, const int *na_max, const int *n2_max) {
         buf0.reserve(sizeof(cplx<T>) * (size_t)cells);
         buf1.reserve(sizeof(cplx<T>) * (size_t)cells);
-        for (int d = 0; d < dim; ++d) {
-            // growing a table frees its contents: forget the geometry they were built for, so that set_geometry
-            // rebuilds them instead of trusting an unchanged (na, n2)
-            if (sizeof(T) * (size_t)na_max[d] > dec[d].cap || sizeof(cplx<T>) * (size_t)n2_max[d] > tw[d].cap) {
-                geo.d[d].na = -1;
-                geo.d[d].n2 = -1;
-            }
-            dec[d].reserve(sizeof(T) * (size_t)na_max[d]);
-            tw[d].reserve(sizeof(cplx<T>) * (size_t)n2_max[d]);
-        }
+        (void)na_max;
+        (void)n2_max;
     }
 
     // Bounds -> grid sizes, deconvolution + twiddle tables.
@@ -2606,12 +2622,13 @@ class Nufft3 {
                       double scale_max) {
         Geom old = geo;
         const bool first = geom_serial == 0;
+        const double slack = slack_for(X, B, scale_max);
         for (int d = 0; d < dim; ++d) {
             geo.d[d].xc = xc[d];
             geo.d[d].X = X[d];
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
-            set_dim_geom(geo.d[d], sigma, ker.w, scale_max, d == dim - 1, grid_slack);
+            set_dim_geom(geo.d[d], sigma, ker.w, scale_max, d == dim - 1, slack);
             if (d > 0) cap_column_q(geo.d[d]);
             // (residue-major storage of the last dimension as well: C3's FFT passes -2.5 %, its gather +41 %)
             geo.d[d].rm = d != dim - 1 && !debug_switch_natural_order();
@@ -2621,13 +2638,27 @@ class Nufft3 {
         if (first || old.nbin[0] != geo.nbin[0] || old.nbin[1] != geo.nbin[1] || disc_radius > 0.0) build_block_order();
         for (int d = 0; d < dim; ++d) {
             const DimGeom &g = geo.d[d];
-            if (old.d[d].na == g.na && old.d[d].n2 == g.n2 && dec[d].p && !first) continue;
-            dec[d].reserve(sizeof(T) * g.na);
-            hipLaunchKernelGGL(k_deconv_table<T>, dim3(cdiv(g.na, 256)), dim3(256), 0, stream, g.na,
-                               g.n2, ker, dec[d].as<T>());
-            tw[d].reserve(sizeof(cplx<T>) * g.n2);
-            hipLaunchKernelGGL(k_twiddle_table<T>, dim3(cdiv(g.n2, 256)), dim3(256), 0, stream,
-                               g.n2, tw[d].as<cplx<T>>());
+            if (old.d[d].na == g.na && old.d[d].n2 == g.n2 && dec_cur[d] && !first) continue;
+            std::unique_ptr<DimTables> &e = tab_cache[d][{g.na, g.n2}];
+            if (!e) {
+                if (tab_cache[d].size() > 256) {  // (a long-lived plan that met hundreds of geometries: start over)
+                    FV_HIP(hipStreamSynchronize(stream));
+                    tab_cache[d].clear();
+                }
+                std::unique_ptr<DimTables> &f = tab_cache[d][{g.na, g.n2}];
+                f.reset(new DimTables);
+                f->dec.reserve(sizeof(T) * g.na);
+                hipLaunchKernelGGL(k_deconv_table<T>, dim3(cdiv(g.na, 256)), dim3(256), 0, stream, g.na,
+                                   g.n2, ker, f->dec.template as<T>());
+                f->tw.reserve(sizeof(cplx<T>) * g.n2);
+                hipLaunchKernelGGL(k_twiddle_table<T>, dim3(cdiv(g.n2, 256)), dim3(256), 0, stream,
+                                   g.n2, f->tw.template as<cplx<T>>());
+                dec_cur[d] = f->dec.template as<T>();
+                tw_cur[d] = f->tw.template as<cplx<T>>();
+                continue;
+            }
+            dec_cur[d] = e->dec.template as<T>();
+            tw_cur[d] = e->tw.template as<cplx<T>>();
         }
         bool changed = first;
         for (int d = 0; d < dim; ++d)
@@ -2731,6 +2762,7 @@ class Nufft3 {
             hipLaunchKernelGGL(k_twiddle_table<T>, dim3(cdiv(g[d].n2, 256)), dim3(256), 0, stream,
                                g[d].n2, tw[d].as<cplx<T>>());
         }
+        for (int d = 0; d < 2; ++d) tw_cur[d] = tw[d].as<cplx<T>>();
     }
     cplx<T> *fft_input(int ntrans) {
         int64_t c0, c1;
@@ -2833,7 +2865,7 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
                               (const int *)i0s.as<int>(), (const T *)kw.as<T>(),
                               (const int *)bin_start.as<int>(),
                               (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin,
-                              (const T *)dec[0].as<T>(), (const T *)dec[1].as<T>(),
+                              dec_cur[0], dec_cur[1],
                               buf0.as<cplx<T>>(), x.na, y.na, geo.nbin[0], ker.w,
                               order_ptr, nchunk, sm);
     } else {
@@ -2842,8 +2874,8 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
                               (const int *)i0s.as<int>(), (const T *)kw.as<T>(),
                               (const int *)bin_start.as<int>(),
                               (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin, nchunk,
-                              (const T *)dec[0].as<T>(), (const T *)dec[1].as<T>(),
-                              (const T *)dec[2].as<T>(), buf0.as<cplx<T>>(), x.na, y.na, z.na,
+                              dec_cur[0], dec_cur[1],
+                              dec_cur[2], buf0.as<cplx<T>>(), x.na, y.na, z.na,
                               geo.nbin[0], geo.nbin[1], ker.w);
     }
     return tbegin + nchunk * TCH;
@@ -3132,7 +3164,7 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
     const int blk = b_block_log();
     FV_REQUIRE(!col_tab || (blk && y_reads_columns() && !fused_active), "column plan: blocked B, column-mode y-pass, stand-alone gather");
     first_pass_ext = row_ext_ptr;  // the spread left the blocks outside the disc unwritten (build_block_order)
-    rowfft(cur, oth, x, tw[0].as<cplx<T>>(), np, y.na, (int64_t)y.na * x.na, x.na, 1, xp, 0, nullptr, cur1, oth1, 0, blk);
+    rowfft(cur, oth, x, tw_cur[0], np, y.na, (int64_t)y.na * x.na, x.na, 1, xp, 0, nullptr, cur1, oth1, 0, blk);
     first_pass_ext = nullptr;
     std::swap(cur, oth);
     std::swap(cur1, oth1);
@@ -3140,7 +3172,7 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
         // the y-pass reads rpw adjacent columns of B at once (32-128 B segments; neighbouring workgroups share lines),
         // which fuses the transpose:  B -> C [p][no_x][no_y]; the xp - no_x padding columns of a
         // plane are skipped as rows
-        rowfft(cur, oth, y, tw[1].as<cplx<T>>(), np, xp, (int64_t)y.na * xp, 1, xp, 0, xcols(),
+        rowfft(cur, oth, y, tw_cur[1], np, xp, (int64_t)y.na * xp, 1, xp, 0, xcols(),
                fused_active ? &fused_args : nullptr, cur1, oth1, blk, 0);
         std::swap(cur, oth);
         std::swap(cur1, oth1);
@@ -3149,14 +3181,14 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
         dim3 tg((unsigned)cdiv(x.nos(), 32), (unsigned)cdiv(y.na, 32), (unsigned)np);
         hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, cur, oth, y.na, x.nos());
         if (mate) hipLaunchKernelGGL(k_transpose<T>, tg, dim3(256), 0, stream, cur1, oth1, y.na, x.nos());
-        rowfft(oth, cur, y, tw[1].as<cplx<T>>(), np, x.nos(), (int64_t)x.nos() * y.na, y.na, 1, 0, 0, nullptr,
+        rowfft(oth, cur, y, tw_cur[1], np, x.nos(), (int64_t)x.nos() * y.na, y.na, 1, 0, 0, nullptr,
                oth1, cur1);
     }
     if (dim > 2) {
         // z-pass: C [t][na_z][nc] (nc = no_x no_y) -> D [t][nc][no_z]; adjacent (lx, ly) columns
         // are adjacent in memory, so the column-mode load is coalesced whenever rpw >= 4.
         const int64_t nc = (int64_t)x.nos() * y.nos();
-        rowfft(cur, oth, z, tw[2].as<cplx<T>>(), ntrans, nc, (int64_t)z.na * nc, 1, nc);
+        rowfft(cur, oth, z, tw_cur[2], ntrans, nc, (int64_t)z.na * nc, 1, nc);
         std::swap(cur, oth);
     }
     grid_out = cur;
