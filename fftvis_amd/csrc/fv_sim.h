@@ -1542,12 +1542,8 @@ class Sim : public SimBase {
                 }
                 off.push_back((int64_t)all.size());
             }
-        // the eigenbeam contraction reads per-antenna coefficients by baseline: catalogue order (measured: no gain from (u, v) order)
-        struct Restore {
-            bool &b;
-            ~Restore() { b = true; }
-        } restore{order_pairs};
-        order_pairs = false;
+        // (u, v) order here too: redundant baselines are gathered once (build_unique) and only the contraction with the
+        // per-antenna coefficients runs per baseline
         set_beam_pairs((int)bi.size(), bi.data(), bj.data(), off.data(), all.data(), fl.data());
     }
 
