@@ -458,6 +458,16 @@ def main():
                     "share_of_step": tm_all["fft"] / total,
                     "algorithmic_bytes_per_step": fft_bytes,
                 }
+                # the same passes against the vector pipe (fp64 MFMA has the same peak on gfx950 and a dense DFT costs
+                # an order of magnitude more flops): flops priced as plain transforms, 5 n2 log2 n2 per line transformed
+                fl = st_all.get("fft_flops", 0.0)
+                if fl > 0:
+                    peak_tf = 78.6 if R8 == 8 else 157.3
+                    tfs = fl / (tm_all["fft"] * 1e-3) / 1e12
+                    fft["flops"] = {"bound": "valu", "achieved": tfs, "peak": peak_tf, "unit": "TFLOP/s", "frac": tfs / peak_tf,
+                                    "flops_per_step": fl,
+                                    "note": "vector fp%d peak of MI355X_MICROARCH.md; since the column plan the passes move a third "
+                                            "of the bytes they did and are bound by their instruction stream, not by HBM" % (8 * R8)}
             if tm_all["interp"] > 0 and a.path == "type3":
                 # gather at the targets: algorithmic bytes = w^d grid values per (target, transform[, mirror side])
                 # footprint + one output value per target and transform

@@ -465,22 +465,12 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
         rs0[r] = s0;
         rnc[r] = byl + r <= by ? s1 - s0 : 0;  // sources in the range
     }
-    const int nc0 = (rnc[0] + SPREAD_CHUNK - 1) / SPREAD_CHUNK, nc1 = (rnc[1] + SPREAD_CHUNK - 1) / SPREAD_CHUNK,
-              nc2 = (rnc[2] + SPREAD_CHUNK - 1) / SPREAD_CHUNK;
-    const int nct = nc0 + nc1 + nc2;
-    auto chunk_at = [&](int c, int &n) -> int {  // first source and size of chunk c (wave-uniform)
-        int r0 = rs0[0], len = rnc[0], k = c;
-        if (c >= nc0 + nc1) {
-            r0 = rs0[2];
-            len = rnc[2];
-            k = c - nc0 - nc1;
-        } else if (c >= nc0) {
-            r0 = rs0[1];
-            len = rnc[1];
-            k = c - nc0;
-        }
-        n = min(SPREAD_CHUNK, len - k * SPREAD_CHUNK);
-        return r0 + k * SPREAD_CHUNK;
+    // the sources of the <= 3 bin rows form ONE visit list (rows one after the other) cut into chunks of 16: separate
+    // lists made up to three short chunks per block, and the chunks are a serial chain of load round trips
+    const int L0 = rnc[0], L01 = rnc[0] + rnc[1], ntot = L01 + rnc[2];
+    const int nct = (ntot + SPREAD_CHUNK - 1) / SPREAD_CHUNK;
+    auto src_of = [&](int i) -> int {  // visit-list element i -> sorted source index
+        return i < L0 ? rs0[0] + i : i < L01 ? rs0[1] + (i - L0) : rs0[2] + (i - L01);
     };
     // a chunk travels global -> registers (requested one chunk ahead, so the loads fly while the
     // previous chunk is accumulated) -> the wave's LDS slice -> broadcast reads
@@ -489,31 +479,39 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
     cplx<T> ps[NS];
     T pkx[NW], pky[NW];
     int pix = 0, piy = 0;
-    auto request = [&](int base, int n) {
+    int wj[NW], wk[NW];  // weight element e = lane + 64 i of a chunk: slot e / w, tap e % w (the same for every chunk)
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int e = lane + 64 * i;
+        wj[i] = e / w;
+        wk[i] = e - wj[i] * w;
+    }
+    auto request = [&](int base, int n) {  // base: first visit-list element of the chunk
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int e = lane + 64 * i;
             ps[i] = {T(0), T(0)};
-            if (e < n * TCH) ps[i] = cs[(int64_t)(base + e / TCH) * ntrans + tbase + e % TCH];
+            if (e < n * TCH) ps[i] = cs[(int64_t)src_of(base + e / TCH) * ntrans + tbase + e % TCH];
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int e = lane + 64 * i;
             pkx[i] = pky[i] = T(0);
-            if (e < n * w) {  // rows of w weights are contiguous: element e of the chunk's block
-                pkx[i] = kwx[(int64_t)base * w + e];
-                pky[i] = kwy[(int64_t)base * w + e];
+            if (wj[i] < n) {
+                const int64_t at = (int64_t)src_of(base + wj[i]) * w + wk[i];
+                pkx[i] = kwx[at];
+                pky[i] = kwy[at];
             }
         }
         if (lane < n) {
-            pix = i0x[base + lane];
-            piy = i0y[base + lane];
+            const int sidx = src_of(base + lane);
+            pix = i0x[sidx];
+            piy = i0y[sidx];
         }
     };
     int n = 0, base = 0;
     if (nct > 0) {
-        base = chunk_at(0, n);
-        request(base, n);
+        n = min(SPREAD_CHUNK, ntot);
+        request(0, n);
     }
     for (int c = 0; c < nct; ++c) {
         // ---- registers -> LDS (wave-private slice; same-wave LDS ops stay in order) -----------
@@ -525,10 +523,9 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int e = lane + 64 * i;
-            if (e < n * w) {
-                const int j = e / w, k = e - j * w;
-                s_kw[wave][j][0][k] = pkx[i];
-                s_kw[wave][j][1][k] = pky[i];
+            if (wj[i] < n) {
+                s_kw[wave][wj[i]][0][wk[i]] = pkx[i];
+                s_kw[wave][wj[i]][1][wk[i]] = pky[i];
             }
         }
         if (lane < n) {
@@ -537,7 +534,8 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
         }
         const int ncur = n;
         if (c + 1 < nct) {
-            base = chunk_at(c + 1, n);
+            base = (c + 1) * SPREAD_CHUNK;
+            n = min(SPREAD_CHUNK, ntot - base);
             request(base, n);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -735,6 +733,191 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d_cg(
         const T f = fx * decy[cy0 + k];
 #pragma unroll
         for (int q = 0; q < CPL; ++q) o[q * plane + (int64_t)k * nax] = {ar[q][k] * f, ai[q][k] * f};
+    }
+}
+
+// --- 2-D spread as a small matrix product (fp64, TCH = 8 | 16, source-dense grids) ---------------------------
+// Same block / bin / chunk walk and staging as k_spread2d_cg; the accumulation is
+//     D[real r of the transforms][cell c] += sum_k  S[r][source k] * W[source k][cell c],     W = wx(c) wy(c),
+// on the matrix pipe: v_mfma_f64_16x16x4_f64 takes 16 reals (8 complex transforms) x 16 cells x 4 sources.  Same fp64
+// rate as the vector pipe -- the gain is operand traffic: the channel-group kernel reads 88 B of LDS per lane and
+// source visit (8 y weights, its strengths, an x weight; LDS returns bytes per lane whether or not the address is shared)
+// and is bound by exactly that at 10^6 sources; here a lane reads ONE strength real and forms ONE weight product per
+// (source, cell) -- 14 B per source visit -- and the instruction broadcasts them.  Operands (guide: A[l & 15][k = l >> 4],
+// B[k = l >> 4][l & 15], D[row = (l >> 4) + 4 reg][col = l & 15]): rows are mapped to (transform, re | im) so that
+// a lane's four results are the complex values of transforms 2 g and 2 g + 1 (g = l >> 4) of cell l & 15 -- 16-byte
+// stores, 8 lanes = one 128-byte row piece.  A block's 64 cells are four 16-cell tiles (two rows of 8) = four
+// independent accumulators in flight.  Sources beyond a chunk's count enter with zero strengths.
+#ifndef FV_SPREAD_MM_MINW8
+#define FV_SPREAD_MM_MINW8 4  // waves per SIMD the register allocation aims at (6 / 4 spill two dozen registers and lose:
+#define FV_SPREAD_MM_MINW16 3 // 0.55 against 0.37 ms per launch at 10^6 sources)
+#endif
+template <int TCH>
+__global__ __launch_bounds__(SPREAD_THREADS, TCH == 8 ? FV_SPREAD_MM_MINW8 : FV_SPREAD_MM_MINW16) void k_spread2d_mm(
+    int64_t M, const int *__restrict__ i0s_a, const double *__restrict__ kw_a,
+    const int *__restrict__ bin_start_a, const cplx<double> *__restrict__ cs_a, int ntrans, int tbegin,
+    const double *__restrict__ decx, const double *__restrict__ decy, cplx<double> *__restrict__ grid_a, int nax,
+    int nay, int nbx, int w, const int *__restrict__ order, int nchunk, SpreadMate mate) {
+    using T = double;
+    using d4 = double __attribute__((ext_vector_type(4)));
+    const int *__restrict__ i0s = blockIdx.y ? mate.i0s : i0s_a;
+    const T *__restrict__ kw = blockIdx.y ? static_cast<const T *>(mate.kw) : kw_a;
+    const int *__restrict__ bin_start = blockIdx.y ? mate.bin_start : bin_start_a;
+    const cplx<T> *__restrict__ cs = blockIdx.y ? static_cast<const cplx<T> *>(mate.cs) : cs_a;
+    cplx<T> *__restrict__ grid = blockIdx.y ? static_cast<cplx<T> *>(mate.grid) : grid_a;
+    static_assert(TCH == 8 || TCH == 16, "8 transforms per 16-row operand tile");
+    constexpr int MT = TCH / 8;  // operand tiles of 16 reals
+    __shared__ T s_sr[SPREAD_THREADS / 64][SPREAD_CHUNK][MT * 16];
+    __shared__ T s_kwx[SPREAD_THREADS / 64][SPREAD_CHUNK][MAX_W];
+    __shared__ T s_kwy[SPREAD_THREADS / 64][SPREAD_CHUNK][MAX_W];
+    __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int og = order[blockIdx.x / nchunk];
+    const int bx = (og & 0xffff) * 4 + wave, by = og >> 16;
+    if (bx >= nbx) return;  // wave-uniform
+    const int tbase = tbegin + (blockIdx.x % nchunk) * TCH;
+    const int g = lane >> 4;                                           // operand k index / result row group
+    const int cx = (bx << BINLOG) + (lane & 7), cy0 = (by << BINLOG) + ((lane >> 3) & 1);  // cell of tile t: (cx, cy0 + 2 t)
+    const int *i0x = i0s, *i0y = i0s + M;
+    const T *kwx = kw, *kwy = kw + M * w;
+    d4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = d4{0.0, 0.0, 0.0, 0.0};
+    const int bxl = max((bx << BINLOG) - w + 1, 0) >> BINLOG;
+    const int byl = max((by << BINLOG) - w + 1, 0) >> BINLOG;
+    int rs0[3], rnc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yb = min(byl + r, by);
+        const int s0 = bin_start[yb * nbx + bxl], s1 = bin_start[yb * nbx + bx + 1];
+        rs0[r] = s0;
+        rnc[r] = byl + r <= by ? s1 - s0 : 0;
+    }
+    // The sources of the <= 3 bin rows form ONE visit list (rows one after the other) cut into chunks of 16: at a few
+    // sources per bin three separate lists made two or three half-empty chunks per block, and the chunks are a serial
+    // chain of load round trips (the kernel is bound by that latency at 10^6 sources, not by its arithmetic).
+    const int L0 = rnc[0], L01 = rnc[0] + rnc[1], ntot = L01 + rnc[2];
+    const int nct = (ntot + SPREAD_CHUNK - 1) / SPREAD_CHUNK;
+    auto src_of = [&](int i) -> int {  // visit-list element i -> sorted source index
+        return i < L0 ? rs0[0] + i : i < L01 ? rs0[1] + (i - L0) : rs0[2] + (i - L01);
+    };
+    // weights and origins of slots a short chunk leaves untouched must be finite and in range from the start
+    // (their strengths are zero; 0 x NaN would not be)
+    if (nct > 0) {
+        for (int e = lane; e < SPREAD_CHUNK * MAX_W; e += 64) {
+            (&s_kwx[wave][0][0])[e] = T(0);
+            (&s_kwy[wave][0][0])[e] = T(0);
+        }
+        if (lane < SPREAD_CHUNK * 2) (&s_i0[wave][0][0])[lane] = 0;
+    }
+    constexpr int NS = TCH / 4;                      // strengths per lane: 16 TCH / 64
+    constexpr int NW = (SPREAD_CHUNK * MAX_W) / 64;  // weights per lane and dimension
+    cplx<T> ps[NS];
+    T pkx[NW], pky[NW];
+    int pix = 0, piy = 0;
+    int wj[NW], wk[NW];  // weight element e = lane + 64 i of a chunk: slot e / w, tap e % w (the same for every chunk)
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int e = lane + 64 * i;
+        wj[i] = e / w;
+        wk[i] = e - wj[i] * w;
+    }
+    auto request = [&](int base, int n) {  // base: first visit-list element of the chunk
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int e = lane + 64 * i;
+            ps[i] = {T(0), T(0)};
+            if (e < n * TCH) ps[i] = cs[(int64_t)src_of(base + e / TCH) * ntrans + tbase + e % TCH];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            pkx[i] = pky[i] = T(0);
+            if (wj[i] < n) {
+                const int64_t at = (int64_t)src_of(base + wj[i]) * w + wk[i];
+                pkx[i] = kwx[at];
+                pky[i] = kwy[at];
+            }
+        }
+        if (lane < n) {
+            const int sidx = src_of(base + lane);
+            pix = i0x[sidx];
+            piy = i0y[sidx];
+        }
+    };
+    int n = 0, base = 0;
+    if (nct > 0) {
+        n = min(SPREAD_CHUNK, ntot);
+        request(0, n);
+    }
+    for (int c = 0; c < nct; ++c) {
+        // ---- registers -> LDS: every slot's strengths (zeros beyond the chunk's count), this chunk's weights ------
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int e = lane + 64 * i;  // (source j, transform tq) of the chunk, zero beyond n
+            const int j = e / TCH, tq = e % TCH;
+            // operand row of (transform, part): tile tq / 8, row (tq' / 2) + 4 (2 (tq' % 2) + part), tq' = tq % 8
+            const int row = (tq >> 3) * 16 + ((tq & 7) >> 1) + 8 * (tq & 1);
+            s_sr[wave][j][row] = ps[i].re;
+            s_sr[wave][j][row + 4] = ps[i].im;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = lane + 64 * i;
+            if (wj[i] < n) {
+                s_kwx[wave][wj[i]][wk[i]] = pkx[i];
+                s_kwy[wave][wj[i]][wk[i]] = pky[i];
+            }
+        }
+        if (lane < n) {
+            s_i0[wave][lane][0] = pix;
+            s_i0[wave][lane][1] = piy;
+        }
+        const int ncur = n;
+        if (c + 1 < nct) {
+            base = (c + 1) * SPREAD_CHUNK;
+            n = min(SPREAD_CHUNK, ntot - base);
+            request(base, n);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- four sources per instruction ------------------------------------------------------------------
+        const int nq = (ncur + 3) >> 2;
+        for (int q = 0; q < nq; ++q) {
+            const int sj = 4 * q + g;  // this lane's source of the k dimension (slots beyond ncur: zero strengths)
+            const int dx = cx - s_i0[wave][sj][0], dy0 = cy0 - s_i0[wave][sj][1];
+            const T wx = (unsigned)dx < (unsigned)w ? s_kwx[wave][sj][dx] : T(0);
+            T a[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = s_sr[wave][sj][m * 16 + (lane & 15)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int dy = dy0 + 2 * t;
+                const T b = (unsigned)dy < (unsigned)w ? wx * s_kwy[wave][sj][dy] : T(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next chunk
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // results: lane (g, cell) holds transforms 2 g, 2 g + 1 of every operand tile as (re, im) pairs
+    const T fx = decx[cx];
+    const int64_t plane = (int64_t)nay * nax;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int cy = cy0 + 2 * t;
+        const T f = fx * decy[cy];
+        cplx<T> *o = grid + (int64_t)tbase * plane + (int64_t)cy * nax + cx;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            o[(int64_t)(m * 8 + 2 * g) * plane] = {acc[m][t][0] * f, acc[m][t][1] * f};
+            o[(int64_t)(m * 8 + 2 * g + 1) * plane] = {acc[m][t][2] * f, acc[m][t][3] * f};
+        }
     }
 }
 
@@ -2814,6 +2997,16 @@ class Nufft3 {
         return ok;
     }
     double fft_traffic_cells() const;  // cells read + written by all FFT passes, per transform
+    // real flops of the passes per transform, priced as plain radix-2 transforms: 5 n2 log2(n2) per line transformed
+    // (x-pass: na_y lines, y-pass: the columns kept; 3-D adds the z lines) -- what the pruned passes replace
+    double fft_flops() const {
+        const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
+        const double zin = dim > 2 ? z.na : 1;
+        auto f = [](const DimGeom &g) { return 5.0 * g.n2 * std::log2((double)g.n2); };
+        double c = zin * y.na * f(x) + zin * (double)xcols() * f(y);
+        if (dim > 2) c += (double)x.nos() * y.nos() * f(z);
+        return c;
+    }
     int64_t spread_cells() const { return dim == 2 ? order_cells : geo.cells_a(); }  // cells of A the spread writes, per transform
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
     // index list / flip flags of length N, per-group scale (device, nfg doubles).
@@ -2859,8 +3052,14 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
         const char *force_cell = std::getenv("FFTVIS_HIP_SPREAD_CELL");
         const bool dense = (double)M >= 3.0 * (double)geo.nbin[0] * (double)geo.nbin[1];
         auto kern = k_spread2d<T, TCH>;
-        if constexpr (TCH >= 8)
+        if constexpr (TCH >= 8) {
             if (force_cell ? std::atoi(force_cell) == 0 : dense) kern = k_spread2d_cg<T, TCH>;
+            // fp64 on source-dense grids: the accumulation as a matrix product (FFTVIS_HIP_SPREAD_MM = 0: channel groups)
+            if constexpr (sizeof(T) == 8) {
+                const char *emm = std::getenv("FFTVIS_HIP_SPREAD_MM");
+                if (emm ? std::atoi(emm) != 0 : (dense && !force_cell)) kern = k_spread2d_mm<TCH>;
+            }
+        }
         hipExtLaunchKernelGGL(kern, g, dim3(SPREAD_THREADS), 0, stream, es, ee, 0, M,
                               (const int *)i0s.as<int>(), (const T *)kw.as<T>(),
                               (const int *)bin_start.as<int>(),

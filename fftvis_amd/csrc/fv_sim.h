@@ -1064,7 +1064,7 @@ class Sim : public SimBase {
     std::vector<std::pair<int, double>> mhist_log;  // (time index, transforms spread) per processed time
 
     // stats / timing
-    double st[12] = {0};
+    double st[16] = {0};
     int timing_level = 0;  // 1: spread only, sampled (events ride on the dispatches); 3: the same on every spread launch; 2: every kernel family
     int64_t targets_serial = 1;  // version of the device-side target data (baselines, frequencies, pair lists)
     struct Ev {
@@ -2428,6 +2428,7 @@ class Sim : public SimBase {
                     }
                     ev_end(e4, ls);
                     st[3] += nufft->fft_traffic_cells() * ntrans * nm;
+                    st[12] += nufft->fft_flops() * ntrans * nm;
                     RoctxRange rg("gather");
                     size_t e5 = ev_begin(TM_INTERP, ls);
                     BasisTerm bt{d_coefs.p, d_ant1.as<int>(), d_ant2.as<int>(), pr.bi, pr.bj, nbasis,
@@ -2597,7 +2598,7 @@ class Sim : public SimBase {
     }
     void stats(double *v, int n) override {
         fold_mhist();
-        for (int i = 0; i < n && i < 12; ++i) v[i] = st[i];
+        for (int i = 0; i < n && i < 16; ++i) v[i] = st[i];
     }
     void reset_stats() override {
         for (double &x : st) x = 0;

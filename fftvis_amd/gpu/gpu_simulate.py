@@ -206,10 +206,10 @@ class SimHandle:
         _lib.check(self._L.fv_sim_sync(self._h))
 
     def stats(self):
-        v = np.zeros(12)
-        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 12))
+        v = np.zeros(13)
+        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 13))
         keys = ["spread_launches", "spread_cells", "source_visits", "fft_cells", "interp_items",
-                "sources_above_horizon", "n2x", "n2y", "n2z", "w", "upsample_used", "max_above_horizon"]
+                "sources_above_horizon", "n2x", "n2y", "n2z", "w", "upsample_used", "max_above_horizon", "fft_flops"]
         return dict(zip(keys, v))
 
     def reset_stats(self):

@@ -36,15 +36,16 @@ def shard_blocks(world: int, nfreqs: int, ntimes: int):
     return blocks
 
 
-def slice_cost(freqs, fixed: float = 0.1, power: float = 2.4) -> np.ndarray:
+def slice_cost(freqs, fixed: float = 0.1, power: float = 2.0) -> np.ndarray:
     """Relative cost of one (time, channel) slice on the GPU engine: the fine grid has
     ~(2 sigma b_max nu / c)^2 cells, and spread output, FFT passes and gather input all scale with
-    it (HERA's 100-200 MHz band: the top channel costs > 4x the bottom one); ``fixed`` (in units of
+    it (HERA's 100-200 MHz band: the top channel costs 4x the bottom one); ``fixed`` (in units of
     the top channel's grid cost) stands for the per-slice work that does not.  The exponent is
-    measured, not 2: FFT lengths step (n2 = 5120 ... 10240 on HERA-350) and the longer rows fold more
-    residues -- with nu^2 the two frequency parts of an 8-rank C3 job, 81 and 47 channels, ran 226 and
-    247 ms per step on the same GPU (``bench.py --as-rank R --of-ranks 8``); nu^2.4 calls that split
-    1.09 : 1, as measured."""
+    measured (``bench.py --as-rank R --of-ranks 8``: the two frequency parts of an 8-rank job on the
+    same GPU).  Round 2's passes wanted nu^2.4 (FFT lengths step, the longer rows fold more residues);
+    since the column plan and the source disc of round 3 the y-pass and the stores no longer follow
+    the FFT length, and with 2.4 the parts of C3 (cut at channel 83) ran 120.2 and 110.1 ms, those of
+    C4 (cut at 164) 862 and 787 ms: both 1.09 : 1 -- what plain nu^2 with the same ``fixed`` predicts."""
     f = np.abs(np.asarray(freqs, dtype=float))
     return (f / f.max()) ** power + fixed
 

@@ -230,7 +230,8 @@ int fv_sim_sync(fv_sim *h);
  * [2] source x trans visits, [3] cells moved through HBM by the pruned FFT passes,
  * [4] gathered footprints (targets x transforms, x 2 for packed transforms: read at s and -s), [5] above-horizon sources summed over times, [6] last n2x,
  * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w, [10] upsampling factor the
- * last run used, [11] largest above-horizon source count of any time step since the reset.   */
+ * last run used, [11] largest above-horizon source count of any time step since the reset, [12] real flops of the FFT
+ * passes priced as plain transforms (5 n2 log2 n2 per line transformed).   */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,

@@ -50,12 +50,17 @@ def test_nufft2d_upsample_1p25(gpu, eps):
     assert rel_l2(gpu_nufft2d(x, y, c, s, t, eps, upsample_factor=1.25), ex) < 10 * eps
 
 
-@pytest.mark.parametrize("cell", ["0", "1"])
+@pytest.mark.parametrize("cell", ["0", "1", "mm"])
 def test_nufft2d_both_spread_lane_mappings(gpu, cell, monkeypatch):
-    """The 2-D spread has two lane mappings (lane per cell; lane per (x cell, channel group) for chunks
-    of >= 8 transforms) chosen by source density: force each one over kernel widths 2..16, transform
-    counts that mix 16-, 8- and smaller chunks, clustered sources (many chunks per block) and fp32."""
-    monkeypatch.setenv("FFTVIS_HIP_SPREAD_CELL", cell)
+    """The 2-D spread has three accumulation schemes chosen by source density and precision (lane per cell; lane per
+    (x cell, channel group) for chunks of >= 8 transforms; fp64 chunks of 8 / 16 transforms as a matrix product on the
+    MFMA pipe, k_spread2d_mm): force each one over kernel widths 2..16, transform counts that mix 16-, 8- and
+    smaller chunks, clustered sources (many chunks per block, short last chunks) and fp32."""
+    if cell == "mm":
+        monkeypatch.setenv("FFTVIS_HIP_SPREAD_MM", "1")
+    else:
+        monkeypatch.setenv("FFTVIS_HIP_SPREAD_MM", "0")
+        monkeypatch.setenv("FFTVIS_HIP_SPREAD_CELL", cell)
     for eps, ntr, seed in ((1e-1, 8, 0), (1e-4, 24, 1), (6e-8, 19, 2), (1e-11, 16, 3), (1e-14, 9, 4)):
         x, y, c, s, t = _problem(4000, 300, 40.0, ntr, seed=seed)
         x[:1500] = x[0] + 1e-3 * (x[:1500] - x[0])  # a dense cluster: > 16 sources in one bin
