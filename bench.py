@@ -400,6 +400,10 @@ def main():
             nax, nay = int(st["n2z"]) // 65536, int(st["n2z"]) % 65536
             if os.environ.get("FFTVIS_HIP_SPREAD_CELL") == "0" or nsrc >= 3 * ((nax + 7) // 8) * ((nay + 7) // 8):
                 spread_kernel = "k_spread2d_cg"
+                # ... and in fp64 the same walk with the accumulation on the matrix pipe (k_spread2d_mm)
+                mm = os.environ.get("FFTVIS_HIP_SPREAD_MM")
+                if R8 == 8 and (mm != "0" if mm is not None else "FFTVIS_HIP_SPREAD_CELL" not in os.environ):
+                    spread_kernel = "k_spread2d_mm"
         if a.path == "type1" and breakdown:
             # lattice path: every (source, channel) pair is an entry with its own origin and 2 w
             # weights; timed in the extra step (event records around the launch)
