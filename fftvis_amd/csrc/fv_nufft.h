@@ -1005,6 +1005,90 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
 // stride-16 middle pass and the stride-256 digit-reversed read-out all spread over the banks.
 __host__ __device__ inline int fft_pidx(int i) { return i + (i >> 4) + (i >> 8); }
 
+// Complex arithmetic of the FFT passes.  fp64: plain expressions.  fp32 (FV_PK_F32, default on): one complex value =
+// one even-aligned VGPR pair and every operation a packed instruction -- v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with
+// the op_sel / neg modifiers doing the swizzles of a complex product (a.re w, then +- a.im (w.im, w.re)) and of a
+// multiplication by i for free.  Scalar fp32 issues at the fp64 rate on gfx950 (16 lanes per clock; the 157 TF vector
+// peak is the packed rate), so the fp32 passes cost what the fp64 ones do unless they are packed; the compiler packs the
+// additions by itself but moves the halves around for every product (490 v_mov per thread when tried), hence the
+// inline assembly for the products.  A radix-16 butterfly: 84 packed instructions instead of 168 scalar ones.
+#ifndef FV_PK_F32
+#define FV_PK_F32 1
+#endif
+using f2v = float __attribute__((ext_vector_type(2)));
+template <typename T>
+struct PkF32 {
+    static constexpr bool on = false;
+};
+template <>
+struct PkF32<float> {
+    static constexpr bool on = FV_PK_F32 != 0;
+};
+__device__ inline cplx<float> pk_add(cplx<float> a, cplx<float> b) {
+    return __builtin_bit_cast(cplx<float>, __builtin_bit_cast(f2v, a) + __builtin_bit_cast(f2v, b));
+}
+__device__ inline cplx<float> pk_sub(cplx<float> a, cplx<float> b) {
+    return __builtin_bit_cast(cplx<float>, __builtin_bit_cast(f2v, a) - __builtin_bit_cast(f2v, b));
+}
+__device__ inline cplx<float> pk_isub(cplx<float> a, cplx<float> b) {  // i (a - b)
+    f2v r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,1]"
+        : "=v"(r)
+        : "v"(__builtin_bit_cast(f2v, a)), "v"(__builtin_bit_cast(f2v, b)));
+    return __builtin_bit_cast(cplx<float>, r);
+}
+__device__ inline cplx<float> pk_mul(cplx<float> a, cplx<float> w) {  // a w
+    const f2v av = __builtin_bit_cast(f2v, a), wv = __builtin_bit_cast(f2v, w);
+    f2v t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(wv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(wv), "v"(t));
+    return __builtin_bit_cast(cplx<float>, r);
+}
+__device__ inline cplx<float> pk_mul_s(cplx<float> a, cplx<float> w) {  // a w, w wave-uniform (scalar registers)
+    const f2v av = __builtin_bit_cast(f2v, a), wv = __builtin_bit_cast(f2v, w);
+    f2v t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "s"(wv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "s"(wv), "v"(t));
+    return __builtin_bit_cast(cplx<float>, r);
+}
+__device__ inline cplx<float> pk_mac(cplx<float> acc, cplx<float> a, cplx<float> w) {  // acc + a w
+    const f2v av = __builtin_bit_cast(f2v, a), wv = __builtin_bit_cast(f2v, w);
+    f2v t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(av), "v"(wv), "v"(__builtin_bit_cast(f2v, acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(wv), "v"(t));
+    return __builtin_bit_cast(cplx<float>, r);
+}
+__device__ inline cplx<float> pk_mac_s(cplx<float> acc, cplx<float> a, cplx<float> w) {  // acc + a w, w wave-uniform
+    const f2v av = __builtin_bit_cast(f2v, a), wv = __builtin_bit_cast(f2v, w);
+    f2v t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(av), "s"(wv), "v"(__builtin_bit_cast(f2v, acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "s"(wv), "v"(t));
+    return __builtin_bit_cast(cplx<float>, r);
+}
+// the passes' products and multiply-adds: packed in fp32, plain otherwise (_u: the factor is wave-uniform -- it stays in
+// scalar registers instead of being copied into a vector pair)
+template <typename T>
+__device__ inline cplx<T> xmul(cplx<T> a, cplx<T> w) {
+    if constexpr (PkF32<T>::on)
+        return pk_mul(a, w);
+    else
+        return cmul(a, w);
+}
+template <typename T>
+__device__ inline cplx<T> xmul_u(cplx<T> a, cplx<T> w) {
+    if constexpr (PkF32<T>::on)
+        return pk_mul_s(a, w);
+    else
+        return cmul(a, w);
+}
+template <typename T>
+__device__ inline cplx<T> xmac(cplx<T> acc, cplx<T> a, cplx<T> w) {
+    if constexpr (PkF32<T>::on)
+        return pk_mac(acc, a, w);
+    else
+        return {acc.re + (a.re * w.re - a.im * w.im), acc.im + (a.re * w.im + a.im * w.re)};
+}
+
 template <typename T>
 __device__ inline cplx<T> cmul_root16(cplx<T> d, int k) {  // d * exp(+2 pi i k / 16), 0 <= k < 8
     constexpr T C1 = T(0.92387953251128675613), S1 = T(0.38268343236508977173),
@@ -1029,8 +1113,27 @@ __device__ inline void dif_regs(cplx<T> *v) {
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             const cplx<T> a = v[k], b = v[k + H];
-            v[k] = {a.re + b.re, a.im + b.im};
-            v[k + H] = cmul_root16<T>(cplx<T>{a.re - b.re, a.im - b.im}, k * (16 / R));
+            if constexpr (PkF32<T>::on) {
+                constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, HH = 0.70710678118654752440f;
+                const int kk = k * (16 / R);  // compile-time after unrolling: d exp(+2 pi i kk / 16), d = a - b
+                v[k] = pk_add(a, b);
+                if (kk == 0)
+                    v[k + H] = pk_sub(a, b);
+                else if (kk == 4)
+                    v[k + H] = pk_isub(a, b);  // the rotation rides on the subtraction
+                else {
+                    const cplx<float> wr = kk == 1   ? cplx<float>{C1, S1}
+                                           : kk == 2 ? cplx<float>{HH, HH}
+                                           : kk == 3 ? cplx<float>{S1, C1}
+                                           : kk == 5 ? cplx<float>{-S1, C1}
+                                           : kk == 6 ? cplx<float>{-HH, HH}
+                                                     : cplx<float>{-C1, S1};
+                    v[k + H] = pk_mul_s(pk_sub(a, b), wr);
+                }
+            } else {
+                v[k] = {a.re + b.re, a.im + b.im};
+                v[k + H] = cmul_root16<T>(cplx<T>{a.re - b.re, a.im - b.im}, k * (16 / R));
+            }
         }
         dif_regs<T, H>(v);
         dif_regs<T, H>(v + H);
@@ -1361,8 +1464,8 @@ __device__ inline void st_twiddle(cplx<T> *v, cplx<T> w) {
     cplx<T> wk = w;
 #pragma unroll
     for (int k = 1; k < R; ++k) {
-        v[bitrev_small(k, LR)] = cmul(v[bitrev_small(k, LR)], wk);
-        if (k + 1 < R) wk = cmul(wk, w);
+        v[bitrev_small(k, LR)] = xmul(v[bitrev_small(k, LR)], wk);
+        if (k + 1 < R) wk = xmul(wk, w);
     }
 }
 
@@ -1375,8 +1478,8 @@ __device__ inline void st_twiddle_from(cplx<T> *v, cplx<T> start, cplx<T> w) {
     cplx<T> wk = start;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        v[bitrev_small(k, LR)] = cmul(v[bitrev_small(k, LR)], wk);
-        if (k + 1 < R) wk = cmul(wk, w);
+        v[bitrev_small(k, LR)] = xmul(v[bitrev_small(k, LR)], wk);
+        if (k + 1 < R) wk = xmul(wk, w);
     }
 }
 __device__ inline int mul24(int a, int b) { return (int)__mul24(a, b); }  // both factors below 2^23: full-rate multiply
@@ -1688,18 +1791,23 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                     mpo = mod_p(mpo + mod_p(p_other));
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
-                        mine[hh + j].re += x[t][j].re * cm.re - x[t][j].im * cm.im;
-                        mine[hh + j].im += x[t][j].re * cm.im + x[t][j].im * cm.re;
-                        theirs[hh + j].re += x[t][j].re * co.re - x[t][j].im * co.im;
-                        theirs[hh + j].im += x[t][j].re * co.im + x[t][j].im * co.re;
+                        if constexpr (PkF32<T>::on) {
+                            mine[hh + j] = pk_mac_s(mine[hh + j], x[t][j], cm);
+                            theirs[hh + j] = pk_mac_s(theirs[hh + j], x[t][j], co);
+                        } else {
+                            mine[hh + j].re += x[t][j].re * cm.re - x[t][j].im * cm.im;
+                            mine[hh + j].im += x[t][j].re * cm.im + x[t][j].im * cm.re;
+                            theirs[hh + j].re += x[t][j].re * co.re - x[t][j].im * co.im;
+                            theirs[hh + j].im += x[t][j].re * co.im + x[t][j].im * co.re;
+                        }
                     }
                 }
             }
             // the uniform part of the slot twiddle, w^{k S1 p}, k = h + j (k S1 p < n2 also for p = P)
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                mine[hh + j] = cmul(mine[hh + j], tw[(h + j) * S1 * p]);
-                theirs[hh + j] = cmul(theirs[hh + j], tw[(h + j) * S1 * p_other]);
+                mine[hh + j] = xmul_u(mine[hh + j], tw[(h + j) * S1 * p]);
+                theirs[hh + j] = xmul_u(theirs[hh + j], tw[(h + j) * S1 * p_other]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1768,14 +1876,22 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                     const cplx<T> cm = tw[mp * Q];
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
-                        acc[j].re += xs[j].re * cm.re - xs[j].im * cm.im;
-                        acc[j].im += xs[j].re * cm.im + xs[j].im * cm.re;
+                        if constexpr (PkF32<T>::on) {
+                            acc[j] = pk_mac_s(acc[j], xs[j], cm);
+                        } else {
+                            acc[j].re += xs[j].re * cm.re - xs[j].im * cm.im;
+                            acc[j].im += xs[j].re * cm.im + xs[j].im * cm.re;
+                        }
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
-                        acc[j].re += xs[j].re;
-                        acc[j].im += xs[j].im;
+                        if constexpr (PkF32<T>::on) {
+                            acc[j] = pk_add(acc[j], xs[j]);
+                        } else {
+                            acc[j].re += xs[j].re;
+                            acc[j].im += xs[j].im;
+                        }
                     }
                 }
             };
@@ -1794,7 +1910,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                 // the uniform part of the slot twiddle, w^{k S1 p} (k = 0: one)
 #pragma unroll
                 for (int j = 0; j < CH; ++j)
-                    if (h + j) acc[j] = cmul(acc[j], tw[(h + j) * S1 * p]);  // k S1 p < n2
+                    if (h + j) acc[j] = xmul_u(acc[j], tw[(h + j) * S1 * p]);  // k S1 p < n2
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j) va[h + j] = acc[j];
@@ -1833,9 +1949,9 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                     const cplx<T> f = tw[jr * S1 * p];
                     const cplx<T> fc = cmul(f, cplx<T>{cq.re, -cq.im});
                     if (NLD == R1)
-                        va[jr] = cmul(va[jr], cplx<T>{hi ? fc.re : f.re, hi ? fc.im : f.im});
+                        va[jr] = xmul(va[jr], cplx<T>{hi ? fc.re : f.re, hi ? fc.im : f.im});
                     else
-                        va[jr] = cmul(va[jr], i >= NH ? fc : f);
+                        va[jr] = xmul(va[jr], i >= NH ? fc : f);
                 }
             }
         } else {
@@ -1863,9 +1979,9 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                         const cplx<T> f = tw[jr * S1 * p];
                         const cplx<T> fc = cmul(f, cplx<T>{cq.re, -cq.im});
                         if (NLD == R1)
-                            x[j] = cmul(x[j], cplx<T>{his[j] ? fc.re : f.re, his[j] ? fc.im : f.im});
+                            x[j] = xmul(x[j], cplx<T>{his[j] ? fc.re : f.re, his[j] ? fc.im : f.im});
                         else
-                            x[j] = cmul(x[j], h + j >= NH ? fc : f);
+                            x[j] = xmul(x[j], h + j >= NH ? fc : f);
                     }
                 }
     #pragma unroll
