@@ -1210,7 +1210,8 @@ struct RowDifArgs {
     const void *in1;  // gang launch (grid.y = 2): input / output of the second, identically shaped problem
     void *out1;
     // Column plan (row mode, blocked output; see Nufft3::arm_columns): ctab[(plane / ctab_tpol) ctab_stride + position]
-    // = 1 + the COMPACT column an output position is stored at, 0 = no target's footprint reads that column: not stored.
+    // = 1 + the ELEMENT INDEX, inside a row's blocked output, of the compact column an output position is stored at
+    // ((c >> b) (rows << b) + (c & (2^b - 1)) for compact column c), 0 = no target's footprint reads that column: not stored.
     const int *ctab;
     int ctab_stride, ctab_tpol;
     // Row extents (row mode, first pass of a 2-D transform whose sources lie in a disc; Nufft3::disc_radius): the input
@@ -2133,19 +2134,19 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     bool use_ctab = false;
     int ct[NI3][R3];
     if constexpr (!COL && !FUSED) {
-        use_ctab = out_blocked && a.ctab != nullptr;
+        use_ctab = out_blocked && a.ctab != nullptr && ostep == 1;
         if (use_ctab) {
-            const int *trow = wave_uniform_ptr(a.ctab + (int64_t)__builtin_amdgcn_readfirstlane((int)(rplane / a.ctab_tpol)) * a.ctab_stride);
-            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(trow), 0, (uint32_t)a.ctab_stride * 4u, 0x00020000);
+            // a descriptor over exactly this residue's run of the table row: entry `rel` of the run, and zero -- "not
+            // stored" -- for the outputs beyond it, without a compare (negative rel wraps past the extent)
+            const int *trow = wave_uniform_ptr(a.ctab + (int64_t)__builtin_amdgcn_readfirstlane((int)(rplane / a.ctab_tpol)) * a.ctab_stride +
+                                               __builtin_amdgcn_readfirstlane(res0));
+            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(trow), 0, (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_len) * 4u, 0x00020000);
 #pragma unroll
             for (int i = 0; i < NI3; ++i) {
-                const int v = u + i * TPR;
+                const int rel0 = (u + i * TPR - ks_lo) * 4;
 #pragma unroll
-                for (int k = 0; k < R3; ++k) {
-                    const int rel = (v - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
-                    const int pos = res0 + mul24(rel, ostep);
-                    ct[i][k] = __builtin_amdgcn_raw_buffer_load_b32(trs, (unsigned)rel < blk_len ? (uint32_t)pos * 4u : 0xfffffffcu, 0, 0);
-                }
+                for (int k = 0; k < R3; ++k)
+                    ct[i][k] = __builtin_amdgcn_raw_buffer_load_b32(trs, (uint32_t)(rel0 + (k * (Q / R3) - (k >= R3 / 2 ? Q : 0)) * 4), 0, 0);
             }
         }
     }
@@ -2189,8 +2190,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                     // uniform constants -- two adds, a compare and a select per store
                     const int rel = (v - ks_lo) + k * (Q / R3) - (k >= R3 / 2 ? Q : 0);
                     if (use_ctab) {  // uniform: compact columns, only those a target reads
-                        const int t = ct[i][k];
-                        rowout.store(t ? mul24((t - 1) >> a.out_blk, blk_rows) + ((t - 1) & blk_mask) : -1, vc[i][bitrev_small(k, L3)]);
+                        rowout.store(ct[i][k] - 1, vc[i][bitrev_small(k, L3)]);  // 0: index -1, dropped by the range check
                         continue;
                     }
                     const int pos0 = res0 + mul24(v - ks_lo, ostep);
@@ -2673,7 +2673,8 @@ class Nufft3 {
     // table.  col_tab[fg * x.nos() + position] = 1 + compact column | 0 (device; built by the caller from its targets,
     // per frequency of the group: tpol transforms share an entry), col_ncc = compact columns (largest over the
     // frequencies).  Armed by the caller before fft(); nullptr = every column.
-    const int *col_tab = nullptr;
+    const int *col_tab = nullptr;   // the gather's view: 1 + compact column
+    const int *col_xtab = nullptr;  // the x-pass's view: 1 + element index inside a row's blocked output (RowDifArgs::ctab)
     int col_tab_tpol = 1, col_ncc = 0;
     const int *first_pass_ext = nullptr;  // RowDifArgs::row_ext of the rowfft call in flight (fft())
     double grid_slack = -1.0;
@@ -2695,9 +2696,10 @@ class Nufft3 {
     const unsigned long long *col_omask = nullptr;  // RowDifArgs::omask of the y-pass (k_plan_rowmask), or nullptr
     int col_omask_nblk = 0;
     double col_out_cells = 0;  // cells of C per transform the masked y-pass stores (0: all)
-    void arm_columns(const int *tab, int tpol, int ncc, int *err = nullptr, const unsigned long long *omask = nullptr,
+    void arm_columns(const int *tab, const int *xtab, int tpol, int ncc, int *err = nullptr, const unsigned long long *omask = nullptr,
                      int omask_nblk = 0) {
-        col_tab = tab && dim == 2 && b_block_log() ? tab : nullptr;
+        col_tab = tab && xtab && dim == 2 && b_block_log() ? tab : nullptr;
+        col_xtab = col_tab ? xtab : nullptr;
         col_tab_tpol = tpol;
         col_ncc = ncc;
         col_err = err;
@@ -2732,6 +2734,7 @@ class Nufft3 {
                            flip, ustart, scale_dev, a, ctab, mask);
     }
     int xcols() const { return col_tab ? col_ncc : geo.d[0].nos(); }  // columns of B / rows of C per transform
+    int b_block_log_public() const { return b_block_log(); }
     bool columns_possible() const { return dim == 2 && b_block_log() != 0 && y_reads_columns() && !fused_possible(); }
     bool fused_possible() const;
     // Arms the fused gather for the next fft() (which then leaves no grid for interp()); false when the
@@ -3322,7 +3325,7 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     }
     if (first_pass_ext) a.row_ext = first_pass_ext;  // (row mode, register-resident kernels: fft() only sets it there)
     if (out_blk && col_tab) {  // the x-pass of a column plan
-        a.ctab = col_tab;
+        a.ctab = col_xtab;
         a.ctab_stride = g.nos();
         a.ctab_tpol = col_tab_tpol;
     }

@@ -1429,7 +1429,8 @@ class Sim : public SimBase {
         int pair, fa, fb, nos, sP, cnt, n2, no, w;
         double h, btc;
         bool both;
-        DevBuf tab;
+        DevBuf tab, xtab;  // the gather's table (1 + compact column) and the x-pass's (1 + element index of that column)
+        int yna = 0, blk = 0;
         int ncc = 0;
         bool use = false;
         // y-pass output mask (k_plan_rowmask): which 16-output chunks of each (column block, residue) hold a footprint row
@@ -1449,7 +1450,7 @@ class Sim : public SimBase {
             if (c->serial == targets_serial && c->pair == pi && c->fa == fa && c->fb == fb && c->nos == x.nos() &&
                 c->sP == x.sP() && c->cnt == x.cnt() && c->n2 == x.n2 && c->no == x.no && c->w == w && c->h == x.h &&
                 c->btc == x.btc && c->both == both && c->yn2 == y.n2 && c->yno == y.no && c->yP == y.P && c->yQ == y.Q &&
-                c->yh == y.h && c->ybtc == y.btc)
+                c->yh == y.h && c->ybtc == y.btc && c->yna == y.na && c->blk == n0->b_block_log_public())
                 return c.get();
         if (col_plans.size() > 512) col_plans.clear();  // stale versions of earlier target sets
         std::unique_ptr<ColPlan> c(new ColPlan{targets_serial, pi, fa, fb, x.nos(), x.sP(), x.cnt(), x.n2, x.no, w, x.h, x.btc, both});
@@ -1486,8 +1487,18 @@ class Sim : public SimBase {
         }
         c->ncc = (c->ncc + 7) / 8 * 8;
         c->yn2 = y.n2; c->yno = y.no; c->yP = y.P; c->yQ = y.Q; c->yh = y.h; c->ybtc = y.btc;
+        c->yna = y.na;
+        c->blk = n0->b_block_log_public();
         if (c->use) {
             upload(c->tab, tab.data(), sizeof(int) * tab.size(), 0);
+            // the x-pass stores compact column cc of a row at element (cc >> b) (na_y << b) + (cc & (2^b - 1)) of the row's
+            // blocked output (RowDifArgs::out_blk): tabulated, so that a store index is one subtraction
+            {
+                std::vector<int> xt(tab.size());
+                const int b = c->blk, rows = y.na << b, mask = (1 << b) - 1;
+                for (size_t i = 0; i < tab.size(); ++i) xt[i] = tab[i] ? ((tab[i] - 1) >> b) * rows + ((tab[i] - 1) & mask) + 1 : 0;
+                upload(c->xtab, xt.data(), sizeof(int) * xt.size(), 0);
+            }
             // the y-pass output mask, on the device from the same targets
             if (y.logQ >= 9 && y.logQ <= 11 && !std::getenv("FFTVIS_HIP_NO_OUTPUT_MASK")) {
                 const int bl = n0->ypass_cols_log(), nw = y.Q > 1024 ? y.Q / 1024 : 1;
@@ -2385,7 +2396,8 @@ class Sim : public SimBase {
                         ColPlan *cp = col_plan_of[(size_t)(&grp - groups.data()) * pairs.size() + (size_t)(&pr - pairs.data())];
                         const bool on = cp && cp->use;
                         for (int m = 0; m < nm; ++m) {
-                            Ls[m]->nufft->arm_columns(on ? cp->tab.template as<int>() : nullptr, tg, on ? cp->ncc : 0, d_err.as<int>() + 3,
+                            Ls[m]->nufft->arm_columns(on ? cp->tab.template as<int>() : nullptr, on ? cp->xtab.template as<int>() : nullptr, tg,
+                                                      on ? cp->ncc : 0, d_err.as<int>() + 3,
                                                       on && cp->omask.p ? cp->omask.template as<unsigned long long>() : nullptr,
                                                       on ? cp->nblk : 0);
                             Ls[m]->nufft->col_out_cells = on && cp->omask.p ? cp->out_cells : 0.0;
