@@ -1452,7 +1452,6 @@ class Sim : public SimBase {
                 c->btc == x.btc && c->both == both && c->yn2 == y.n2 && c->yno == y.no && c->yP == y.P && c->yQ == y.Q &&
                 c->yh == y.h && c->ybtc == y.btc && c->yna == y.na && c->blk == n0->b_block_log_public())
                 return c.get();
-        if (col_plans.size() > 512) col_plans.clear();  // stale versions of earlier target sets
         std::unique_ptr<ColPlan> c(new ColPlan{targets_serial, pi, fa, fb, x.nos(), x.sP(), x.cnt(), x.n2, x.no, w, x.h, x.btc, both});
         const int nfg = fb - fa, stride = x.nos(), P = x.sP(), cnt = x.cnt();
         std::vector<int> tab((size_t)nfg * stride, 0);
@@ -2240,6 +2239,12 @@ class Sim : public SimBase {
             }
             // column plans of every (group, pair), from the geometry the run will set (large 2-D grids only)
             col_plan_of.assign(groups.size() * pairs.size(), nullptr);
+            // plans of earlier target sets / groupings pile up in a long-lived handle: start over now and then (here,
+            // before this run takes pointers into the list, and after everything an earlier run queued has finished)
+            if (col_plans.size() > 512) {
+                FV_HIP(hipDeviceSynchronize());
+                col_plans.clear();
+            }
             if (D == 2 && !std::getenv("FFTVIS_HIP_NO_COLUMN_PLAN")) {
                 Nufft3<T> *n0 = lanes[0].nufft.get();
                 for (size_t gi = 0; gi < groups.size(); ++gi) {
