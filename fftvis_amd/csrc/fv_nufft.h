@@ -58,7 +58,10 @@ inline bool debug_switch_natural_order() {
 constexpr int BINLOG = 3;      // sources are binned by footprint origin in 8x8-cell bins
 constexpr int GROUP = 16;      // lanes cooperating on one source / one target (>= MAX_W)
 constexpr int SPREAD_THREADS = 256;
-constexpr int INTERP_THREADS = 256;
+#ifndef FV_INTERP_THREADS
+#define FV_INTERP_THREADS 256
+#endif
+constexpr int INTERP_THREADS = FV_INTERP_THREADS;
 constexpr int FFT_THREADS = 256;
 #ifndef FV_FFT_QMAX_LOG
 #define FV_FFT_QMAX_LOG 12
