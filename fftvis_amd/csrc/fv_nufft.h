@@ -108,7 +108,7 @@ struct Geom {
 // n2 = P * 2^b >= nmin with 16 <= 2^b <= 4096 and P <= 16 (P unbounded at 2^b = 4096), chosen to
 // minimise n2 * (1 + 0.03 (P - 1)): HBM traffic grows with n2, per-row work with P.  Then as many
 // factors of two as possible move from P into Q.
-inline void choose_pq(int nmin, DimGeom &g) {
+inline void choose_pq(int nmin, DimGeom &g, bool last_dim = false) {
     double best = 0;
     int bp = 0, bq = 0;
     for (int b = 4; b <= FFT_QMAX_LOG; ++b) {
@@ -123,7 +123,10 @@ inline void choose_pq(int nmin, DimGeom &g) {
         // every extra residue re-reads the row (from L2) and re-applies the input twiddles: measured on C3's
         // mix of grid sizes with the sweep-wise fold of k_rowfft_st<.., FOLD>: 0.05-0.12 per extra residue
         // beats 0.25 by 2 % (10240 = 5 x 2048 instead of 12288 = 3 x 4096 for the widest grids)
-        static const double pen = std::getenv("FFTVIS_HIP_PQ_PENALTY") ? std::atof(std::getenv("FFTVIS_HIP_PQ_PENALTY")) : 0.12;
+        static const double pen0 = std::getenv("FFTVIS_HIP_PQ_PENALTY") ? std::atof(std::getenv("FFTVIS_HIP_PQ_PENALTY")) : 0.12;
+        // the last dimension (column passes: 8 columns of Q <= 1024 or 4 of Q = 2048 per workgroup) takes its own penalty
+        static const double pen1 = std::getenv("FFTVIS_HIP_PQ_PENALTY_LAST") ? std::atof(std::getenv("FFTVIS_HIP_PQ_PENALTY_LAST")) : pen0;
+        const double pen = last_dim ? pen1 : pen0;
         const double cost = (double)p * q * (1.0 + pen * (pp - 1));
         if (best == 0 || cost < best) {
             best = cost;
@@ -175,7 +178,7 @@ inline void set_dim_geom(DimGeom &g, double sigma, int w, double scale_max, bool
     // (no periodic wrap there): n2 (1 - 1 / sigma) >= w + 4.  Only tiny grids at sigma = 1.25 are affected
     // (they lost up to 250 eps at tight tolerances before).
     const int nwrap = (int)std::ceil((w + 4) / (1.0 - 1.0 / sigma));
-    choose_pq(std::max({(int)cdiv(n1, 1 << BINLOG) << BINLOG, (int)std::ceil(sigma * n1), nwrap}), g);
+    choose_pq(std::max({(int)cdiv(n1, 1 << BINLOG) << BINLOG, (int)std::ceil(sigma * n1), nwrap}), g, last_dim);
     // n2 = P 2^b is rounded up, by up to a third (6144, 8192, 10240 ...), and the transform itself only needs
     // n2 >= sigma n1.  The slack goes into a FINER source grid: spacing h = pi / (so S) with so >= sigma -- the
     // outer step more oversampled than asked, never less accurate -- grown until sigma n1(so) reaches n2.  The
