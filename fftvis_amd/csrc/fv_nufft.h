@@ -1043,32 +1043,38 @@ __device__ inline cplx<float> pk_isub(cplx<float> a, cplx<float> b) {  // i (a -
         : "v"(__builtin_bit_cast(f2v, a)), "v"(__builtin_bit_cast(f2v, b)));
     return __builtin_bit_cast(cplx<float>, r);
 }
+// (Both instructions of a product sit in ONE asm statement: between two statements the compiler's hazard recogniser, which
+// cannot see inside, puts an s_nop -- 97 of them per thread in the folded x-pass, an issue slot each, when they were two.)
 __device__ inline cplx<float> pk_mul(cplx<float> a, cplx<float> w) {  // a w
-    const f2v av = __builtin_bit_cast(f2v, a), wv = __builtin_bit_cast(f2v, w);
     f2v t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(wv));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(wv), "v"(t));
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(t), "=v"(r)
+        : "v"(__builtin_bit_cast(f2v, a)), "v"(__builtin_bit_cast(f2v, w)));
     return __builtin_bit_cast(cplx<float>, r);
 }
 __device__ inline cplx<float> pk_mul_s(cplx<float> a, cplx<float> w) {  // a w, w wave-uniform (scalar registers)
-    const f2v av = __builtin_bit_cast(f2v, a), wv = __builtin_bit_cast(f2v, w);
     f2v t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "s"(wv));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "s"(wv), "v"(t));
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(t), "=v"(r)
+        : "v"(__builtin_bit_cast(f2v, a)), "s"(__builtin_bit_cast(f2v, w)));
     return __builtin_bit_cast(cplx<float>, r);
 }
 __device__ inline cplx<float> pk_mac(cplx<float> acc, cplx<float> a, cplx<float> w) {  // acc + a w
-    const f2v av = __builtin_bit_cast(f2v, a), wv = __builtin_bit_cast(f2v, w);
     f2v t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(av), "v"(wv), "v"(__builtin_bit_cast(f2v, acc)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(wv), "v"(t));
+    asm("v_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(t), "=v"(r)
+        : "v"(__builtin_bit_cast(f2v, a)), "v"(__builtin_bit_cast(f2v, w)), "v"(__builtin_bit_cast(f2v, acc)));
     return __builtin_bit_cast(cplx<float>, r);
 }
 __device__ inline cplx<float> pk_mac_s(cplx<float> acc, cplx<float> a, cplx<float> w) {  // acc + a w, w wave-uniform
-    const f2v av = __builtin_bit_cast(f2v, a), wv = __builtin_bit_cast(f2v, w);
     f2v t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(av), "s"(wv), "v"(__builtin_bit_cast(f2v, acc)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "s"(wv), "v"(t));
+    asm("v_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(t), "=v"(r)
+        : "v"(__builtin_bit_cast(f2v, a)), "s"(__builtin_bit_cast(f2v, w)), "v"(__builtin_bit_cast(f2v, acc)));
     return __builtin_bit_cast(cplx<float>, r);
 }
 // the passes' products and multiply-adds: packed in fp32, plain otherwise (_u: the factor is wave-uniform -- it stays in
