@@ -2335,7 +2335,8 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const T *__restrict__ bt1, const T *__restrict__ bt2, const int *__restrict__ bl_idx,
     const signed char *__restrict__ flip, const double *__restrict__ scale, InterpArgs a,
     KerParams ker, cplx<T> *__restrict__ out, const cplx<T> *__restrict__ coef,
-    const int *__restrict__ ant1, const int *__restrict__ ant2, const int *__restrict__ ustart) {
+    const int *__restrict__ ant1, const int *__restrict__ ant2, const int *__restrict__ ustart,
+    const int *__restrict__ upairs) {
     const int tid = threadIdx.x;
     const int g = tid & (GROUP - 1);
     const int lane_base = (tid & 63) & ~(GROUP - 1);
@@ -2351,8 +2352,14 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     // [ustart[i], ustart[i + 1]) of the (u, v)-ordered list share target i -- the same point of the transform -- so it
     // is gathered once, at the first member's coordinates, and the 16 lanes then write every member's output slot
     // (each with its own conjugation / feed transposition / eigenbeam coefficients).
-    const int64_t ui = item % N;
+    // Packed runs (HERM) evaluate every target at s AND -s: a run of baselines b and the run of baselines -b are the same
+    // two evaluations, so they are one item (upairs[2 i], upairs[2 i + 1] = the two runs, the second may be -1) and the
+    // second run takes its values with the roles of the two sides swapped.
+    const int64_t ui0 = item % N;
+    const int64_t ui = upairs ? upairs[2 * ui0] : ui0;
+    const int64_t uj = upairs ? upairs[2 * ui0 + 1] : -1;
     const int64_t m0 = ustart ? ustart[ui] : ui, m1 = ustart ? ustart[ui + 1] : ui + 1;
+    const int64_t n0 = uj >= 0 ? ustart[uj] : 0, n1 = uj >= 0 ? ustart[uj + 1] : 0;  // members of the mirror run
     const int64_t kl = m0;
     const int64_t k = bl_idx ? bl_idx[kl] : kl;
     const double sg = ((flip && flip[kl]) != (a.negate_all != 0)) ? -1.0 : 1.0;
@@ -2521,13 +2528,17 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     }
     if constexpr (HERM) {
         // P = T1(s), M = T1(-s), C = T2(s), D = T2(-s)
-        const double Pr = vre[0][0], Pi = vim[0][0], Mr = vre[1][0], Mi = vim[1][0];
+      for (int sec = 0; sec < 2; ++sec) {  // the run of the target, then (packed pairs of runs) the run of its mirror image,
+        if (sec && n1 <= n0) break;       // which sees the two sides the other way round (uniform over the 16 lanes)
+        const double Pr = sec ? vre[1][0] : vre[0][0], Pi = sec ? vim[1][0] : vim[0][0], Mr = sec ? vre[0][0] : vre[1][0],
+                     Mi = sec ? vim[0][0] : vim[1][0];
         double o_re[4], o_im[4];
         o_re[0] = 0.5 * (Pr + Mr);   // (P + conj M) / 2
         o_im[0] = 0.5 * (Pi - Mi);
         o_re[3] = 0.5 * (Pi + Mi);   // (P - conj M) / 2i = -i/2 ((Pr - Mr) + i (Pi + Mi))
         o_im[3] = -0.5 * (Pr - Mr);
-        const double Cr = vre[0][1], Ci = vim[0][1], Dr = vre[1][1], Di = vim[1][1];
+        const double Cr = sec ? vre[1][1] : vre[0][1], Ci = sec ? vim[1][1] : vim[0][1], Dr = sec ? vre[0][1] : vre[1][1],
+                     Di = sec ? vim[0][1] : vim[1][1];
         if (a.herm == 2) {  // all four strengths real: T2 = F[c_01 + i c_10], unpacked like T1
             o_re[1] = 0.5 * (Cr + Dr);
             o_im[1] = 0.5 * (Ci - Di);
@@ -2539,7 +2550,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
             o_re[2] = Dr;   // conj D
             o_im[2] = -Di;
         }
-        for (int64_t m = m0 + g; m < m1; m += GROUP) {  // the target's members, dealt over the 16 lanes (no list: lane 0)
+        for (int64_t m = (sec ? n0 : m0) + g; m < (sec ? n1 : m1); m += GROUP) {  // the run's members, dealt over the 16 lanes (no list: lane 0)
             const int64_t km = bl_idx ? bl_idx[m] : m;
             const bool neg = (flip && flip[m]) != (a.negate_all != 0);
             cplx<T> *ob = out + (int64_t)fg * a.out_fg_stride + km * a.out_k_stride;
@@ -2578,6 +2589,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                 }
             }
         }
+      }
     }
 }
 
@@ -3145,7 +3157,7 @@ class Nufft3 {
                 const signed char *flip, const double *scale_dev, int nfg, int tpol,
                 cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                 const int64_t *out_pol_off, bool accumulate, const struct BasisTerm *basis = nullptr,
-                int herm = 0, const int *ustart = nullptr, int64_t nuniq = 0);
+                int herm = 0, const int *ustart = nullptr, int64_t nuniq = 0, const int *upairs = nullptr);
 
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
@@ -3620,8 +3632,9 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
                        const signed char *flip, const double *scale_dev, int nfg, int tpol,
                        cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                        const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis, int herm,
-                       const int *ustart, int64_t nuniq) {
+                       const int *ustart, int64_t nuniq, const int *upairs) {
     if (N == 0 || nfg == 0) return;
+    FV_REQUIRE(!upairs || (herm && ustart), "paired runs: packed gathers over run lists");
     if (ustart) N = nuniq;  // items are the distinct targets; bl_idx / flip stay the caller's full list
     FV_REQUIRE(!herm || (tpol == 2 && (herm == 2 || !basis || basis->kk == basis->ll)),
                "packed gather: two transforms per frequency; off-diagonal eigenbeam terms only with real strengths");
@@ -3688,7 +3701,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
                          : (herm ? (r9 ? k_interp<T, 3, true, 9> : k_interp<T, 3, true, 16>)
                                  : (r9 ? k_interp<T, 3, false, 9> : k_interp<T, 3, false, 16>));
     hipLaunchKernelGGL(kern, grid, dim3(INTERP_THREADS), 0, stream, (const cplx<T> *)grid_out, N, bt[0], bt[1], bt[2],
-                       bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2, ustart);
+                       bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2, ustart, upairs);
 }
 
 }  // namespace fv

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <thread>
 #include "fv_nufft.h"
+#include <unordered_map>
 
 #include <algorithm>
 #include <cstdlib>
@@ -1002,9 +1003,10 @@ class Sim : public SimBase {
         std::vector<int> h_idx, h_ustart;
         std::vector<signed char> h_flip;
         bool sorted = false;  // the list is visited in (u, v) order
-        std::unique_ptr<DevBuf> ustart;
-        int64_t nu = 0;
+        std::unique_ptr<DevBuf> ustart, upairs;  // run starts; (packed runs) pairs of runs b / -b that share one gather item
+        int64_t nu = 0, nitems = 0;               // runs; gather items (= runs unless paired)
         double utol = -1.0;
+        int upairs_herm = -1;
         double btc[3], B[3];   // tight box of its (sign-adjusted) baselines: centre, half-width [s]
         double Bs[3];          // half-width of the box made symmetric about 0
         int herm = 0;          // this run packs its strengths into two transforms: 1 Hermitian, 2 all real (per run)
@@ -1396,8 +1398,10 @@ class Sim : public SimBase {
         if (p.utol == tol) return;
         p.utol = tol;
         p.ustart.reset();
+        p.upairs.reset();
+        p.upairs_herm = -1;  // (pair_mirror_runs starts over on the new runs)
         p.h_ustart.clear();
-        p.nu = p.n;
+        p.nu = p.nitems = p.n;
         ++targets_serial;  // column plans were built from the old runs
         if (off || !p.sorted) return;
         std::vector<int> st(1, 0);
@@ -1415,6 +1419,64 @@ class Sim : public SimBase {
         upload(*p.ustart, st.data(), sizeof(int) * st.size(), 0);
         p.nu = nu;
         p.h_ustart = std::move(st);
+    }
+
+    // Packed runs gather every target at s and at -s: the run of baselines b and the run of baselines -b want the same
+    // two evaluations and share one item (k_interp: upairs).  Runs are matched through a hash of their vectors rounded
+    // to 4 tol (the 27 neighbouring cells are searched: either vector may sit next to a rounding boundary).
+    void pair_mirror_runs(Pair &p, double tol) {
+        const bool want = p.herm != 0 && p.ustart && tol > 0.0 && !std::getenv("FFTVIS_HIP_NO_TARGET_PAIRS");
+        if (p.upairs_herm == (want ? 1 : 0)) return;
+        p.upairs_herm = want ? 1 : 0;
+        p.upairs.reset();
+        p.nitems = p.nu;
+        ++targets_serial;
+        if (!want) return;
+        const double q = 4.0 * tol;
+        struct Key {
+            int64_t a, b, c;
+            bool operator==(const Key &o) const { return a == o.a && b == o.b && c == o.c; }
+        };
+        struct Hash {
+            size_t operator()(const Key &k) const { return (size_t)(k.a * 0x9E3779B97F4A7C15ull) ^ (size_t)(k.b * 0xC2B2AE3D27D4EB4Full) ^ (size_t)(k.c * 0x165667B19E3779F9ull); }
+        };
+        auto vec = [&](int64_t u, int d) {
+            const int64_t kl = p.h_ustart[u];
+            return (p.h_flip[kl] ? -1.0 : 1.0) * h_bls[(size_t)d * nbls + p.h_idx[kl]];
+        };
+        std::unordered_map<Key, int, Hash> at;
+        at.reserve((size_t)p.nu * 2);
+        for (int64_t u = 0; u < p.nu; ++u) at[Key{(int64_t)std::llround(vec(u, 0) / q), (int64_t)std::llround(vec(u, 1) / q), (int64_t)std::llround(vec(u, 2) / q)}] = (int)u;
+        std::vector<int> partner((size_t)p.nu, -1), items;
+        for (int64_t u = 0; u < p.nu; ++u) {
+            if (partner[u] >= 0) continue;
+            const int64_t k0 = std::llround(-vec(u, 0) / q), k1 = std::llround(-vec(u, 1) / q), k2 = std::llround(-vec(u, 2) / q);
+            int best = -1;
+            for (int da = -1; da <= 1 && best < 0; ++da)
+                for (int db = -1; db <= 1 && best < 0; ++db)
+                    for (int dc = -1; dc <= 1 && best < 0; ++dc) {
+                        auto it = at.find(Key{k0 + da, k1 + db, k2 + dc});
+                        if (it == at.end()) continue;
+                        const int v = it->second;
+                        if (v == (int)u || partner[v] >= 0) continue;
+                        bool same = true;
+                        for (int d = 0; d < 3 && same; ++d) same = std::fabs(vec(v, d) + vec(u, d)) <= tol;
+                        if (same) best = v;
+                    }
+            if (best >= 0) {
+                partner[u] = best;
+                partner[best] = (int)u;
+            }
+        }
+        for (int64_t u = 0; u < p.nu; ++u) {
+            if (partner[u] >= 0 && partner[u] < (int)u) continue;  // listed with its partner
+            items.push_back((int)u);
+            items.push_back(partner[u]);
+        }
+        if ((int64_t)items.size() / 2 == p.nu) return;  // no mirror pairs
+        p.upairs.reset(new DevBuf());
+        upload(*p.upairs, items.data(), sizeof(int) * items.size(), 0);
+        p.nitems = (int64_t)items.size() / 2;
     }
 
     // Column plan (Nufft3::arm_columns): which columns of the transform's first dimension the targets of one (frequency
@@ -2101,7 +2163,10 @@ class Sim : public SimBase {
             double fall = 0;
             for (double f : freqs) fall = std::max(fall, std::fabs(f));
             const double tol = 1e-3 * eps / (2.0 * M_PI * std::max(fall, 1.0));
-            for (Pair &p : pairs) build_unique(p, tol);
+            for (Pair &p : pairs) {
+                build_unique(p, tol);
+                pair_mirror_runs(p, tol);
+            }
         }
         int tg_max = 1;  // transforms per frequency on the grid, largest over the pairs
         for (const Pair &p : pairs)
@@ -2464,10 +2529,11 @@ class Sim : public SimBase {
                                       pr.trivial ? nullptr : pr.flip->template as<signed char>(),
                                       d_freqs.as<double>() + fa, nfg, tg, obase + (int64_t)m * per_tf,
                                       (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr, pr.herm,
-                                      pr.ustart ? pr.ustart->template as<int>() : nullptr, pr.nu);
+                                      pr.ustart ? pr.ustart->template as<int>() : nullptr, pr.upairs ? pr.nitems : pr.nu,
+                                      pr.upairs ? pr.upairs->template as<int>() : nullptr);
                             }
                     ev_end(e5, ls);
-                    st[4] += (double)(pr.ustart ? pr.nu : pr.n) * ntrans * nm * (pr.herm ? 2 : 1);  // footprints gathered: distinct targets; packed transforms are read at s and -s
+                    st[4] += (double)(pr.upairs ? pr.nitems : pr.ustart ? pr.nu : pr.n) * ntrans * nm * (pr.herm ? 2 : 1);  // footprints gathered: distinct targets; packed transforms are read at s and -s
                     st[6] = nufft->geo.d[0].n2;
                     st[7] = nufft->geo.d[1].n2;
                     st[8] = nufft->geo.d[0].na * 65536.0 + nufft->geo.d[1].na;
