@@ -1989,8 +1989,9 @@ class Sim : public SimBase {
             const unsigned hw = std::thread::hardware_concurrency();
             return (int)std::max(1u, std::min(16u, hw / 4));
         }
-        void start(int device, void *ptr, size_t bytes) {
-            t0 = std::chrono::steady_clock::now();
+        void mark() { t0 = std::chrono::steady_clock::now(); }  // the clock of since() / t_pinned: the run's start
+        void start(int device, void *ptr, size_t bytes, bool keep_clock = false) {
+            if (!keep_clock) mark();
             th = std::thread([this, device, ptr, bytes] {
                 (void)hipSetDevice(device);
                 char *p = static_cast<char *>(ptr), *end = p + bytes;
@@ -2102,8 +2103,16 @@ class Sim : public SimBase {
         const bool drain = !out_on_device && out_bytes >= drain_min_bytes();
         std::vector<DrainItem> drain_items;
         size_t drained = 0;
+        // the helper touches and pins the caller's array once the first unit is queued: started at once, its sixteen page-
+        // faulting threads slowed the main thread's set-up and first launches (first unit queued after 95 ms instead of 50)
         HostPin pin;
-        if (drain) pin.start(device, out, out_bytes);
+        pin.mark();
+        bool pin_started = false;
+        static const bool pin_early = std::getenv("FFTVIS_HIP_PIN_EARLY") != nullptr;
+        if (drain && pin_early) {
+            pin.start(device, out, out_bytes, true);
+            pin_started = true;
+        }
 
         double xc[3], X[3];
         source_box(xc, X);
@@ -2279,6 +2288,8 @@ class Sim : public SimBase {
             L.d_blockoff.reserve(sizeof(int) * (nblk + 1));
             L.binned_ti = -1;
         }
+        const bool dbg_t = std::getenv("FFTVIS_HIP_DEBUG_DRAIN") != nullptr;
+        if (dbg_t) std::fprintf(stderr, "run: set-up done %.3f s (lanes, unique targets, groups)\n", pin.since());
         // Size every lane's grid and strength buffers for the largest (frequency group, beam pair) of this run now,
         // before anything is queued (Nufft3::plan_buffer_cells): no reallocation -- a device synchronisation each --
         // while the first time step runs.
@@ -2327,6 +2338,7 @@ class Sim : public SimBase {
                 FV_HIP(hipStreamSynchronize(n0->stream));  // the table kernels of these set_geometry calls are done before the run's own
             }
         }
+        if (dbg_t) std::fprintf(stderr, "run: buffers and column plans %.3f s\n", pin.since());
         if (nlanes > 1 && !pipe) {  // lane 1 starts after the output memset queued on the main stream
             FV_HIP(hipEventRecord(ev_start, stream));
             FV_HIP(hipStreamWaitEvent(lanes[1].stream, ev_start, 0));
@@ -2543,6 +2555,11 @@ class Sim : public SimBase {
             if (pipe) {
                 if (!heavy_recorded) FV_HIP(hipEventRecord(L0.heavy_done, ls));
                 L0.heavy_pending = true;
+            }
+            if (dbg_t && tu == t0 && chunk == 0) std::fprintf(stderr, "run: first unit queued %.3f s\n", pin.since());
+            if (drain && !pin_started) {
+                pin.start(device, out, out_bytes, true);
+                pin_started = true;
             }
             close_time();
         }
