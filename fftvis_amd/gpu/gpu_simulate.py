@@ -30,18 +30,25 @@ logger = logging.getLogger(__name__)
 
 
 # Handles kept between ``simulate`` calls.  Creating and destroying a handle (streams, events, device
-# buffers, per-geometry tables) costs ~15 ms, ten times the GPU work of a HERA-37 simulation; every
-# ``fv_sim_set_*`` call fully replaces what it configures, so a handle whose creation parameters
-# match can serve the next call.  At most two idle handles, and only while this process holds less
-# than FFTVIS_HIP_HANDLE_CACHE_BYTES of device memory (default 2 GiB; 0 = never keep one).
+# buffers, per-geometry tables) costs ~15 ms, ten times the GPU work of a HERA-37 simulation -- and for a
+# HERA-350 call ~85 ms of buffers, tables, launch lists and column plans that the next call on the same array
+# would find ready; every ``fv_sim_set_*`` call fully replaces what it configures (re-setting what is already
+# there keeps what was planned from it), so a handle whose creation parameters match can serve the next call.
+# At most two idle handles, and only while this process holds less than FFTVIS_HIP_HANDLE_CACHE_BYTES of device
+# memory (default: a quarter of the device's memory, at least 2 GiB; 0 = never keep one).
 _IDLE_HANDLES: dict = {}
 atexit.register(lambda: release_handles())
 
 
-def _cache_limit() -> int:
+def _cache_limit(device: int = 0) -> int:
     import os
 
-    return int(float(os.environ.get("FFTVIS_HIP_HANDLE_CACHE_BYTES", 2 * 1024**3)))
+    env = os.environ.get("FFTVIS_HIP_HANDLE_CACHE_BYTES")
+    if env is not None:
+        return int(float(env))
+    free, total = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().fv_device_mem_info(int(device), ctypes.byref(free), ctypes.byref(total)))
+    return max(2 * 1024**3, total.value // 4)
 
 
 def release_handles():
@@ -62,7 +69,8 @@ def _acquire_handle(device, precision, eps, upsample_factor, polarized):
 def _return_handle(key, h):
     held = ctypes.c_int64(0)
     _lib.check(_lib.lib().fv_device_bytes(ctypes.byref(held)))
-    if _cache_limit() <= 0 or held.value > _cache_limit():
+    limit = _cache_limit(key[0])
+    if limit <= 0 or held.value > limit:
         h.close()
         return
     while len(_IDLE_HANDLES) >= 2:
