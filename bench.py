@@ -33,7 +33,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-PMC_FILE = os.path.join("profiles", "r03_hbm_traffic_pmc.json")
+
+
+def pmc_file():
+    """The newest committed PMC summary (profiles/rNN_hbm_traffic_pmc.json, tools/refresh_profiles.py)."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic_pmc.json")))
+    return os.path.relpath(found[-1], ROOT) if found else None
+
+
+def git_blob_id(path):
+    """`git hash-object` of a file, computed here (the GPU box has no .git): names the exact committed content."""
+    import hashlib
+
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 def parse():
@@ -44,7 +59,15 @@ def parse():
                    help="untimed steps first (default: 1; 20 for C2 -- a 1.5 ms step needs ~30 ms of work "
                         "before clocks and caches settle)")
     p.add_argument("--workload", default=os.environ.get("FFTVIS_BENCH_WORKLOAD", "C3"),
-                   choices=["C1", "C2", "C3", "C4", "C5"])
+                   choices=["C1", "C2", "C3", "C3z", "C4", "C5"],
+                   help="C3z = C3's array with a seeded 3 cm height scatter (non-coplanar: the 3-D transform the "
+                        "reference takes whenever any |b_z| > 1e-6 m, cpu_simulate.py:655), 8 channels x 2 times")
+    p.add_argument("--array", default=None, choices=["scattered"],
+                   help="scattered = 350 antennas uniformly inside HERA-350's footprint: no lattice, no repeated "
+                        "baseline vectors (the generic type-3 workload; same catalog / beam / band)")
+    p.add_argument("--z-scatter", type=float, default=None, help="height scatter in metres (C3z: 0.03)")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the short side runs of the default line (generic_array, default_path_gpu, c2_ms_per_step)")
     p.add_argument("--nsrc", type=int, default=None)
     p.add_argument("--nfreq", type=int, default=None)
     p.add_argument("--ntimes", type=int, default=None)
@@ -67,6 +90,12 @@ def parse():
                    help="skip the extra single-stream step that times every kernel family (profiling runs)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     a = p.parse_args()
+    a.base = "C3" if a.workload == "C3z" else a.workload
+    if a.workload == "C3z":
+        a.nfreq = a.nfreq or 8
+        a.ntimes = a.ntimes or 2
+        a.z_scatter = 0.03 if a.z_scatter is None else a.z_scatter
+    a.z_scatter = a.z_scatter or 0.0
     a.light = a.workload in ("C1", "C2") and not (a.nsrc and a.nsrc > 200000)
     if a.steps is None:
         a.steps = 50 if a.light else 3
@@ -221,6 +250,120 @@ def spawn_ranks(n: int) -> int:
     return proc.wait()
 
 
+def device_catalog(cfg, dev):
+    """The prepared catalog (unit vectors, coherency per source and channel) as device tensors."""
+    import torch
+
+    from fftvis_amd import parallel
+    from fftvis_amd.core import utils
+    from fftvis_amd.core.coords import eq_unit_vectors
+
+    precision = cfg.get("precision", 2)
+    coh, pol_sky = utils.prepare_source_catalog(cfg["fluxes"], cfg["polarized"])
+    rdt = torch.float32 if precision == 1 else torch.float64
+    cdt = torch.complex64 if precision == 1 else torch.complex128
+    return parallel.DeviceCatalog(torch.from_numpy(eq_unit_vectors(cfg["ra"], cfg["dec"])).to(dev, rdt),
+                                  torch.from_numpy(np.ascontiguousarray(coh)).to(dev, cdt if pol_sky else rdt), pol_sky)
+
+
+def make_handle(cfg, cat, device_index, eps, upsample, path):
+    """An engine handle configured for one workload (catalog already in HBM); returns (handle, coplanar)."""
+    from fftvis_amd.core import utils
+    from fftvis_amd.core.coords import SiderealRotation
+    from fftvis_amd.gpu.gpu_simulate import SimHandle, prepare_array
+
+    freqs, baselines = cfg["freqs"], cfg["baselines"]
+    R, bls, coplanar = prepare_array(cfg["ants"], baselines, 1e-6, np.float64)
+    pairs, pidx, pflip = utils.prepare_beam_evaluation(list(cfg["ants"]), baselines, None)
+    h = SimHandle(device_index, cfg.get("precision", 2), eps, upsample, cfg["polarized"])
+    h.set_sources_device(cat.nsrc, cat.nfreq, cat.eq.data_ptr(), cat.flux.data_ptr(), cat.polarized_sky)
+    h.set_times(SiderealRotation(cfg["times"], cfg["telescope_loc"]).matrices())
+    h.set_freqs(freqs)
+    if path == "type1":
+        from fftvis_amd.core.antenna_gridding import check_antpos_griddability
+
+        ok, grid, basis = check_antpos_griddability(cfg["ants"])
+        assert ok, "workload array is not a lattice"
+        bint = np.round(np.array([grid[b[1]] - grid[b[0]] for b in baselines]).T).astype(int)
+        h.set_array_type1(basis / utils.speed_of_light, bint, 2 * int(np.abs(bint).max()) + 1)
+    else:
+        h.set_array(R, bls, coplanar)
+    blist = cfg["beam"] if isinstance(cfg["beam"], list) else [cfg["beam"]]
+    h.set_beams(blist, freqs)
+    if "beam_coefs" in cfg:  # eigenbeam workload (C5): K (K + 1) / 2 NUFFTs per slice
+        antnums = list(cfg["ants"])
+        h.set_basis(cfg["beam_coefs"], [antnums.index(b[0]) for b in baselines],
+                    [antnums.index(b[1]) for b in baselines])
+    else:
+        h.set_beam_pairs(pairs, pidx, pflip)
+    return h, coplanar
+
+
+def mini_run(cfg, device_index, path="type3", upsample=2.0, steps=2, warmup=1, settle_s=0.0, breakdown=False):
+    """A short device-resident run of ANOTHER workload on this GPU with its own handle -- the side entries of the
+    default line (generic_array, default_path_gpu, c2_ms_per_step): same step definition, same timing bracket
+    (synchronise, K steps, synchronise), inputs resident in HBM, output left on the device."""
+    import torch
+
+    dev = torch.device("cuda", device_index)
+    cat = device_catalog(cfg, dev)
+    h, coplanar = make_handle(cfg, cat, device_index, cfg["eps"], upsample, path)
+    nt, nf = len(cfg["times"]), len(cfg["freqs"])
+    cdt = torch.complex64 if cfg.get("precision", 2) == 1 else torch.complex128
+    out = torch.empty(h.out_shape(nt, nf), dtype=cdt, device=dev)
+
+    def step():
+        h.run_device(0, nt, 0, nf, out.data_ptr())
+
+    t_s = time.perf_counter()
+    for _ in range(warmup):
+        step()
+    h.sync()
+    while time.perf_counter() - t_s < settle_s:
+        step()
+        h.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    h.sync()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    res = {"ms_per_step": ms, "value": len(cfg["baselines"]) * nf * nt / (ms * 1e-3), "unit": "visibilities/s",
+           "steps": steps, "warmup": warmup,
+           "finite_output": bool(torch.isfinite(torch.view_as_real(out)).all().item())}
+    if breakdown:
+        h.reset_stats()
+        h.enable_timing(2)
+        step()
+        h.sync()
+        tm, st = h.timing(), h.stats()
+        h.enable_timing(0)
+        RB = 4.0 if cfg.get("precision", 2) == 1 else 8.0
+        fam = ("spread", "fft", "interp", "strengths", "prep")
+        total = max(sum(tm[k] for k in fam), 1e-9)
+        l2 = max(st["spread_launches"], 1.0)
+        res["share_of_step"] = {k: tm[k] / total for k in fam}
+        res["launches_per_step"] = l2
+        if tm["fft"] > 0:
+            gbps = st["fft_cells"] * 2 * RB / (tm["fft"] * 1e-3) / 1e9
+            res["roofline_fft"] = {"achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                                   "fft_ms_per_launch": tm["fft"] / l2}
+            if st.get("fft_flops", 0) > 0:
+                peak_tf = 78.6 if RB == 8 else 157.3
+                res["roofline_fft"]["flops_frac"] = st["fft_flops"] / (tm["fft"] * 1e-3) / 1e12 / peak_tf
+        if tm["spread"] > 0:
+            res["spread_ms_per_launch"] = tm["spread"] / l2
+        if tm["interp"] > 0:
+            res["interp_ms_per_launch"] = tm["interp"] / l2
+        res["grid_top_channel"] = {"n2": [int(st["n2x"]), int(st["n2y"])],
+                                   "active": [int(st["n2z"]) // 65536, int(st["n2z"]) % 65536]}
+    h.close()
+    del out, cat
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and a.as_rank is None:
@@ -234,9 +377,6 @@ def main():
     import torch
 
     from fftvis_amd import _lib, parallel, synth
-    from fftvis_amd.core import utils
-    from fftvis_amd.core.coords import SiderealRotation
-    from fftvis_amd.gpu.gpu_simulate import SimHandle, prepare_array
 
     if a.lanes is not None:
         os.environ["FFTVIS_HIP_LANES"] = str(a.lanes)
@@ -259,7 +399,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg = synth.make_config(a.workload, nsrc=a.nsrc, nfreq=a.nfreq, ntimes=a.ntimes)
+    cfg = synth.make_config(a.base, nsrc=a.nsrc, nfreq=a.nfreq, ntimes=a.ntimes,
+                            array="scattered350" if a.array == "scattered" else None, z_scatter=a.z_scatter)
     if a.eps is None:
         a.eps = cfg["eps"]
     cfg["eps"] = a.eps
@@ -278,13 +419,7 @@ def main():
                                                 cfg["fluxes"] if rank == 0 else None, pol, precision, dev,
                                                 via_host=backend != "nccl")
     else:
-        from fftvis_amd.core.coords import eq_unit_vectors
-
-        coh, pol_sky = utils.prepare_source_catalog(cfg["fluxes"], pol)
-        rdt = torch.float32 if precision == 1 else torch.float64
-        cat = parallel.DeviceCatalog(torch.from_numpy(eq_unit_vectors(cfg["ra"], cfg["dec"])).to(dev, rdt),
-                                     torch.from_numpy(np.ascontiguousarray(coh)).to(dev, cdt if pol_sky else rdt),
-                                     pol_sky)
+        cat = device_catalog(cfg, dev)
     torch.cuda.synchronize()
 
     # ---- this rank's block of the observation ----------------------------------------------------
@@ -294,30 +429,8 @@ def main():
         assert world == 1 and a.of_ranks and 0 <= a.as_rank < a.of_ranks, "--as-rank R --of-ranks N, single process"
         blocks = [parallel.shard_blocks_weighted(a.of_ranks, freqs, ntimes, nsrc)[a.as_rank]]
         mine = blocks[0]
-    R, bls, coplanar = prepare_array(cfg["ants"], baselines, 1e-6, np.float64)
-    pairs, pidx, pflip = utils.prepare_beam_evaluation(list(cfg["ants"]), baselines, None)
-
-    h = SimHandle(local_rank, precision, a.eps, a.upsample, pol)
-    h.set_sources_device(cat.nsrc, cat.nfreq, cat.eq.data_ptr(), cat.flux.data_ptr(), cat.polarized_sky)
-    h.set_times(SiderealRotation(cfg["times"], cfg["telescope_loc"]).matrices())
-    h.set_freqs(freqs)
-    if a.path == "type1":
-        from fftvis_amd.core.antenna_gridding import check_antpos_griddability
-
-        ok, grid, basis = check_antpos_griddability(cfg["ants"])
-        assert ok, "workload array is not a lattice"
-        bint = np.round(np.array([grid[b[1]] - grid[b[0]] for b in baselines]).T).astype(int)
-        h.set_array_type1(basis / utils.speed_of_light, bint, 2 * int(np.abs(bint).max()) + 1)
-    else:
-        h.set_array(R, bls, coplanar)
+    h, coplanar = make_handle(cfg, cat, local_rank, a.eps, a.upsample, a.path)
     blist = cfg["beam"] if isinstance(cfg["beam"], list) else [cfg["beam"]]
-    h.set_beams(blist, freqs)
-    if "beam_coefs" in cfg:  # eigenbeam workload (C5): K (K + 1) / 2 NUFFTs per slice
-        antnums = list(cfg["ants"])
-        h.set_basis(cfg["beam_coefs"], [antnums.index(b[0]) for b in baselines],
-                    [antnums.index(b[1]) for b in baselines])
-    else:
-        h.set_beam_pairs(pairs, pidx, pflip)
     outs = []
     for tsl, fsl in mine:
         outs.append(torch.empty(h.out_shape(tsl.stop - tsl.start, fsl.stop - fsl.start), dtype=cdt, device=dev))
@@ -387,14 +500,17 @@ def main():
         launches = max(st["spread_launches"], 1.0)
         timed = max(tm.get("spread_launches_timed", 0.0), 1.0)
         R8 = RB
-        d = 2 if coplanar else 3
+        # transforms are 2-D for coplanar arrays AND for nearly flat ones, which run as K 2-D transforms per slice
+        # (height terms, fv_sim.h wt_K); 3-D otherwise
+        hterms = int(st.get("height_terms", 0))
+        d = 2 if coplanar or hterms else 3
         my_times = sum(t.stop - t.start for t, _ in mine)
         # algorithmic bytes:  M (d R + T 2R)  +  T G1 2R   summed over launches
         spread_bytes = st["source_visits"] * 2 * R8 + (st["sources_above_horizon"] / max(my_times * a.steps, 1)) \
             * d * R8 * launches + st["spread_cells"] * 2 * R8
         spread_s = tm["spread"] * 1e-3 * launches / timed  # all launches (level 3: timed == launches)
-        spread_kernel = "k_spread2d" if coplanar else "k_spread3d"
-        if coplanar and os.environ.get("FFTVIS_HIP_SPREAD_CELL", "") != "1":
+        spread_kernel = "k_spread2d" if d == 2 else "k_spread3d"
+        if d == 2 and os.environ.get("FFTVIS_HIP_SPREAD_CELL", "") != "1":
             # Nufft3::launch_spread picks the channel-group lane mapping once the catalog has >= 3
             # sources per 8 x 8-cell block (all launches of these workloads are chunks of >= 8 transforms)
             nax, nay = int(st["n2z"]) // 65536, int(st["n2z"]) % 65536
@@ -418,17 +534,35 @@ def main():
             timed = launches
         ach = spread_bytes / spread_s / 1e9 if spread_s > 0 else 0.0
         # HBM traffic of the spread kernel from the committed PMC passes over this same command (rocprofv3
-        # counters cannot be read from inside the process): only for the workload those passes ran.
+        # counters cannot be read from inside the process): only for the workload those passes ran -- and only if
+        # the file still describes THIS run: same kernel family, same launches per time step, bytes that can belong
+        # to the launches timed here.  A file that no longer matches fails the run instead of going quietly to null.
         traffic, traffic_src = None, None
-        try:
-            if a.workload in ("C2", "C3") and not (a.nsrc or a.nfreq or a.ntimes) and a.upsample == 2.0 and world == 1 \
-                    and a.path == "type3" and "FFTVIS_HIP_NO_HERMITIAN" not in os.environ and a.as_rank is None:
-                pm = json.load(open(os.path.join(ROOT, PMC_FILE)))
-                k = pm["counters"][a.workload.lower()][spread_kernel]
+        default_shape = not (a.nsrc or a.nfreq or a.ntimes) and a.upsample == 2.0 and world == 1 and a.path == "type3" \
+            and "FFTVIS_HIP_NO_HERMITIAN" not in os.environ and a.as_rank is None and a.array is None and a.z_scatter == 0
+        pmf = pmc_file()
+        if a.workload in ("C2", "C3") and default_shape and pmf and not os.environ.get("FFTVIS_BENCH_NO_PMC_CHECK"):
+            pm = json.load(open(os.path.join(ROOT, pmf)))
+            ent = pm["counters"].get(a.workload.lower(), {})
+            k = ent.get(spread_kernel)
+            per_time = launches / max(my_times * a.steps, 1)  # logical launches per time step of this run
+            problems = []
+            if k is None:
+                problems.append(f"no entry for kernel family {spread_kernel} (file has {sorted(x for x in ent if x.startswith('k_'))})")
+            else:
+                nlog = ent.get("logical_launches", 0)
+                if per_time <= 0 or abs(nlog / per_time - round(nlog / per_time)) > 1e-9 or nlog < per_time:
+                    problems.append(f"{nlog} logical launches in the file are not whole time steps of this run's {per_time:g} launches per time step")
                 traffic = (2 * k["FETCH_SIZE_KB_avg_per_launch"] + k["WRITE_SIZE_KB_avg_per_launch"]) * 1024
-                traffic_src = PMC_FILE + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; 2*FETCH_SIZE+WRITE_SIZE per the gfx950 note)"
-        except Exception:
-            traffic = None
+                alg = spread_bytes / launches
+                if not 0.9 <= traffic / alg <= 1.6:
+                    problems.append(f"traffic {traffic:.4g} B per launch against {alg:.4g} algorithmic bytes ({traffic / alg:.2f}x): not this kernel's launches")
+            if problems:
+                raise SystemExit(f"bench.py: {pmf} does not describe this run -- " + "; ".join(problems) +
+                                 " -- re-collect it (tools/collect_profiles.sh, tools/refresh_profiles.py) or set FFTVIS_BENCH_NO_PMC_CHECK=1")
+            traffic_src = (f"{pmf} (git blob {git_blob_id(os.path.join(ROOT, pmf))[:12]}; rocprofv3 --pmc, separate FETCH_SIZE / "
+                           "WRITE_SIZE passes; 2*FETCH_SIZE+WRITE_SIZE per the gfx950 note; checked against this run's kernel family, "
+                           "launches per time step and algorithmic bytes)")
         kern, fft, interp_rf = None, None, None
         if breakdown:
             l2 = max(st_all["spread_launches"], 1.0)
@@ -444,16 +578,18 @@ def main():
                 "prep_ms_per_step": tm_all["prep"],
                 "launches_per_step": l2,
                 "share_of_step": {k: tm_all[k] / total for k in fam},
-                "grid_top_channel": {"n2": [int(st["n2x"]), int(st["n2y"])],
-                                     "active": [int(st["n2z"]) // 65536, int(st["n2z"]) % 65536]},
+                "grid_top_channel": {"n2": [int(st["n2x"]), int(st["n2y"])] + ([int(st["n2_3"])] if d == 3 else []),
+                                     "active": [int(st["n2z"]) // 65536, int(st["n2z"]) % 65536] + ([int(st["na_3"])] if d == 3 else [])},
                 "kernel_width": int(st["w"]),
+                "height_terms": hterms,
             }
             if tm_all["fft"] > 0:
                 gbps = fft_bytes / (tm_all["fft"] * 1e-3) / 1e9
                 # the pruned row FFT is the largest share of the step; same accounting: algorithmic
                 # bytes of its passes over its summed pass durations (HIP events)
                 fft = {
-                    "kernel": "k_rowfft_st (x-pass + y-pass of the pruned 2-D FFT)",
+                    "kernel": "k_rowfft_st (x-pass + y-pass of the pruned 2-D FFT)" if d == 2 else
+                              "k_rowfft_st / k_rowfft_dif (x-, y- and z-pass of the pruned 3-D FFT)",
                     "bound": "hbm",
                     "achieved": gbps,
                     "peak": HBM_PEAK_GBS,
@@ -475,7 +611,7 @@ def main():
             if tm_all["interp"] > 0 and a.path == "type3":
                 # gather at the targets: algorithmic bytes = w^d grid values per (target, transform[, mirror side])
                 # footprint + one output value per target and transform
-                gb = st_all["interp_items"] * (int(st["w"]) ** 2) * 2 * R8  # the bench arrays are coplanar: 2-D transforms
+                gb = st_all["interp_items"] * (int(st["w"]) ** d) * 2 * R8  # w^d footprint values per item
                 gbps = gb / (tm_all["interp"] * 1e-3) / 1e9
                 interp_rf = {
                     "kernel": "k_interp (gather of the transform grid at the baselines)",
@@ -489,6 +625,7 @@ def main():
                     "note": "footprint rows are w-element pieces of 128-B lines: the lines fetched are about twice these bytes",
                 }
         own_ms = [1e3 * t / a.steps for t in per_rank]
+        h_closed = False
         res = {
             "metric": "simulated visibilities/sec (baselines x freqs x times) at eps="
                       + ("6e-8" if a.eps == 6e-8 else f"{a.eps:g}"),
@@ -505,7 +642,8 @@ def main():
             "dtype": "f32" if precision == 1 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{a.workload}: {synth.CONFIGS[a.workload][0]}, {nsrc} sources, "
+                "workload": f"{a.workload}: {('scattered350 (no lattice, no repeated baseline vectors)' if a.array == 'scattered' else synth.CONFIGS[a.base][0])}"
+                            f"{(' + %g m height scatter (non-coplanar: %s)' % (a.z_scatter, ('%d height terms, 2-D transforms' % hterms) if hterms else '3-D transform')) if a.z_scatter else ''}, {nsrc} sources, "
                             f"{nfreq} freqs, {ntimes} times, {nbls} baselines, "
                             f"{('%d basis beams (eigenbeam path), polarized' % len(blist)) if 'beam_coefs' in cfg else 'polarized table beam' if pol else 'unpolarized Airy beam'}, "
                             f"{a.path} NUFFT eps={a.eps:g} upsampfac={st.get('upsample_used', a.upsample):g}"
@@ -548,6 +686,7 @@ def main():
             outs.clear()
             del cat
             torch.cuda.empty_cache()
+            h_closed = True
             kw = dict(cfg, upsample_factor=a.upsample if a.upsample else "auto",
                       force_use_type3=a.path == "type3")
             walls, nbytes = [], 0
@@ -568,10 +707,32 @@ def main():
                 "d2h": "off" if os.environ.get("FFTVIS_HIP_D2H_OVERLAP") == "0" else
                        "caller's array pinned in place, one async copy per (channel, finished time step) on a copy stream",
             }
+        if a.workload == "C3" and default_shape and not a.no_extras:
+            # ---- side runs that ride in the driver's line so that they cannot rot unseen -----------------------
+            if not h_closed:
+                h.close()
+                outs.clear()
+                del cat
+                torch.cuda.empty_cache()
+                h_closed = True
+            # (1) the generic type-3 engine: the same workload on an array WITHOUT a lattice or repeated baseline
+            # vectors -- no column plan, no redundant-baseline gather (what finufft's contract promises nothing about)
+            g = mini_run(synth.make_config("C3", array="scattered350"), local_rank, steps=2, warmup=1, breakdown=True)
+            res["generic_array"] = dict(g, what="C3 on scattered350 (350 antennas uniform in HERA-350's footprint, all 61075 "
+                                                "baselines distinct): type-3 NUFFT without the regular-array prunings",
+                                        ratio_to_lattice_step=g["ms_per_step"] / res["ms_per_step"])
+            # (2) the path the reference takes BY DEFAULT on this lattice array (type 1, cpu_simulate.py:634-681)
+            t1 = mini_run(dict(synth.make_config("C3"), force_use_type3=False), local_rank, path="type1", steps=3, warmup=1)
+            res["default_path_gpu"] = dict(t1, what="C3 through the lattice (type-1) path simulate_vis takes on this array "
+                                                    "unless force_use_type3 (BASELINE.md 3.3)")
+            # (3) C2 (configs[1]) as a 50-step mini-run: the small-grid regime, tracked round to round
+            c2 = mini_run(synth.make_config("C2"), local_rank, steps=50, warmup=20, settle_s=0.04)
+            res["c2_ms_per_step"] = c2["ms_per_step"]
+            res["c2"] = c2
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
         print(json.dumps(res))
-    h.close()
+    h.close()  # (idempotent)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

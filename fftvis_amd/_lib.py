@@ -29,6 +29,7 @@ SYMBOLS = {
     "fv_device_count": (c_int, [POINTER(c_int)]),
     "fv_last_error": (c_char_p, []),
     "fv_device_bytes": (c_int, [POINTER(c_int64)]),
+    "fv_device_bytes_on": (c_int, [c_int, POINTER(c_int64)]),
     "fv_device_mem_info": (c_int, [c_int, POINTER(c_int64), POINTER(c_int64)]),
     "fv_release_workspaces": (c_int, []),
     "fv_nufft3": (c_int, [c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -384,6 +384,11 @@ int fv_device_bytes(int64_t *bytes) {
     return bytes ? 0 : 1;
 }
 
+int fv_device_bytes_on(int device, int64_t *bytes) {
+    if (bytes) *bytes = (int64_t)fv::dev_bytes_on(device).load();
+    return bytes ? 0 : 1;
+}
+
 int fv_device_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes) {
     return guarded([&] {
         FV_REQUIRE(free_bytes && total_bytes, "null output");

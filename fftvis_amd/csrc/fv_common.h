@@ -45,26 +45,37 @@ inline std::atomic<size_t> &dev_bytes_held() {
     static std::atomic<size_t> v{0};
     return v;
 }
+// ... and the share of it on one device (fv_device_bytes_on): what a run on THAT device can count on reusing
+constexpr int DEV_SLOTS = 64;
+inline std::atomic<size_t> &dev_bytes_on(int device) {
+    static std::atomic<size_t> v[DEV_SLOTS + 1];
+    return v[device >= 0 && device < DEV_SLOTS ? device : DEV_SLOTS];
+}
 
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    int dev = -1;  // the device the memory sits on (the current device of the allocating call)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() {
         if (p) (void)hipFree(p);
         dev_bytes_held() -= cap;
+        if (cap) dev_bytes_on(dev) -= cap;
     }
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
         if (p) FV_HIP(hipFree(p));
         dev_bytes_held() -= cap;
+        if (cap) dev_bytes_on(dev) -= cap;
         p = nullptr;
         cap = 0;
         FV_HIP(hipMalloc(&p, bytes));
+        (void)hipGetDevice(&dev);
         cap = bytes;
         dev_bytes_held() += cap;
+        dev_bytes_on(dev) += cap;
     }
     template <typename U>
     U *as() const {

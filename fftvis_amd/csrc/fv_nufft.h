@@ -2313,7 +2313,30 @@ struct InterpArgs {
     const int *ctab;
     int ctab_stride, ncc;
     int *err;
+    // Height term of a nearly flat array (Sim::run, "w-term expansion"): this launch gathered the 2-D transform F_k of the
+    // strengths c_j ((z_j - wt_zc) / wt_zh)^k, and every member adds  exp(i wt_zc zq) (i wt_zh zq)^k / k!  F_k  with its own
+    // sign-adjusted height coordinate zq = nu (+-b_z) (wt_bz: the baselines' third component, by global baseline id) --
+    // the k-th term of exp(i z_j zq) expanded about the middle of the sources' height range.  wt_k < 0: off.
+    int wt_k;
+    double wt_zc, wt_zh;
+    const void *wt_bz;
 };
+
+// exp(i zc zq) (i zh zq)^k / k!
+__device__ inline cplx<double> wterm_factor(int k, double zc, double zh, double zq) {
+    double sn, cs;
+    sincos(zc * zq, &sn, &cs);
+    double mag = 1.0;
+    const double a = zh * zq;
+    for (int i = 1; i <= k; ++i) mag *= a / (double)i;
+    const cplx<double> e = {cs * mag, sn * mag};
+    switch (k & 3) {  // times i^k
+        case 0: return e;
+        case 1: return {-e.im, e.re};
+        case 2: return {-e.re, -e.im};
+        default: return {e.im, -e.re};
+    }
+}
 
 // HERM (Hermitian strengths): the grid holds two transforms per frequency instead of four --
 //   T1 = F[c_00 + i c_11]  (both real),   T2 = F[c_01]   (c_10 = conj(c_01)) --
@@ -2479,16 +2502,22 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                 sr += __shfl_xor(sr, off, 64);
                 si += __shfl_xor(si, off, 64);
             }
-            double vr = (double)sr * pr - (double)si * pis;
-            double vi = (double)sr * pis + (double)si * pr;
+            const double vr0 = (double)sr * pr - (double)si * pis;
+            const double vi0 = (double)sr * pis + (double)si * pr;
             if constexpr (HERM) {
-                vre[side][r] = vr;
-                vim[side][r] = vi;
+                vre[side][r] = vr0;
+                vim[side][r] = vi0;
                 continue;
             }
             for (int64_t m = m0 + g; m < m1; m += GROUP) {  // the target's members, dealt over the 16 lanes (no list: lane 0)
                 const int64_t km = bl_idx ? bl_idx[m] : m;
                 const bool neg = (flip && flip[m]) != (a.negate_all != 0);
+                double vr = vr0, vi = vi0;
+                if (a.wt_k >= 0) {  // uniform: this member's height factor, before the conjugation
+                    const cplx<double> f = wterm_factor(a.wt_k, a.wt_zc, a.wt_zh, sc * (neg ? -1.0 : 1.0) * (double)((const T *)a.wt_bz)[km]);
+                    vr = vr0 * f.re - vi0 * f.im;
+                    vi = vr0 * f.im + vi0 * f.re;
+                }
                 const double vim_ = neg ? -vi : vi;  // conj for flipped baselines (cpu_simulate.py:298)
                 const int rt = a.transpose_flipped && neg && a.tpol == 4 ? (r & 1) * 2 + (r >> 1) : r;
                 const int64_t po = rt < 16 ? a.out_pol_off[rt] : (int64_t)rt * a.out_pol_off[1];
@@ -2567,9 +2596,13 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                     w2 = cmul(cplx<double>{(double)c1l.re, -(double)c1l.im}, cplx<double>{(double)c2k.re, (double)c2k.im});
                 }
             }
+            cplx<double> wf = {1.0, 0.0};
+            if (a.wt_k >= 0)  // uniform: this member's height factor, applied before the conjugation
+                wf = wterm_factor(a.wt_k, a.wt_zc, a.wt_zh, sc * (neg ? -1.0 : 1.0) * (double)((const T *)a.wt_bz)[km]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double vr = o_re[r], vi = neg ? -o_im[r] : o_im[r];  // conj for flipped baselines
+                const double xr = o_re[r] * wf.re - o_im[r] * wf.im, xi = o_re[r] * wf.im + o_im[r] * wf.re;
+                const double vr = xr, vi = neg ? -xi : xi;  // conj for flipped baselines
                 cplx<T> *o = ob + a.out_pol_off[a.transpose_flipped && neg ? (r & 1) * 2 + (r >> 1) : r];
                 if (a.basis) {
                     const cplx<double> v1 = cmul(w1, cplx<double>{vr, vi});
@@ -2660,6 +2693,13 @@ struct BasisTerm {
     const int *ant1, *ant2;  // device (nbls) antenna index of each baseline
     int kk, ll, nbasis, nfreq, f_first;
     int part = 0, negate = 0;  // InterpArgs::basis_part / negate_all
+};
+
+// Height term handed to Nufft3::interp (InterpArgs::wt_*)
+struct WTerm {
+    int k;
+    double zc, zh;
+    const void *bz;
 };
 
 inline bool rowfft_uses_st(const DimGeom &g, bool col);
@@ -2830,7 +2870,10 @@ class Nufft3 {
     int order_n = 0;
     int64_t order_cells = 0;  // cells of A per transform that the spread writes and the first pass reads (2-D)
     double disc_radius = 0.0;
-    static constexpr double disc_margin() { return sizeof(T) == 4 ? 1e-5 : 1e-9; }  // rounding of the callers' unit vectors
+    // rounding of the callers' unit vectors: fp64 runs are also handed vectors that were computed in float32 (a coord_mgr
+    // or catalog_device of single-precision arrays: norms off by 6e-8), so the fp64 margin is 1e-6 too -- 0.002 cells
+    // at the rim of the largest grids, not a block more
+    static constexpr double disc_margin() { return sizeof(T) == 4 ? 1e-5 : 1e-6; }
     void build_block_order() {
         const int nbx = geo.nbin[0], nby = geo.nbin[1], ngx = (int)cdiv(nbx, 4);
         const bool disc = disc_radius > 0.0 && dim == 2 && rowfft_uses_st(geo.d[0], false);  // (the LDS kernel reads whole rows)
@@ -3157,7 +3200,8 @@ class Nufft3 {
                 const signed char *flip, const double *scale_dev, int nfg, int tpol,
                 cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                 const int64_t *out_pol_off, bool accumulate, const struct BasisTerm *basis = nullptr,
-                int herm = 0, const int *ustart = nullptr, int64_t nuniq = 0, const int *upairs = nullptr);
+                int herm = 0, const int *ustart = nullptr, int64_t nuniq = 0, const int *upairs = nullptr,
+                const struct WTerm *wt = nullptr);
 
    private:
     void rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const cplx<T> *twd,
@@ -3632,7 +3676,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
                        const signed char *flip, const double *scale_dev, int nfg, int tpol,
                        cplx<T> *out, int64_t out_fg_stride, int64_t out_k_stride,
                        const int64_t *out_pol_off, bool accumulate, const BasisTerm *basis, int herm,
-                       const int *ustart, int64_t nuniq, const int *upairs) {
+                       const int *ustart, int64_t nuniq, const int *upairs, const WTerm *wt) {
     if (N == 0 || nfg == 0) return;
     FV_REQUIRE(!upairs || (herm && ustart), "paired runs: packed gathers over run lists");
     if (ustart) N = nuniq;  // items are the distinct targets; bl_idx / flip stay the caller's full list
@@ -3691,6 +3735,14 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     }
     a.herm = herm;
     a.transpose_flipped = transpose_flipped ? 1 : 0;
+    a.wt_k = -1;
+    if (wt) {
+        FV_REQUIRE(dim == 2 && wt->bz && wt->k >= 0, "height terms ride on 2-D transforms");
+        a.wt_k = wt->k;
+        a.wt_zc = wt->zc;
+        a.wt_zh = wt->zh;
+        a.wt_bz = wt->bz;
+    }
     const int64_t items = N * nfg;
     constexpr int IPW = INTERP_THREADS / GROUP;
     a.items_per_xcd = cdiv(cdiv(items, 8), IPW) * IPW;  // whole workgroups

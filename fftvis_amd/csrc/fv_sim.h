@@ -514,6 +514,10 @@ struct StrengthArgs {
     double h[3], btc[3];
     int na[3];
     BeamDesc bi, bj;
+    // height term k of a nearly flat array (Sim::run): strengths times ((z - wt_zc) wt_inv)^k, z = the sources' third
+    // coordinate (compacted order).  A real factor: the Hermitian / all-real packings stay what they are.  wt_k <= 0: none.
+    int wt_k;
+    double wt_zc, wt_inv;
 };
 
 // Strengths of compacted source jc at catalog frequency fidx for one beam pair, times `pre`:
@@ -579,7 +583,7 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const in
                             const int *__restrict__ src_idx, const T *__restrict__ az,
                             const T *__restrict__ za, const void *__restrict__ flux,
                             const double *__restrict__ freqs, const int *__restrict__ i0s,
-                            const T *__restrict__ fs, cplx<T> *__restrict__ cs) {
+                            const T *__restrict__ fs, cplx<T> *__restrict__ cs, const T *__restrict__ zsrc) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= min((int64_t)*Mp, a.M) * a.nfg) return;
     const int64_t p = idx / a.nfg;
@@ -594,7 +598,14 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const in
     cplx<double> pre = {1.0, 0.0};
     if (dot != 0.0) sincos(freqs[fidx] * dot, &pre.im, &pre.re);
     const int tp = a.herm ? 2 : a.polarized ? 4 : 1;
-    strength_eval<T, ORD>(a, perm[p], fidx, pre, src_idx, az, za, flux, freqs, cs + (p * a.nfg + fgi) * tp);
+    cplx<T> *dst = cs + (p * a.nfg + fgi) * tp;
+    strength_eval<T, ORD>(a, perm[p], fidx, pre, src_idx, az, za, flux, freqs, dst);
+    if (a.wt_k > 0) {  // uniform
+        const double t = ((double)zsrc[perm[p]] - a.wt_zc) * a.wt_inv;
+        double sc = t;
+        for (int i = 1; i < a.wt_k; ++i) sc *= t;
+        for (int r = 0; r < tp; ++r) dst[r] = {(T)((double)dst[r].re * sc), (T)((double)dst[r].im * sc)};
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1006,6 +1017,7 @@ class Sim : public SimBase {
         std::unique_ptr<DevBuf> ustart, upairs;  // run starts; (packed runs) pairs of runs b / -b that share one gather item
         int64_t nu = 0, nitems = 0;               // runs; gather items (= runs unless paired)
         double utol = -1.0;
+        int udims = 3;  // components compared when runs were built (2 under height terms: b_z is per member there)
         int upairs_herm = -1;
         double btc[3], B[3];   // tight box of its (sign-adjusted) baselines: centre, half-width [s]
         double Bs[3];          // half-width of the box made symmetric about 0
@@ -1084,6 +1096,18 @@ class Sim : public SimBase {
     double spread_timed = 0;
 
     int dim() const { return coplanar ? 2 : 3; }
+    // Height terms ("w-term expansion", run()): a non-coplanar array whose heights are small against the wavelength --
+    // every surveyed real array: centimetres to decimetres after the plane fit -- does not need a third grid dimension.
+    // exp(i z s_z), z the sources' height coordinate in [zc - zh, zc + zh], s_z = nu b_z, is expanded about zc:
+    //     V(s) = sum_k  exp(i zc s_z) (i zh s_z)^k / k!  F_k(s_x, s_y),   F_k = 2-D transform of c_j ((z_j - zc) / zh)^k,
+    // K terms with (zh |s_z|)^K / K! <= eps / 10: K 2-D transforms (8 for 3 cm of scatter at 200 MHz) with all of the 2-D
+    // machinery (Hermitian packing, column plan, source disc) instead of a 3-D grid whose third dimension is all kernel
+    // width (16 planes for a source range of 1.4 cells) plus a z-pass.  The terms carry the transform's relative error
+    // each, summed with weights a^k / k!: the 2-D plans run at eps / e^a.  Taken while K <= 16 (|b_z| up to metres);
+    // beyond, or with FFTVIS_HIP_NO_WTERM=1, the 3-D transform runs.
+    int wt_K = 0;   // terms of the current run (0: no expansion)
+    double wt_zc = 0.0, wt_zh = 0.0, wt_a = 0.0;
+    int run_D = 2;  // dimensions of the current run's transforms
 
     size_t ev_slot(int kind) {
         if (ev_used == ev_pool.size()) {
@@ -1419,8 +1443,10 @@ class Sim : public SimBase {
     void build_unique(Pair &p, double tol) {
         const bool off = std::getenv("FFTVIS_HIP_NO_TARGET_DEDUP") != nullptr;  // read per run: tests flip it
         if (off) tol = -2.0;
-        if (p.utol == tol) return;
+        const int nd = wt_K ? 2 : 3;  // height terms: a run shares (u, v) only, every member brings its own b_z
+        if (p.utol == tol && p.udims == nd) return;
         p.utol = tol;
+        p.udims = nd;
         p.ustart.reset();
         p.upairs.reset();
         p.upairs_herm = -1;  // (pair_mirror_runs starts over on the new runs)
@@ -1433,7 +1459,7 @@ class Sim : public SimBase {
         for (int64_t k = 1; k < p.n; ++k) {
             const int64_t k0 = st.back();
             bool same = true;
-            for (int d = 0; d < 3 && same; ++d) same = std::fabs(comp(k, d) - comp(k0, d)) <= tol;
+            for (int d = 0; d < nd && same; ++d) same = std::fabs(comp(k, d) - comp(k0, d)) <= tol;
             if (!same) st.push_back((int)k);
         }
         st.push_back((int)p.n);
@@ -1450,8 +1476,9 @@ class Sim : public SimBase {
     // to 4 tol (the 27 neighbouring cells are searched: either vector may sit next to a rounding boundary).
     void pair_mirror_runs(Pair &p, double tol) {
         const bool want = p.herm != 0 && p.ustart && tol > 0.0 && !std::getenv("FFTVIS_HIP_NO_TARGET_PAIRS");
-        if (p.upairs_herm == (want ? 1 : 0)) return;
-        p.upairs_herm = want ? 1 : 0;
+        const int nd = p.udims;
+        if (p.upairs_herm == (want ? nd : 0)) return;
+        p.upairs_herm = want ? nd : 0;
         p.upairs.reset();
         p.nitems = p.nu;
         ++targets_serial;
@@ -1470,21 +1497,22 @@ class Sim : public SimBase {
         };
         std::unordered_map<Key, int, Hash> at;
         at.reserve((size_t)p.nu * 2);
-        for (int64_t u = 0; u < p.nu; ++u) at[Key{(int64_t)std::llround(vec(u, 0) / q), (int64_t)std::llround(vec(u, 1) / q), (int64_t)std::llround(vec(u, 2) / q)}] = (int)u;
+        auto cell2 = [&](double v) { return nd > 2 ? (int64_t)std::llround(v / q) : (int64_t)0; };
+        for (int64_t u = 0; u < p.nu; ++u) at[Key{(int64_t)std::llround(vec(u, 0) / q), (int64_t)std::llround(vec(u, 1) / q), cell2(vec(u, 2))}] = (int)u;
         std::vector<int> partner((size_t)p.nu, -1), items;
         for (int64_t u = 0; u < p.nu; ++u) {
             if (partner[u] >= 0) continue;
-            const int64_t k0 = std::llround(-vec(u, 0) / q), k1 = std::llround(-vec(u, 1) / q), k2 = std::llround(-vec(u, 2) / q);
+            const int64_t k0 = std::llround(-vec(u, 0) / q), k1 = std::llround(-vec(u, 1) / q), k2 = cell2(-vec(u, 2));
             int best = -1;
             for (int da = -1; da <= 1 && best < 0; ++da)
                 for (int db = -1; db <= 1 && best < 0; ++db)
-                    for (int dc = -1; dc <= 1 && best < 0; ++dc) {
+                    for (int dc = (nd > 2 ? -1 : 0); dc <= (nd > 2 ? 1 : 0) && best < 0; ++dc) {
                         auto it = at.find(Key{k0 + da, k1 + db, k2 + dc});
                         if (it == at.end()) continue;
                         const int v = it->second;
                         if (v == (int)u || partner[v] >= 0) continue;
                         bool same = true;
-                        for (int d = 0; d < 3 && same; ++d) same = std::fabs(vec(v, d) + vec(u, d)) <= tol;
+                        for (int d = 0; d < nd && same; ++d) same = std::fabs(vec(v, d) + vec(u, d)) <= tol;
                         if (same) best = v;
                     }
             if (best >= 0) {
@@ -1711,6 +1739,7 @@ class Sim : public SimBase {
         // is touched in parallel and pinned while the kernels run (HostPin), then one copy at PCIe rate (0.72 -> 0.3 s)
         const bool drain = !out_on_device && out_bytes >= drain_min_bytes();
         HostPin pin;
+        pin.drain_on = &stream;  // copy_block_pinned below rides on the main stream
         if (drain) pin.start(device, out, out_bytes);
         const double sigma = this->sigma == 0.0 ? 2.0 : this->sigma;  // "auto" is a type-3 matter
         sigma_run = sigma;
@@ -1999,6 +2028,7 @@ class Sim : public SimBase {
         std::atomic<int> state{0};  // 0 pinning, 1 pinned, -1 refused (locked-memory limit, exotic mapping)
         std::vector<std::pair<char *, size_t>> pieces;  // registered so far (helper thread only, until joined)
         double t_pinned = 0;  // seconds after start() (FFTVIS_HIP_DEBUG_DRAIN)
+        hipStream_t *drain_on = nullptr;  // the stream copies into the pinned pieces are queued on (the owner's copy stream)
         std::chrono::steady_clock::time_point t0;
         double since() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
         // Pinning a FRESH array is slow because every page is touched for the first time inside the call, by one thread
@@ -2032,16 +2062,28 @@ class Sim : public SimBase {
                     for (std::thread &t : pool) t.join();
                 }
                 bool ok = true;
+                // FFTVIS_HIP_PIN_FAIL_AFTER = n (tests): the (n + 1)-th registration is refused
+                const char *ef = std::getenv("FFTVIS_HIP_PIN_FAIL_AFTER");
+                const long fail_after = ef ? std::atol(ef) : -1;
                 while (ok && p < end) {
                     const uintptr_t stop = (reinterpret_cast<uintptr_t>(p) / PIECE + 1) * PIECE;
                     char *q = std::min(end, reinterpret_cast<char *>(stop));
-                    if (hipHostRegister(p, (size_t)(q - p), hipHostRegisterDefault) == hipSuccess) {
+                    if ((fail_after < 0 || (long)pieces.size() < fail_after) &&
+                        hipHostRegister(p, (size_t)(q - p), hipHostRegisterDefault) == hipSuccess) {
                         pieces.push_back({p, (size_t)(q - p)});
                         p = q;
                     } else {
                         (void)hipGetLastError();
                         ok = false;
                     }
+                }
+                if (!ok) {
+                    // refused part-way (locked-memory limit): the caller's array must not stay HALF pinned -- the fallback
+                    // is ONE pageable copy over the whole range, and a range that is part registered, part pageable may be
+                    // taken for pinned as a whole.  Nothing has been copied into the pieces yet (copies are only queued
+                    // once state is 1), so they are simply released before the refusal is published.
+                    for (auto &pc : pieces) (void)hipHostUnregister(pc.first);
+                    pieces.clear();
                 }
                 t_pinned = since();
                 state.store(ok ? 1 : -1, std::memory_order_release);
@@ -2054,6 +2096,8 @@ class Sim : public SimBase {
         }
         ~HostPin() {  // also on the error paths: never leave the caller's memory pinned
             if (th.joinable()) th.join();
+            // an exception may unwind past copies that are still in flight into the pieces: they end first
+            if (!pieces.empty() && drain_on && *drain_on) (void)hipStreamSynchronize(*drain_on);
             for (auto &pc : pieces) (void)hipHostUnregister(pc.first);
         }
     };
@@ -2111,7 +2155,34 @@ class Sim : public SimBase {
             return;
         }
         const int nt = t1 - t0, nf = f1 - f0;
-        const int D = dim();
+        // height terms instead of a third grid dimension (see wt_K)
+        double xc[3], X[3];
+        source_box(xc, X);
+        wt_K = 0;
+        wt_a = 0.0;
+        if (!coplanar && !std::getenv("FFTVIS_HIP_NO_WTERM")) {
+            double fmax = 0, bz = 0;
+            for (int f = f0; f < f1; ++f) fmax = std::max(fmax, std::fabs(freqs[f]));
+            for (const Pair &p : pairs)
+                if (p.n) bz = std::max(bz, p.Bs[2]);
+            const double a = X[2] * fmax * bz;  // largest |(z - zc) s_z|
+            int K = 1;
+            double term = a;  // a^K / K!
+            while (term > 0.1 * eps && K < 64) {
+                ++K;
+                term *= a / K;
+            }
+            const char *ek = std::getenv("FFTVIS_HIP_WTERM_MAX");
+            if (K <= (ek ? std::atoi(ek) : 16)) {
+                wt_K = K;
+                wt_zc = xc[2];
+                wt_zh = X[2];
+                wt_a = a;
+            }
+        }
+        const int D = wt_K ? 2 : dim();
+        run_D = D;
+        st[15] = wt_K;
         const int64_t per_tf = (int64_t)tpol * nbls;   // elements per (freq, time)
         const size_t out_bytes = sizeof(cplx<T>) * (size_t)nf * nt * per_tf;
         cplx<T> *dout;
@@ -2130,6 +2201,7 @@ class Sim : public SimBase {
         // the helper touches and pins the caller's array once the first unit is queued: started at once, its sixteen page-
         // faulting threads slowed the main thread's set-up and first launches (first unit queued after 95 ms instead of 50)
         HostPin pin;
+        pin.drain_on = &copy_stream;
         pin.mark();
         bool pin_started = false;
         static const bool pin_early = std::getenv("FFTVIS_HIP_PIN_EARLY") != nullptr;
@@ -2138,8 +2210,6 @@ class Sim : public SimBase {
             pin_started = true;
         }
 
-        double xc[3], X[3];
-        source_box(xc, X);
         int64_t pol_off[16] = {0};
         if (polarized)
             for (int r = 0; r < 4; ++r) pol_off[r] = (int64_t)((r % 2) * 2 + r / 2) * nbls;
@@ -2297,8 +2367,11 @@ class Sim : public SimBase {
         }
         for (int li = 0; li < nlanes_used; ++li) {
             Lane &L = lanes[li];
-            if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma)
-                L.nufft.reset(new Nufft3<T>(D, eps, sigma, li < 2 ? L.stream : stream));
+            // height terms: term k enters with weight a^k / k!, each with the transform's relative error -- the plans run
+            // at eps / e^a so that the sum keeps eps
+            const double eps_plan = wt_K ? std::max(eps * std::exp(-wt_a), sizeof(T) == 8 ? 1e-14 : 1e-7) : eps;
+            if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma || L.nufft->eps != eps_plan)
+                L.nufft.reset(new Nufft3<T>(D, eps_plan, sigma, li < 2 ? L.stream : stream));
             L.nufft->err_oob = d_err.as<int>();
             // the sources are 2 pi x (projections of unit vectors onto the array plane): inside a disc whatever the box
             L.nufft->disc_radius = D == 2 && !std::getenv("FFTVIS_HIP_NO_DISC") ? 2.0 * M_PI : 0.0;
@@ -2475,6 +2548,9 @@ class Sim : public SimBase {
                     if (pr.n == 0) continue;
                     const int tg = pr.herm ? 2 : tpol;  // transforms per frequency on the grid
                     const int ntrans = nfg * tg;
+                    // height terms (wt_K): one round of strengths -> spread -> FFT -> gather per term, the gather adding
+                    // term k with every baseline's own factor; otherwise a single round
+                    for (int kt = 0; kt < std::max(1, wt_K); ++kt) {
                     for (int m = 0; m < nm; ++m) {
                         Lane &L = *Ls[m];
                         Nufft3<T> *nf_ = L.nufft.get();
@@ -2494,8 +2570,8 @@ class Sim : public SimBase {
                         }
                         ev_end(e1, ls);
                         // ---- strengths (already queued with the preparation for the first pair) -------
-                        if (!(strengths_ahead && &grp == &groups.front() && &pr == first_pair))
-                            launch_strengths(L, pr, fa, nfg, M, Mps[m], ls);
+                        if (!(strengths_ahead && &grp == &groups.front() && &pr == first_pair && kt == 0))
+                            launch_strengths(L, pr, fa, nfg, M, Mps[m], ls, kt);
                     }
                     // ---- NUFFT ----------------------------------------------------------
                     {
@@ -2515,7 +2591,7 @@ class Sim : public SimBase {
                         const size_t e3 = ev_slot(TM_SPREAD);
                         nufft->spread(ntrans, ev_pool[e3].a, ev_pool[e3].b, mate);
                         spread_timed += nm;  // a gang launch serves nm time steps: counted per time step
-                    } else if (ride_heavy_done && pipe && &grp == &groups.back() && &pr == last_pair) {
+                    } else if (ride_heavy_done && pipe && &grp == &groups.back() && &pr == last_pair && kt + 1 >= std::max(1, wt_K)) {
                         // the unit's last spread is the last reader of the lanes' per-time arrays (the FFT
                         // passes and the gather work on the grids): its dispatch carries the "lane scratch
                         // is free" event, which saves the main stream a marker packet per unit
@@ -2532,7 +2608,7 @@ class Sim : public SimBase {
                     // small 2-D grids: the last FFT pass serves the targets from its LDS tiles (no C
                     // buffer, no gather kernel); the output block was zeroed at the start of the run
                     const bool fused =
-                        !nbasis && !pr.herm &&
+                        !nbasis && !pr.herm && !wt_K &&
                         nufft->prepare_fused_gather(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
                                                     pr.trivial ? nullptr : pr.idx->template as<int>(),
                                                     pr.trivial ? nullptr : pr.flip->template as<signed char>(),
@@ -2554,6 +2630,7 @@ class Sim : public SimBase {
                     // exact eigenbeam symmetry (reference_compat off): the (l, k) term of an off-diagonal pair of
                     // complex basis beams comes from a second gather at -b (all-real pairs: packed, exact already)
                     const int nparts = nbasis && !reference_compat && pr.bi != pr.bj && !pr.herm ? 2 : 1;
+                    const WTerm wterm{kt, wt_zc, wt_zh, (const void *)(d_bls.as<T>() + 2 * nbls)};
                     if (!fused)
                         for (int m = 0; m < nm; ++m)
                             for (int part = 1; part <= nparts; ++part) {
@@ -2564,16 +2641,19 @@ class Sim : public SimBase {
                                       pr.trivial ? nullptr : pr.idx->template as<int>(),
                                       pr.trivial ? nullptr : pr.flip->template as<signed char>(),
                                       d_freqs.as<double>() + fa, nfg, tg, obase + (int64_t)m * per_tf,
-                                      (int64_t)nt * per_tf, 1, pol_off, accumulate, nbasis ? &bt : nullptr, pr.herm,
+                                      (int64_t)nt * per_tf, 1, pol_off, accumulate || kt > 0, nbasis ? &bt : nullptr, pr.herm,
                                       pr.ustart ? pr.ustart->template as<int>() : nullptr, pr.upairs ? pr.nitems : pr.nu,
-                                      pr.upairs ? pr.upairs->template as<int>() : nullptr);
+                                      pr.upairs ? pr.upairs->template as<int>() : nullptr, wt_K ? &wterm : nullptr);
                             }
                     ev_end(e5, ls);
                     st[4] += (double)(pr.upairs ? pr.nitems : pr.ustart ? pr.nu : pr.n) * ntrans * nm * (pr.herm ? 2 : 1);  // footprints gathered: distinct targets; packed transforms are read at s and -s
                     st[6] = nufft->geo.d[0].n2;
                     st[7] = nufft->geo.d[1].n2;
                     st[8] = nufft->geo.d[0].na * 65536.0 + nufft->geo.d[1].na;
+                    st[13] = D > 2 ? nufft->geo.d[2].n2 : 1;
+                    st[14] = D > 2 ? nufft->geo.d[2].na : 1;
                     st[9] = nufft->ker.w;
+                    }  // height terms
                 }
             }
             if (pipe) {
@@ -2624,9 +2704,9 @@ class Sim : public SimBase {
     }
 
     // beam x coherency strengths of one (frequency group, beam pair) for the lane's current sources
-    void launch_strengths(Lane &L, const Pair &pr, int fa, int nfg, int64_t M, const int *Mp, hipStream_t on) {
+    void launch_strengths(Lane &L, const Pair &pr, int fa, int nfg, int64_t M, const int *Mp, hipStream_t on, int wt_k = 0) {
         Nufft3<T> *nufft = L.nufft.get();
-        const int D = dim();
+        const int D = run_D;
         RoctxRange rr("strengths");
         size_t e2 = ev_begin(TM_STRENGTHS, on);
         StrengthArgs sa{};
@@ -2647,12 +2727,16 @@ class Sim : public SimBase {
         }
         sa.bi = desc(pr.bi);
         sa.bj = desc(pr.bj);
+        sa.wt_k = wt_K ? wt_k : 0;
+        sa.wt_zc = wt_zc;
+        sa.wt_inv = wt_zh > 0 ? 1.0 / wt_zh : 0.0;
         cplx<T> *cs = nufft->strengths_buffer(nfg * (pr.herm ? 2 : tpol));
         hipLaunchKernelGGL((beam_order == 3 ? k_strengths<T, 3> : k_strengths<T, 1>),
                            dim3(cdiv((int64_t)M * nfg, 256)), dim3(256), 0, on, sa, Mp,
                            nufft->perm.template as<int>(), L.d_srcidx.template as<int>(),
                            L.d_az.template as<T>(), L.d_za.template as<T>(), d_flux.p, d_freqs.as<double>(),
-                           nufft->i0s.template as<int>(), nufft->fs.template as<T>(), cs);
+                           nufft->i0s.template as<int>(), nufft->fs.template as<T>(), cs,
+                           (const T *)(L.d_xyz.template as<T>() + 2 * M));
         ev_end(e2, on);
     }
 

@@ -63,12 +63,18 @@ def release_handles():
 def _acquire_handle(device, precision, eps, upsample_factor, polarized):
     key = (int(device), int(precision), float(eps), str(upsample_factor), bool(polarized))
     h = _IDLE_HANDLES.pop(key, None)
+    # the other idle handles of this device hold memory that wrapper.device_memory_budget counts as the run's:
+    # released now (a matching handle's buffers are reused instead), as is the stand-alone NUFFT workspace on a miss
+    for k in [k for k in _IDLE_HANDLES if k[0] == key[0]]:
+        _IDLE_HANDLES.pop(k).close()
+    if h is None and _lib._lib is not None:
+        _lib._lib.fv_release_workspaces()
     return key, (h if h is not None else SimHandle(device, precision, eps, upsample_factor, polarized))
 
 
 def _return_handle(key, h):
     held = ctypes.c_int64(0)
-    _lib.check(_lib.lib().fv_device_bytes(ctypes.byref(held)))
+    _lib.check(_lib.lib().fv_device_bytes_on(key[0], ctypes.byref(held)))
     limit = _cache_limit(key[0])
     if limit <= 0 or held.value > limit:
         h.close()
@@ -214,10 +220,12 @@ class SimHandle:
         _lib.check(self._L.fv_sim_sync(self._h))
 
     def stats(self):
-        v = np.zeros(13)
-        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 13))
+        v = np.zeros(16)
+        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 16))
+        # ("n2z" is historical: active cells na_x * 65536 + na_y; the third dimension's sizes are n2_3 / na_3)
         keys = ["spread_launches", "spread_cells", "source_visits", "fft_cells", "interp_items",
-                "sources_above_horizon", "n2x", "n2y", "n2z", "w", "upsample_used", "max_above_horizon", "fft_flops"]
+                "sources_above_horizon", "n2x", "n2y", "n2z", "w", "upsample_used", "max_above_horizon", "fft_flops",
+                "n2_3", "na_3", "height_terms"]
         return dict(zip(keys, v))
 
     def reset_stats(self):
@@ -234,20 +242,29 @@ class SimHandle:
 
 def register_with_reference() -> bool:
     """Make ``isinstance(engine, fftvis.core.simulate.SimulationEngine)`` hold where the reference is
-    installed (virtual-subclass registration on its ABC, core/simulate.py:22).  Called at import; the stub
-    module of INTEGRATION.md, route A, may call it again once ``fftvis.core`` is importable."""
+    installed (virtual-subclass registration on its ABC, core/simulate.py:22).  Lazy: importing this module
+    registers only if ``fftvis.core.simulate`` is ALREADY imported (importing the reference pulls in finufft,
+    matvis, astropy and pyuvdata -- seconds, for an ``ABC.register``), the first ``GPUSimulationEngine()`` tries
+    again if the caller has imported ``fftvis`` since, and the stub module of INTEGRATION.md, route A, calls this
+    function itself (which does import ``fftvis.core.simulate``).  Only a missing reference is swallowed: any other
+    error of that import is the caller's to see."""
+    global _REGISTERED
     import sys
 
-    try:
-        mod = sys.modules.get("fftvis.core.simulate")
-        if mod is None:
-            import importlib
+    mod = sys.modules.get("fftvis.core.simulate")
+    if mod is None:
+        import importlib
 
+        try:
             mod = importlib.import_module("fftvis.core.simulate")
-        mod.SimulationEngine.register(GPUSimulationEngine)
-        return True
-    except Exception:  # the reference (or one of its dependencies) is not installed
-        return False
+        except ImportError:  # the reference (or one of its dependencies) is not installed
+            return False
+    mod.SimulationEngine.register(GPUSimulationEngine)
+    _REGISTERED = True
+    return True
+
+
+_REGISTERED = False
 
 
 def prepare_array(ants: dict, baselines, flat_array_tol: float, real_dtype):
@@ -269,6 +286,10 @@ class GPUSimulationEngine(SimulationEngine):
     """MI355X implementation of the simulation engine."""
 
     def __init__(self, device: int = 0):
+        import sys
+
+        if not _REGISTERED and "fftvis" in sys.modules:  # the caller uses the reference: be an instance of ITS ABC
+            register_with_reference()
         self.device = device
 
     def simulate(
@@ -601,4 +622,5 @@ def _time_block(device, nt, nf, nbls, polarized, precision, nsrc_topo=0):
     return min(n, max(nt, 1))
 
 
-register_with_reference()
+if "fftvis.core.simulate" in __import__("sys").modules:
+    register_with_reference()

@@ -56,9 +56,33 @@ def hera_like_array(kind: str) -> dict:
                     ring.append((big * (q + 0.5 * rr), big * (np.sqrt(3) / 2) * rr, 0.0))
         pos = np.vstack([core, np.array(ring)])
         assert len(pos) == 350
+    elif kind == "scattered350":
+        # 350 antennas drawn uniformly inside the convex hull of hera350 (seeded): the same extent and
+        # baseline count, NO repeated baseline vectors and no lattice -- the generic type-3 workload
+        # (finufft's nufft2d3 contract has no lattice in it, reference cpu/nufft.py:48-59)
+        ref = np.array(list(hera_like_array("hera350").values()))
+        from scipy.spatial import Delaunay
+
+        hull = Delaunay(ref[:, :2])
+        rng = np.random.default_rng(350)
+        lo, hi = ref[:, :2].min(0), ref[:, :2].max(0)
+        pts = np.empty((0, 2))
+        while len(pts) < 350:
+            cand = rng.uniform(lo, hi, size=(1024, 2))
+            pts = np.vstack([pts, cand[hull.find_simplex(cand) >= 0]])
+        pos = np.column_stack([pts[:350], np.zeros(350)])
     else:
         raise ValueError(kind)
     return {i: p for i, p in enumerate(pos)}
+
+
+def with_z_scatter(ants: dict, sigma_m: float = 0.03, seed: int = 7) -> dict:
+    """The same array with a seeded Gaussian height scatter (metres) about its plane: |b_z| then exceeds
+    the reference's flat_array_tol = 1e-6 m (cpu_simulate.py:655), so the run takes the 3-D transform
+    (cpu/nufft.py:62-118) -- every surveyed real array does."""
+    rng = np.random.default_rng(seed)
+    dz = rng.normal(0.0, sigma_m, len(ants))
+    return {k: np.array([p[0], p[1], p[2] + dz[i]]) for i, (k, p) in enumerate(ants.items())}
 
 
 def all_cross_baselines(ants: dict):
@@ -112,12 +136,16 @@ CONFIGS = {
 C5_NBASIS = 4
 
 
-def make_config(name: str, seed: int = 0, nsrc=None, nfreq=None, ntimes=None):
+def make_config(name: str, seed: int = 0, nsrc=None, nfreq=None, ntimes=None, array=None, z_scatter: float = 0.0):
     """Inputs of one BASELINE.json configuration as a dict of simulate_vis keyword arguments
-    (optionally shrunk for tests)."""
+    (optionally shrunk for tests).  ``array`` replaces the configuration's layout (``"scattered350"``:
+    no lattice, no repeated baseline vectors); ``z_scatter`` > 0 adds a seeded height scatter of that many
+    metres (non-coplanar: the 3-D transform)."""
     arr, ns, nf, nt, pol, beamkind = CONFIGS[name]
     ns, nf, nt = nsrc or ns, nfreq or nf, ntimes or nt
-    ants = hera_like_array(arr)
+    ants = hera_like_array(array or arr)
+    if z_scatter > 0:
+        ants = with_z_scatter(ants, z_scatter)
     freqs = np.linspace(100e6, 200e6, nf)
     times = np.linspace(2459845.0, 2459845.05, nt)
     ra, dec, flux = catalog(ns, freqs, seed)

@@ -42,17 +42,19 @@ def create_simulation_engine(backend: str = "gpu", **kwargs) -> SimulationEngine
 
 def device_memory_budget(device: int) -> int:
     """Bytes a run on ``device`` may plan with: what the device reports free PLUS what this process's own
-    cached handles and NUFFT workspaces hold (``fv_device_bytes``) -- the next run reuses or replaces those,
-    so counting them as taken would shrink the budget after every large run (more source chunks, smaller time
-    blocks, results differing at rounding level) although nothing else is using the memory.  The reference
-    measures available host RAM (wrapper.py:292-302), which has no such self-accounting."""
+    cached handle and NUFFT workspaces hold ON THAT DEVICE (``fv_device_bytes_on``) -- the next run reuses that
+    handle's buffers or, if it needs another handle, releases them first (``_acquire_handle`` closes the idle
+    handles of the device on a miss), so counting them as taken would shrink the budget after every large run
+    (more source chunks, smaller time blocks, results differing at rounding level) although nothing else is
+    using the memory.  Memory held on other devices is not this device's to give.  The reference measures
+    available host RAM (wrapper.py:292-302), which has no such self-accounting."""
     import ctypes
 
     from . import _lib
 
     free, total, held = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
     _lib.check(_lib.lib().fv_device_mem_info(int(device), ctypes.byref(free), ctypes.byref(total)))
-    _lib.check(_lib.lib().fv_device_bytes(ctypes.byref(held)))
+    _lib.check(_lib.lib().fv_device_bytes_on(int(device), ctypes.byref(held)))
     return int(min(total.value, free.value + max(held.value, 0)))
 
 

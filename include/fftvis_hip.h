@@ -29,6 +29,9 @@ extern "C" {
 int fv_version(void);                 /* 10000*major + 100*minor + patch */
 int fv_device_count(int *count);      /* number of visible HIP devices (0 on a CPU-only box) */
 int fv_device_bytes(int64_t *bytes);  /* device memory this process's handles hold right now (all devices) */
+/* ... and the share of it on `device`: what the next run there reuses (its cached handle's buffers) -- the term the
+ * host side adds to the free memory when it sizes chunks and blocks (wrapper.py:292-302 measures free host RAM).  */
+int fv_device_bytes_on(int device, int64_t *bytes);
 /* Free / total device memory of `device` (hipMemGetInfo): what the host side sizes its (time, frequency)
  * output blocks and source chunks against -- the device counterpart of the reference's
  * psutil.virtual_memory().available in simulate_vis (src/fftvis/wrapper.py:292-302).                 */
@@ -231,7 +234,10 @@ int fv_sim_sync(fv_sim *h);
  * [4] gathered footprints (targets x transforms, x 2 for packed transforms: read at s and -s), [5] above-horizon sources summed over times, [6] last n2x,
  * [7] last n2y, [8] last (na_x * 65536 + na_y), [9] kernel width w, [10] upsampling factor the
  * last run used, [11] largest above-horizon source count of any time step since the reset, [12] real flops of the FFT
- * passes priced as plain transforms (5 n2 log2 n2 per line transformed).   */
+ * passes priced as plain transforms (5 n2 log2 n2 per line transformed), [13] last n2 of the third dimension (1 for
+ * 2-D runs), [14] last na of the third dimension, [15] height terms of the last run (K > 0: a non-coplanar array ran
+ * as K 2-D transforms per slice, the expansion of exp(i z s_z) about the middle of the sources' height range; 0: no
+ * expansion -- coplanar, or the 3-D transform).   */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,

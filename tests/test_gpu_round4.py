@@ -1,0 +1,216 @@
+"""Round-4 GPU checks: the two new bench workloads (3-D transforms on a non-coplanar HERA-350, the generic
+type-3 engine on an array without a lattice) against the CPU oracle at full catalog size, the host-output
+fallback when the driver refuses to pin part of the caller's array, and fp32-rounded unit vectors at the
+horizon of an fp64 run.  Everything goes through the C ABI."""
+
+import os
+
+import numpy as np
+import pytest
+
+import fftvis_amd
+from fftvis_amd import synth
+from oracle import fftvis_oracle as orc
+from tests.helpers import oracle_simulate, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 5 * 6e-8
+
+
+def _top_of_band(cfg, nch):
+    """The last ``nch`` channels of a configuration (its largest grids), catalog and beam table cut to match."""
+    f = slice(len(cfg["freqs"]) - nch, len(cfg["freqs"]))
+    out = dict(cfg, freqs=cfg["freqs"][f], fluxes=cfg["fluxes"][:, f])
+    b = cfg["beam"]
+    out["beam"] = fftvis_amd.TabulatedBeam(b.data[f], cfg["freqs"][f])
+    return out
+
+
+def test_bench_workload_c3z_three_dimensional_transform_matches_the_oracle(gpu):
+    """`bench.py --workload C3z`: HERA-350 with a 3 cm height scatter -- |b_z| up to 0.17 m, far beyond the
+    reference's flat_array_tol (cpu_simulate.py:655), so the run takes the 3-D transform (cpu/nufft.py:62-118):
+    full catalog, all 61 075 baselines, the two top channels, one time; a random subset of baselines against the
+    oracle's exact sums (its non-coplanar branch), and the height scatter must matter at the tested accuracy."""
+    cfg = _top_of_band(synth.make_config("C3", ntimes=1, z_scatter=0.03), 2)
+    from fftvis_amd.gpu.gpu_simulate import prepare_array
+
+    _, bls, coplanar = prepare_array(cfg["ants"], cfg["baselines"], 1e-6, np.float64)
+    assert not coplanar and np.abs(bls[2]).max() * orc.speed_of_light > 0.1
+    v = fftvis_amd.simulate_vis(**cfg)
+    assert v.shape == (2, 1, 2, 2, 61075) and np.isfinite(v).all()
+    sub = sorted(np.random.default_rng(3).choice(61075, 16, replace=False))
+    sel = dict(cfg, baselines=[cfg["baselines"][i] for i in sub])
+    exact = oracle_simulate(sel)
+    assert rel_l2(v[..., sub], exact) < TOL
+    flat = oracle_simulate(dict(sel, ants={k: np.array([p[0], p[1], 0.0]) for k, p in cfg["ants"].items()}))
+    assert rel_l2(flat, exact) > 100 * TOL  # the z term is not noise
+
+
+def test_bench_workload_scattered_array_matches_the_oracle(gpu, monkeypatch):
+    """`bench.py --array scattered`: 350 antennas without a lattice -- every one of the 61 075 baseline vectors is
+    distinct, so the column plan keeps (nearly) every column and is not used, and no gather item serves two
+    baselines.  Full catalog, all baselines, two top channels, one time, against the oracle on a subset."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    cfg = _top_of_band(synth.make_config("C3", ntimes=1, array="scattered350"), 2)
+    a = np.array(list(cfg["ants"].values()))
+    d = (a[None, :, :2] - a[:, None, :2]).reshape(-1, 2)
+    d = d[np.abs(d).sum(1) > 0]
+    assert len(np.unique(np.round(d, 6), axis=0)) == len(d)  # no repeated baseline vector
+    gpu_simulate.release_handles()
+    monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+    v = fftvis_amd.simulate_vis(**cfg)
+    (h,) = gpu_simulate._IDLE_HANDLES.values()
+    st = h.stats()
+    # packed transforms are gathered at s and -s: 2 footprints per (baseline, transform) when nothing is shared
+    assert st["interp_items"] >= 0.99 * 2 * 61075 * 4, st
+    gpu_simulate.release_handles()
+    assert v.shape == (2, 1, 2, 2, 61075) and np.isfinite(v).all()
+    sub = sorted(np.random.default_rng(5).choice(61075, 16, replace=False))
+    exact = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
+    assert rel_l2(v[..., sub], exact) < TOL
+
+
+def test_partial_pin_refusal_leaves_nothing_pinned_and_the_result_intact(gpu, monkeypatch):
+    """the caller's array is pinned in 256-MiB pieces; a refusal after the first piece used to
+    leave that piece registered under ONE pageable copy of the whole range.  Forced here
+    (FFTVIS_HIP_PIN_FAIL_AFTER=1) on a 312-MB output that spans at least two pieces: the helper releases what it
+    registered, the fallback copy runs over plain pageable memory, and the block equals the pinned run's bit for bit
+    (large grids: no atomics anywhere)."""
+    cfg = synth.make_config("C3", nsrc=2000, nfreq=8, ntimes=10)
+    ref = fftvis_amd.simulate_vis(**cfg)
+    assert ref.nbytes > (256 << 20)  # more than one 256-MiB piece whatever the alignment
+    monkeypatch.setenv("FFTVIS_HIP_PIN_FAIL_AFTER", "1")
+    got = fftvis_amd.simulate_vis(**cfg)
+    monkeypatch.setenv("FFTVIS_HIP_PIN_FAIL_AFTER", "0")
+    got0 = fftvis_amd.simulate_vis(**cfg)
+    monkeypatch.delenv("FFTVIS_HIP_PIN_FAIL_AFTER")
+    assert np.array_equal(got, ref) and np.array_equal(got0, ref)
+    # the caller's memory is ordinary memory again: registering it anew must succeed piece by piece
+    assert np.array_equal(fftvis_amd.simulate_vis(**cfg), ref)
+
+
+def test_float32_rounded_unit_vectors_at_the_horizon_run_in_fp64(gpu):
+    """a coord_mgr whose vectors were computed in float32 has norms off by 6e-8; with sources at the
+    horizon their projections fall outside the unit disc by that much, which the source-disc pruning (margin 1e-9
+    then) took for out-of-box sources and failed the whole precision=2 run.  The margin is 1e-6 now."""
+    cfg = _top_of_band(synth.make_config("C3", nsrc=3000, ntimes=1), 1)
+
+    class Mgr:
+        def __init__(self):
+            self.o = orc.SimpleCoordinateRotation(None, cfg["times"], cfg["telescope_loc"], cfg["ra"], cfg["dec"])
+
+        def setup(self):
+            pass
+
+        def rotate(self, ti):
+            self.o.rotate(ti)
+            t = np.array(self.o._topo, dtype=np.float64)
+            ph = np.linspace(0, 2 * np.pi, 64, endpoint=False)
+            t[:, :64] = np.stack([np.cos(ph), np.sin(ph), np.full(64, 1e-9)])  # 64 sources on the horizon
+            self.all_coords_topo = t.astype(np.float32).astype(np.float64)
+
+    m = Mgr()
+    m.rotate(0)
+    r2 = (m.all_coords_topo[:2, :64] ** 2).sum(0)
+    assert (r2 > 1 + 4e-9).any()  # beyond the old margin
+    got = fftvis_amd.simulate_vis(**cfg, coord_mgr=Mgr())
+    assert np.isfinite(got).all()
+    sub = cfg["baselines"][::4000]
+    o = Mgr()
+
+    # the oracle with the very same vectors
+    class OMgr(orc.SimpleCoordinateRotation):
+        def rotate(self, ti):
+            super().rotate(ti)
+            o.rotate(ti)
+            self._topo = o.all_coords_topo
+
+    beams = [orc.TabulatedBeam(cfg["beam"].data, cfg["freqs"], cfg["beam"].za_max, "efield", 1)]
+    coh, pol_sky = orc.prepare_source_catalog(cfg["fluxes"], True)
+    exact = orc.simulate(cfg["ants"], cfg["freqs"], cfg["fluxes"], beams, cfg["ra"], cfg["dec"], cfg["times"],
+                         cfg["telescope_loc"], baselines=sub, polarized=True, force_use_type3=True,
+                         coord_mgr=OMgr(coh, cfg["times"], cfg["telescope_loc"], cfg["ra"], cfg["dec"]))
+    idx = [cfg["baselines"].index(b) for b in sub]
+    assert rel_l2(got[..., idx], exact) < TOL
+
+
+def _last_handle_stats():
+    from fftvis_amd.gpu import gpu_simulate
+
+    (h,) = gpu_simulate._IDLE_HANDLES.values()
+    return h.stats()
+
+
+def _height_cases():
+    c = synth.make_config("C2", nsrc=700, nfreq=3, ntimes=2)
+    ants = synth.with_z_scatter(c["ants"], 0.05, seed=3)
+    freqs = c["freqs"]
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=46, naz=90), freqs)
+    tab2 = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, diameter=12.0, nza=46, naz=90), freqs)
+    _, _, fl4 = synth.catalog(700, freqs, 0, polarized_sky=True)
+    nant = len(ants)
+    bidx = np.arange(nant) % 2
+    keys = list(ants)
+    bls = c["baselines"][::5] + [(keys[5], keys[1]), (keys[30], keys[2]), (keys[4], keys[4])]  # flipped pairs, an auto
+    rng = np.random.default_rng(12)
+    coefs = rng.normal(size=(nant, 2, len(freqs))) + 1j * rng.normal(size=(nant, 2, len(freqs)))
+    base = dict(c, ants=ants)
+    return {
+        "unpolarized_airy": base,
+        "polarized_table": dict(base, polarized=True, beam=tab),
+        "two_beams_flipped_polarized_sky": dict(base, polarized=True, beam=[tab, tab2], beam_idx=bidx, baselines=bls, fluxes=fl4),
+        "source_chunks": dict(base, min_chunks=3),
+        "eigenbeams": dict(base, polarized=True, beam=[tab, tab2], beam_coefs=coefs, baselines=bls),
+        "fp32": dict(base, precision=1, eps=1e-4),
+        "default_baselines": dict(base, baselines=None),
+    }
+
+
+@pytest.mark.parametrize("name", list(_height_cases()))
+def test_height_terms_replace_the_third_grid_dimension(gpu, monkeypatch, name):
+    """A non-coplanar array whose heights are small against the wavelength (HERA-37 with 5 cm of scatter) runs as K 2-D
+    transforms per slice -- the expansion of exp(i z s_z) about the middle of the sources' height range, every
+    baseline adding its own factor in the gather -- instead of a 3-D grid (reference: finufft.nufft3d3 whenever
+    |b_z| > 1e-6 m, cpu_simulate.py:655, cpu/nufft.py:62-118).  Against the oracle's exact 3-D sums, and against the
+    engine's own 3-D transform (FFTVIS_HIP_NO_WTERM=1), for every kind of run the gather serves."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    cfg = _height_cases()[name]
+    eps = cfg["eps"]
+    gpu_simulate.release_handles()
+    monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+    got = fftvis_amd.simulate_vis(**cfg)
+    st = _last_handle_stats()
+    assert 2 <= st["height_terms"] <= 16 and st["n2_3"] == 1, st  # 2-D grids, K terms
+    gpu_simulate.release_handles()
+    exact = oracle_simulate(cfg)
+    assert got.shape == exact.shape and rel_l2(got, exact) < 5 * eps
+    monkeypatch.setenv("FFTVIS_HIP_NO_WTERM", "1")
+    grid3 = fftvis_amd.simulate_vis(**cfg)
+    st3 = _last_handle_stats()
+    assert st3["height_terms"] == 0 and st3["n2_3"] > 1, st3
+    gpu_simulate.release_handles()
+    assert rel_l2(got, grid3) < 6 * eps
+    # the heights matter at this accuracy: the flat array is a different answer
+    if name == "unpolarized_airy":
+        flat = oracle_simulate(dict(cfg, ants={k: np.array([p[0], p[1], 0.0]) for k, p in cfg["ants"].items()}))
+        assert rel_l2(flat, exact) > 100 * eps
+
+
+def test_height_terms_at_decimetres_and_their_limit(gpu, monkeypatch):
+    """Heights of a decimetre need more terms (the count follows (zh |s_z|)^K / K! <= eps / 10) and the 2-D plans
+    run at eps / e^a; metres of scatter exceed 16 terms and take the 3-D transform."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    c = synth.make_config("C2", nsrc=500, nfreq=2, ntimes=1)
+    monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+    terms = []
+    for sigma_m in (0.01, 0.1, 3.0):
+        cfg = dict(c, ants=synth.with_z_scatter(c["ants"], sigma_m, seed=8))
+        gpu_simulate.release_handles()
+        got = fftvis_amd.simulate_vis(**cfg)
+        terms.append(int(_last_handle_stats()["height_terms"]))
+        assert rel_l2(got, oracle_simulate(cfg)) < TOL, sigma_m
+    gpu_simulate.release_handles()
+    assert 2 <= terms[0] < terms[1] <= 16 and terms[2] == 0, terms

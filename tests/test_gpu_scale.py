@@ -340,7 +340,7 @@ def _band_block(name, f0, f1, ntimes, seed=0):
 def test_launches_the_bench_times_are_parity_checked(gpu, monkeypatch, name, f0, f1, ntimes, nsub):
     """what the driver's bench line times -- C3 / C4 geometry, the full catalog, all
     61 075 baselines on the device, frequency groups of 8 / 16 / 24 packed transforms under the default grid
-    budget (k_spread2d<.., 8|16> at C3's density, k_spread2d_cg<.., 16> at C4's 10^6 sources), gang launches as
+    budget (k_spread2d<.., 8|16> at C3's density, k_spread2d_mm<8|16> at C4's 10^6 sources), gang launches as
     the engine picks them -- checked: a subset of baselines against the CPU oracle (exact sums), ALL baselines
     against the four-transform run (FFTVIS_HIP_NO_HERMITIAN=1: different launches, same answer)."""
     from fftvis_amd.gpu import gpu_simulate

@@ -196,6 +196,28 @@ def test_benchmark_arrays_are_lattices():
         assert len(ants) == nant and ok
 
 
+def test_round4_bench_arrays_are_what_their_names_say():
+    """`bench.py --array scattered` / `--workload C3z`: the scattered array has 350 antennas inside HERA-350's
+    footprint, is flat, is NOT a lattice and repeats no baseline vector; the height-scattered HERA-350 exceeds the
+    reference's flat_array_tol (cpu_simulate.py:655) after the plane fit, i.e. takes the 3-D transform."""
+    from fftvis_amd.core.antenna_gridding import check_antpos_griddability
+    from fftvis_amd.gpu.gpu_simulate import prepare_array
+
+    ref = np.array(list(synth.hera_like_array("hera350").values()))
+    sc = synth.hera_like_array("scattered350")
+    a = np.array(list(sc.values()))
+    assert a.shape == (350, 3) and np.all(a[:, 2] == 0)
+    assert np.all(a[:, :2].min(0) >= ref[:, :2].min(0)) and np.all(a[:, :2].max(0) <= ref[:, :2].max(0))
+    assert not check_antpos_griddability(sc)[0]
+    bl = synth.all_cross_baselines(sc)
+    _, b, coplanar = prepare_array(sc, bl, 1e-6, np.float64)
+    assert coplanar and len(np.unique(np.round(b[:2].T * 299792458.0, 6), axis=0)) == len(bl) == 61075
+    assert np.array_equal(a, np.array(list(synth.hera_like_array("scattered350").values())))  # seeded
+    cz = synth.make_config("C3", nsrc=4, nfreq=2, ntimes=1, z_scatter=0.03)
+    _, bz, coplanar_z = prepare_array(cz["ants"], cz["baselines"], 1e-6, np.float64)
+    assert not coplanar_z and 0.05 < np.abs(bz[2]).max() * 299792458.0 < 0.5
+
+
 def test_spline_opts_orders():
     """The reference passes {"order": 1} (map_coordinates) or {"kx": 1, "ky": 1} (az_za_simple) in its
     own tests (tests/test_cpu_beams.py:72,82,411,428) and its CLI defaults to order 3 (cli.py:50,146):
