@@ -1364,14 +1364,17 @@ struct StPlan<12, COL> {
 // boundaries in a device array that fv_debug_stamps() copies out -- where a job's time goes (load, three radix passes,
 // two exchanges, stores).  Never defined in the product build.
 #ifdef FV_FFT_STAMPS
-__device__ unsigned long long fv_stamps[(size_t)10 << 18];  // 7 realtime stamps, tag, shader-clock count at start / end
+__device__ unsigned long long fv_stamps[(size_t)10 << 18];  // 7 realtime stamps, tag, realtime at the wave's first instruction / after its stores drained
 __device__ unsigned int fv_stamp_count;
 #define FV_STAMP(slot)                                                                          \
     do {                                                                                         \
         if ((threadIdx.x & 63) == 0 && stamp_idx < (1u << 18)) {                                 \
             fv_stamps[(size_t)stamp_idx * 10 + (slot)] = __builtin_amdgcn_s_memrealtime();         \
-            if ((slot) == 0) fv_stamps[(size_t)stamp_idx * 10 + 8] = __builtin_amdgcn_s_memtime(); \
-            if ((slot) == 6) fv_stamps[(size_t)stamp_idx * 10 + 9] = __builtin_amdgcn_s_memtime(); \
+            if ((slot) == 0) fv_stamps[(size_t)stamp_idx * 10 + 8] = stamp_entry;                  \
+            if ((slot) == 6) {                                                                   \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
+                fv_stamps[(size_t)stamp_idx * 10 + 9] = __builtin_amdgcn_s_memrealtime();         \
+            }                                                                                    \
         }                                                                                        \
     } while (0)
 #else
@@ -1379,6 +1382,9 @@ __device__ unsigned int fv_stamp_count;
 #endif
 #ifndef FV_PAIR_DEFAULT
 #define FV_PAIR_DEFAULT 1
+#endif
+#ifndef FV_ST_CX32
+#define FV_ST_CX32 0  // fp32: whole complex values through the LDS exchange (k_rowfft_st, CX): measured slower, see there
 #endif
 #ifndef FV_ST_MINW12
 #define FV_ST_MINW12 3  // waves per SIMD targeted by the register allocation of the Q = 4096 kernels
@@ -1636,7 +1642,15 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     // exchange suffices (column mode spreads a column's threads over all waves: its barriers are
     // workgroup-wide)
     constexpr bool DUAL = FV_ST_DUAL && COL && LOGQ == 9;
-    __shared__ __attribute__((aligned(16))) T smem[(DUAL ? 2 : 1) * RPW * ROW];
+    // fp32 (CX): a complex value is 8 bytes -- the size of the fp64 real a slot holds -- so whole values cross the
+    // exchange in ONE round (write, barrier, read) instead of two, on the bank-conflict-free strides that were searched
+    // for 8-byte slots (StPlan); the halves of a value stay adjacent registers from the LDS read on, which the packed
+    // arithmetic (PkF32) wants anyway.  OFF by default (FV_ST_CX32): it doubles the fp32 kernels' LDS to the fp64 kernels'
+    // 33 KB per workgroup, which takes them from 7 to 4 waves per SIMD, and the lost occupancy costs more than the saved
+    // round: C5's passes 1.47 -> 1.70 ms per launch (round 4, same box; round 3's compiler-packed attempt: 3.61 -> 4.10).
+    constexpr bool CX = FV_ST_CX32 && sizeof(T) == 4 && !DUAL;
+    using ST = std::conditional_t<CX, cplx<T>, T>;  // what an exchange slot holds
+    __shared__ __attribute__((aligned(16))) ST smem[(DUAL ? 2 : 1) * RPW * ROW];
 
     const int tid = threadIdx.x;
     const int vb = blockIdx.x;
@@ -1647,9 +1661,16 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     const int r = PAIR ? (COL ? g * NL + line : tid / TPR) : line;
 #ifdef FV_FFT_STAMPS
     unsigned stamp_idx = 0xffffffffu;
+    const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();  // slot 8: the wave's first instruction; slot 9: its stores drained
     if ((tid & 63) == 0 && (FV_FFT_STAMPS != 2 || COL)) {  // FV_FFT_STAMPS = 2: column-mode kernels only
         stamp_idx = atomicAdd(&fv_stamp_count, 1u);
-        if (stamp_idx < (1u << 18)) fv_stamps[(size_t)stamp_idx * 10 + 7] = ((unsigned long long)LOGQ << 8) | (COL ? 2 : 0) | (FOLD ? 1 : 0) | ((unsigned long long)(sizeof(T) == 8) << 2) | (PAIR ? 8 : 0);
+        // tag: kernel variant, HW_ID (wave slot 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13), XCC and block id: with them the
+        // stamps also say how long a wave slot stays empty between two workgroups (scratch/stamps2.py)
+        if (stamp_idx < (1u << 18))
+            fv_stamps[(size_t)stamp_idx * 10 + 7] = ((unsigned long long)LOGQ << 8) | (COL ? 2 : 0) | (FOLD ? 1 : 0) | ((unsigned long long)(sizeof(T) == 8) << 2) | (PAIR ? 8 : 0) |
+                                                    ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xffffu) << 16) |
+                                                    ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xfu) << 32) |
+                                                    ((unsigned long long)(blockIdx.x & 0xffffffu) << 36);
     }
     FV_STAMP(0);
 #endif
@@ -1682,8 +1703,8 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     const bool ok_line = row < a.nrows && rk < a.rpp_valid;  // the line exists: its inputs are read
     const bool ok = ok_line && p < a.P;                      // ... and so does this thread's residue: outputs are stored
     const int n2 = a.n2;
-    T *rb = smem + r * ROW;
-    T *rbi = DUAL ? rb + RPW * ROW : rb;
+    ST *rb = smem + r * ROW;
+    ST *rbi = DUAL ? rb + RPW * ROW : rb;
 
     // fused gather: this 8-lane slot's first item (id, header, x weight) is requested now, so that
     // two of the three dependent round trips of the gather are long over when the tile is ready
@@ -2030,6 +2051,15 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     // ---- exchange 1 -> pass 2 -------------------------------------------------------------------
     FV_STAMP(2);  // pass 1 done
     cplx<T> vb2[NI2][R2];
+    if constexpr (CX) {
+#pragma unroll
+        for (int k = 0; k < R1; ++k) rb[s1 + k * A] = va[bitrev_small(k, L1)];
+        st_sync<WAVE>();
+#pragma unroll
+        for (int i = 0; i < NI2; ++i)
+#pragma unroll
+            for (int n = 0; n < R2; ++n) vb2[i][n] = rb[base2[i] + n * B];
+    } else {
 #pragma unroll
     for (int k = 0; k < R1; ++k) rb[s1 + k * A] = va[bitrev_small(k, L1)].re;
     if constexpr (!DUAL) {
@@ -2053,6 +2083,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     for (int i = 0; i < NI2; ++i)
 #pragma unroll
         for (int n = 0; n < R2; ++n) vb2[i][n].im = rbi[base2[i] + n * B];
+    }
 
     FV_STAMP(3);  // exchange 1 done
 #pragma unroll
@@ -2065,6 +2096,17 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     // ---- exchange 2 -> pass 3 (pass-2 items write back to the slots they read: no sync before) --
     FV_STAMP(4);  // pass 2 done
     cplx<T> vc[NI3][R3];
+    if constexpr (CX) {
+#pragma unroll
+        for (int i = 0; i < NI2; ++i)
+#pragma unroll
+            for (int k = 0; k < R2; ++k) rb[base2[i] + k * B] = vb2[i][bitrev_small(k, L2)];
+        st_sync<WAVE>();
+#pragma unroll
+        for (int i = 0; i < NI3; ++i)
+#pragma unroll
+            for (int n = 0; n < R3; ++n) vc[i][n] = rb[base3[i] + n];
+    } else {
 #pragma unroll
     for (int i = 0; i < NI2; ++i)
 #pragma unroll
@@ -2092,6 +2134,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     for (int i = 0; i < NI3; ++i)
 #pragma unroll
         for (int n = 0; n < R3; ++n) vc[i][n].im = rbi[base3[i] + n];
+    }
 
     // ---- pass 3 and this residue's outputs: k' = v + k3 Q/R3, l = P k' + p (mod n2, signed) ------
     FV_STAMP(5);  // exchange 2 done

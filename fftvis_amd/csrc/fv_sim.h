@@ -745,7 +745,8 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
     const int lane = threadIdx.x & 63;
     const int bx2 = blockIdx.x * 4 + wave, by2 = blockIdx.y, f = blockIdx.z;
     if (bx2 >= (a.n2 >> TL)) return;  // wave-uniform; the waves of a workgroup share nothing
-    const int cx = (bx2 << TL) + (lane & 7), cy = (by2 << TL) + (lane >> 3);
+    const int tx0 = bx2 << TL, ty0 = by2 << TL;  // the tile's first cell (uniform)
+    const int cx = tx0 + (lane & 7), cy = ty0 + (lane >> 3);
     T ar[4][TP], ai[4][TP];  // cells (cx, cy), (cx + 8, cy), (cx, cy + 8), (cx + 8, cy + 8)
 #pragma unroll
     for (int h = 0; h < 4; ++h)
@@ -813,6 +814,8 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
         if (have) request(cb, cn);
         for (int j = 0; j < n; ++j) {
             const int ox = __builtin_amdgcn_readlane(hdr.x, j), oy = __builtin_amdgcn_readlane(hdr.y, j);
+            // (Skipping, with scalar branches on the wave-uniform origin, the quadrants a footprint misses -- 1.8 of 4 are met
+            // on average -- was measured slower: 1.63 against 1.22 ms per C3 time step; the branches break the schedule.)
             // offsets clamped into [-1, w]: the guards at either end of a row are zero
             const int dx = cx - ox, dy = cy - oy;
             auto clamp = [&](int v) {  // median(v, -1, w): one instruction (the compiler cannot prove -1 <= w for min(max()))
@@ -843,6 +846,137 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_t1_spread(
     for (int q = 0; q < TP; ++q)
 #pragma unroll
         for (int h = 0; h < 4; ++h) o[q * plane + (int64_t)(h >> 1) * 8 * a.n2 + (h & 1) * 8] = {ar[h][q], ai[h][q]};
+}
+
+// The same tile walk with the accumulation on the matrix pipe (fp64).  A footprint's weights are separable, so the update
+// of one 16 x 16 tile by the entries e that reach it is a matrix product per real component c of the strengths,
+//     G_c[y][x] += sum_e (s_{e,c} wy_e[y]) wx_e[x]      --   A[y][e] = s_{e,c} wy_e[y] (16 x 4),  B[e][x] = wx_e[x] (4 x 16),
+// v_mfma_f64_16x16x4_f64: four entries per instruction, 2 TP instructions (the real and imaginary parts of the TP
+// transforms) per four entries.  fp64 MFMA has the vector pipe's flop rate on gfx950, and seven eighths of the products
+// are by the zero guards here too; what it removes is everything around the multiply-adds -- the vector version spends 38
+// instructions per (entry, tile) visit, 16 of them multiply-adds; here a visit is one MFMA (64 cycles) plus a quarter of
+// two LDS reads, two clamps and 2 TP multiplies, issued beside it.  C3 lattice path: 1.22 -> see profiles/MEASUREMENTS.md.
+// Operand layout (as k_spread2d_mm): lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15] and D[(l >> 4) + 4 r][l & 15], r < 4.
+// (The waves-per-SIMD bound is what makes the compiler keep the accumulators in vector registers: without it they
+// travel to accumulator registers and back around every group of MFMAs -- 64 moves per four instructions, and moves
+// issue on the same pipe: 25 vector instructions per MFMA, the kernel no faster than the vector version.)
+template <int TP>
+__global__ __launch_bounds__(SPREAD_THREADS, 4) void k_t1_spread_mm(
+    T1Args a, const unsigned char *__restrict__ recs, const int *__restrict__ bin_start,
+    const cplx<double> *__restrict__ cs, cplx<double> *__restrict__ grid) {
+    using T = double;
+    using d4 = double __attribute__((ext_vector_type(4)));
+    constexpr int KW = MAX_W + 2;
+    constexpr int TL = BINLOG + 1;  // tile = 16 x 16 cells
+    __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][KW];
+    __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TP];
+    __shared__ int s_org[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bx2 = blockIdx.x * 4 + wave, by2 = blockIdx.y, f = blockIdx.z;
+    if (bx2 >= (a.n2 >> TL)) return;  // wave-uniform; the waves of a workgroup share nothing
+    const int tx0 = bx2 << TL, ty0 = by2 << TL;
+    const int li = lane & 15, g = lane >> 4;  // operand row / column, and the entry of a group of four
+    d4 acc[2 * TP];
+#pragma unroll
+    for (int c = 0; c < 2 * TP; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+    const int w = a.w;
+    // zero guards of the weight rows (slots 0 and w + 1) and zero strengths / origins everywhere: the slots a short chunk
+    // leaves untouched enter the products with zero strengths and finite weights
+    for (int e = lane; e < SPREAD_CHUNK * 2 * KW; e += 64) (&s_kw[wave][0][0][0])[e] = T(0);
+    for (int e = lane; e < SPREAD_CHUNK * TP; e += 64) (&s_str[wave][0][0])[e] = {T(0), T(0)};
+    if (lane < SPREAD_CHUNK * 2) (&s_org[wave][0][0])[lane] = 0;
+    const int bxl = (tx0 - w + 1 + T1_PAD) >> BINLOG, bxh = (tx0 + 15 + T1_PAD) >> BINLOG;
+    const int byl = (ty0 - w + 1 + T1_PAD) >> BINLOG, byh = (ty0 + 15 + T1_PAD) >> BINLOG;
+    constexpr int NWV = (2 * MAX_W + 3) / 4;  // weights per staging lane (4 lanes per entry)
+    int yb = byl, s1 = 0, base = 0;
+    auto open_row = [&]() {
+        const int rowb = (f * a.nb1 + yb) * a.nb1;
+        base = __builtin_amdgcn_readfirstlane(bin_start[rowb + bxl]);
+        s1 = __builtin_amdgcn_readfirstlane((int)min((int64_t)bin_start[rowb + bxh + 1], a.ecap));
+    };
+    auto next_chunk = [&](int &cb, int &cn) {
+        while (base >= s1) {
+            if (yb > byh) return false;
+            open_row();
+            ++yb;
+        }
+        cb = base;
+        cn = min(SPREAD_CHUNK, s1 - base);
+        base += cn;
+        return true;
+    };
+    int2 hdr_n = make_int2(0, 0);
+    cplx<T> sv_n = {T(0), T(0)};
+    T wv_n[NWV];
+    // (every load is unconditional -- indices clamped into the chunk, the value selected afterwards: as conditional loads
+    // each sat in an exec-masked region of its own with a branch around it, and vector instructions of the staging
+    // serialise with the MFMAs on the SIMD)
+    const int nwv = (2 * w + 3) >> 2;  // uniform
+    auto request = [&](int cb, int cn) {  // cn >= 1
+        const unsigned char *rb = recs + (int64_t)cb * a.rec;
+        hdr_n = *reinterpret_cast<const int2 *>(rb + (int64_t)min(lane, cn - 1) * a.rec);
+        sv_n = cs[(int64_t)cb * TP + min(lane, cn * TP - 1)];
+        const int j = lane >> 2;
+        const T *wr = reinterpret_cast<const T *>(rb + (int64_t)min(j, cn - 1) * a.rec + T1_HDR);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int k = (lane & 3) + 4 * i;
+            if (i < nwv) wv_n[i] = wr[min(k, 2 * w - 1)];  // uniform; used (or not) when the chunk is staged, not here
+        }
+    };
+    int cb = 0, cn = 0;
+    bool have = next_chunk(cb, cn);
+    if (have) request(cb, cn);
+    while (have) {
+        const int n = cn;
+        if (lane < SPREAD_CHUNK * TP) s_str[wave][lane / TP][lane % TP] = lane < n * TP ? sv_n : cplx<T>{T(0), T(0)};  // zero beyond the chunk's count
+        if (lane < n) {
+            s_org[wave][lane][0] = hdr_n.x - tx0;  // origin relative to the tile
+            s_org[wave][lane][1] = hdr_n.y - ty0;
+        }
+        {
+            const int j = lane >> 2;
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int k = (lane & 3) + 4 * i;
+                if (j < n && k < 2 * w) s_kw[wave][j][k >= w][(k >= w ? k - w : k) + 1] = wv_n[i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        have = next_chunk(cb, cn);
+        if (have) request(cb, cn);
+        auto clamp = [&](int v) {  // median(v, -1, w) + 1: the guards at either end of a row are zero
+            int r;
+            asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(v), "s"(w));
+            return r + 1;
+        };
+        const int nq = (n + 3) >> 2;
+        for (int q = 0; q < nq; ++q) {
+            const int e = 4 * q + g;  // this lane's entry (slots beyond n: zero strengths)
+            const int ox = s_org[wave][e][0], oy = s_org[wave][e][1];
+            const T wy = s_kw[wave][e][1][clamp(li - oy)];  // A: row y = li
+            const T wx = s_kw[wave][e][0][clamp(li - ox)];  // B: column x = li
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                const cplx<T> sv = s_str[wave][e][t];
+                acc[2 * t] = __builtin_amdgcn_mfma_f64_16x16x4f64(sv.re * wy, wx, acc[2 * t], 0, 0, 0);
+                acc[2 * t + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sv.im * wy, wx, acc[2 * t + 1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the rows are rewritten by the next chunk
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // results: lane l, register r = cell (x = tx0 + (l & 15), y = ty0 + (l >> 4) + 4 r): 16 lanes write 256 contiguous bytes
+    const int64_t plane = (int64_t)a.n2 * a.n2;
+    cplx<T> *o = grid + (int64_t)f * TP * plane + (int64_t)(ty0 + g) * a.n2 + tx0 + li;
+#pragma unroll
+    for (int t = 0; t < TP; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t * plane + (int64_t)(4 * r) * a.n2] = {acc[2 * t][r], acc[2 * t + 1][r]};
 }
 
 // vis[f][pol][k] = X_{f,pol}[bx_k][by_k] / (psi_hat(bx) psi_hat(by)); flipped baselines take the
@@ -1884,7 +2018,20 @@ class Sim : public SimBase {
                     cplx<T> *A = t1fft->fft_input(nplanes);
                     size_t e3 = ev_begin(TM_SPREAD, stream);
                     const dim3 gs((unsigned)cdiv(g.n2 >> (BINLOG + 1), 4), (unsigned)(g.n2 >> (BINLOG + 1)), (unsigned)nfg);  // 16 x 16 cells per wave
-                    if (herm1)
+                    // fp64: the accumulation on the matrix pipe (FFTVIS_HIP_T1_MM=0: the vector version)
+                    static const bool t1_mm = !(std::getenv("FFTVIS_HIP_T1_MM") && std::atoi(std::getenv("FFTVIS_HIP_T1_MM")) == 0);
+                    bool spread_done = false;
+                    if constexpr (sizeof(T) == 8) {
+                        if (t1_mm) {
+                            auto kmm = herm1 ? k_t1_spread_mm<2> : polarized ? k_t1_spread_mm<4> : k_t1_spread_mm<1>;
+                            hipLaunchKernelGGL(kmm, gs, dim3(SPREAD_THREADS), 0, stream, a,
+                                               (const unsigned char *)recs.as<unsigned char>(), (const int *)binstart.as<int>(),
+                                               (const cplx<double> *)t1_cs.as<cplx<double>>(), (cplx<double> *)A);
+                            spread_done = true;
+                        }
+                    }
+                    if (spread_done) {
+                    } else if (herm1)
                         hipLaunchKernelGGL((k_t1_spread<T, 2>), gs, dim3(SPREAD_THREADS), 0, stream, a,
                                            (const unsigned char *)recs.as<unsigned char>(),
                                            (const int *)binstart.as<int>(),
