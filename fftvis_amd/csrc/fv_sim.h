@@ -1143,6 +1143,11 @@ class Sim : public SimBase {
         int64_t n;
         bool trivial;  // all baselines in order, nothing flipped
         std::unique_ptr<DevBuf> idx, flip;
+        // the list in the CALLER's order (usually increasing baseline index): what the lattice path's mode pick walks --
+        // its reads are a few thousand distinct modes of a plane that sits in L2 whatever the order, its WRITES are 16 bytes
+        // per (baseline, product) and want neighbouring threads on neighbouring baselines
+        bool trivial0 = false;
+        std::unique_ptr<DevBuf> idx0, flip0;
         // Redundant baselines: runs of the (u, v)-ordered list whose sign-adjusted vectors agree (build_unique) are ONE
         // target of the gather.  h_idx / h_flip: the list as visited (host copy); ustart: nu + 1 run starts (device).
         std::vector<int> h_idx, h_ustart;
@@ -1516,6 +1521,14 @@ class Sim : public SimBase {
             // their common grid lines through one L2 (C3: 0.31 -> 0.25 ms per launch).  The order of a list is free:
             // every baseline writes its own output slot.
             static const bool keep_order = std::getenv("FFTVIS_HIP_NO_TARGET_SORT") != nullptr;
+            pr.trivial0 = pr.n == nbls;
+            for (int64_t k = 0; k < pr.n && pr.trivial0; ++k) pr.trivial0 = ix[k] == k && !fl[k];
+            if (!pr.trivial0 && pr.n && type1) {
+                pr.idx0.reset(new DevBuf());
+                pr.flip0.reset(new DevBuf());
+                upload(*pr.idx0, ix, sizeof(int) * pr.n, 0);
+                upload(*pr.flip0, fl, pr.n, 0);
+            }
             std::vector<int> six(ix, ix + pr.n);
             std::vector<signed char> sfl(fl, fl + pr.n);
             if (!keep_order && order_pairs && pr.n > 1) {
@@ -2060,9 +2073,9 @@ class Sim : public SimBase {
                                        t1fft->fft_output(), g.no, g.P, g.cnt(), nfg, tg,
                                        (const int *)d_blint.as<int>(),
                                        (const int *)d_blint.as<int>() + nbls, pr.n,
-                                       pr.trivial ? (const int *)nullptr : (const int *)pr.idx->template as<int>(),
-                                       pr.trivial ? (const signed char *)nullptr
-                                                  : (const signed char *)pr.flip->template as<signed char>(),
+                                       pr.trivial0 ? (const int *)nullptr : (const int *)(pr.idx0 ? pr.idx0 : pr.idx)->template as<int>(),
+                                       pr.trivial0 ? (const signed char *)nullptr
+                                                   : (const signed char *)(pr.flip0 ? pr.flip0 : pr.flip)->template as<signed char>(),
                                        (const T *)t1_dec.as<T>(), obase, (int64_t)nt * per_tf, pol_off[0],
                                        pol_off[1], pol_off[2], pol_off[3], chunk > 0, herm1, !reference_compat);
                     ev_end(e5, stream);
