@@ -731,7 +731,45 @@ def main():
             res["c2"] = c2
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
-        print(json.dumps(res))
+    # ---- N > 1, host to host: what a caller of the sharded simulate_vis waits for (never `value`) -----------------
+    # every rank: catalog broadcast from rank 0 into device memory, its block through the engine, delivered straight
+    # into its slice of ONE shared-memory result while later time steps compute (parallel.simulate_vis_sharded)
+    if dist is not None and not a.no_e2e and a.as_rank is None:
+        h.close()
+        outs.clear()
+        del cat
+        torch.cuda.empty_cache()
+        kw = dict(cfg, upsample_factor=a.upsample if a.upsample else "auto", force_use_type3=a.path == "type3")
+        if rank != 0:
+            kw["ra"] = kw["dec"] = kw["fluxes"] = None
+        walls = []
+        for _ in range(2):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            v = parallel.simulate_vis_sharded(device=local_rank, gather_to=0, via_host=backend != "nccl", **kw)
+            dist.barrier()
+            walls.append(time.perf_counter() - t_e)
+            nbytes = v.nbytes if v is not None else 0
+            fin = bool(np.isfinite(v[::max(1, v.shape[0] // 4)]).all()) if v is not None else True
+            del v
+        if rank == 0:
+            res["e2e_sharded"] = {
+                "what": "parallel.simulate_vis_sharded(**cfg) on all ranks: host arrays in on rank 0 (catalog broadcast into "
+                        "every rank's HBM), every rank's block delivered straight into its slice of one shared-memory "
+                        "result on the host; barrier to barrier, one call = one step",
+                "first_call_s": walls[0],
+                "second_call_s": walls[1],
+                "ratio_to_device_resident_step": walls[1] / (elapsed / a.steps),
+                "value": vis_per_step / walls[1],
+                "unit": "visibilities/s",
+                "output_bytes": nbytes,
+                "finite_output": fin,
+            }
+    if rank == 0:
+        if dist is not None and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)  # rank 0's host cores, as at N = 1 (the others wait)
+        print(json.dumps(res), flush=True)
     h.close()  # (idempotent)
     if dist is not None:
         dist.barrier()

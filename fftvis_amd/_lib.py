@@ -62,6 +62,7 @@ SYMBOLS = {
     "fv_sim_set_basis": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fv_sim_set_chunking": (c_int, [c_void_p, c_int, c_double]),
     "fv_sim_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
+    "fv_sim_run_into": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int]),
     "fv_sim_sync": (c_int, [c_void_p]),
     "fv_sim_stats": (c_int, [c_void_p, c_void_p, c_int]),
     "fv_sim_reset_stats": (c_int, [c_void_p]),

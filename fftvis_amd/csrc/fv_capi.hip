@@ -567,6 +567,22 @@ int fv_sim_set_chunking(fv_sim *h, int nchunks, double source_buffer) {
 int fv_sim_run(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int out_on_device) {
     FV_SIM_CALL(FV_REQUIRE(out, "null output"); h->impl->run(t0, t1, f0, f1, out, out_on_device));
 }
+int fv_sim_run_into(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int64_t out_f_stride, int shared) {
+    return guarded([&] {
+        FV_REQUIRE(h && h->impl, "null handle");
+        FV_REQUIRE(out, "null output");
+        FV_REQUIRE(out_f_stride >= 0, "negative channel stride");
+        h->impl->out_f_stride = out_f_stride;
+        h->impl->out_shared = shared;
+        try {
+            h->impl->run(t0, t1, f0, f1, out, 0);
+        } catch (...) {  // the layout belongs to this call only
+            h->impl->out_f_stride = 0;
+            h->impl->out_shared = 0;
+            throw;
+        }
+    });
+}
 int fv_sim_sync(fv_sim *h) { FV_SIM_CALL(h->impl->sync()); }
 int fv_sim_stats(fv_sim *h, double *vals, int n) { FV_SIM_CALL(h->impl->stats(vals, n)); }
 int fv_sim_reset_stats(fv_sim *h) { FV_SIM_CALL(h->impl->reset_stats()); }

@@ -1089,6 +1089,12 @@ struct SimBase {
                            const int *ant2) = 0;
     virtual void set_chunking(int nchunks, double source_buffer) = 0;
     virtual void run(int t0, int t1, int f0, int f1, void *out, int out_on_device) = 0;
+    // Host destination of the next run (fv_sim_run_into): `out` is then a block INSIDE a larger array -- channel f of
+    // the block starts f * out_f_stride elements after `out` (0: the block is contiguous) -- and with out_shared other
+    // processes write the rest of that array (a sharded run's ranks filling one shared result): the pinning helper must
+    // then neither write to it nor register more than the block's own runs.  Reset by every run.
+    int64_t out_f_stride = 0;
+    int out_shared = 0;
     virtual void sync() = 0;
     virtual void stats(double *v, int n) = 0;
     virtual void reset_stats() = 0;
@@ -1887,7 +1893,17 @@ class Sim : public SimBase {
         const bool drain = !out_on_device && out_bytes >= drain_min_bytes();
         HostPin pin;
         pin.drain_on = &stream;  // copy_block_pinned below rides on the main stream
-        if (drain) pin.start(device, out, out_bytes);
+        // destination layout of this run (fv_sim_run_into), consumed here
+        const int64_t out_fs = out_f_stride ? out_f_stride : (int64_t)nt * per_tf;
+        const bool shared = out_shared != 0;
+        out_f_stride = 0;
+        out_shared = 0;
+        FV_REQUIRE(out_fs >= (int64_t)nt * per_tf, "fv_sim_run_into: the channel stride is shorter than a channel's run");
+        const size_t run_bytes = sizeof(cplx<T>) * (size_t)nt * per_tf;
+        // (a block inside a larger array is pinned run by run: only worth it -- and only safe against two runs meeting in
+        // one page -- when the runs are long)
+        const bool pinnable = out_fs == (int64_t)nt * per_tf || (run_bytes >= ((size_t)1 << 20) && (size_t)(out_fs - (int64_t)nt * per_tf) * sizeof(cplx<T>) >= 8192);
+        if (drain && pinnable) pin.start(device, out, (size_t)nf, run_bytes, sizeof(cplx<T>) * (size_t)out_fs, shared);
         const double sigma = this->sigma == 0.0 ? 2.0 : this->sigma;  // "auto" is a type-3 matter
         sigma_run = sigma;
         if (!t1fft) t1fft.reset(new Nufft3<T>(2, eps, sigma, stream));
@@ -2096,10 +2112,7 @@ class Sim : public SimBase {
             }
         }
         if (!out_on_device) {
-            if (drain && pin.wait())
-                copy_block_pinned(out, dout, out_bytes, stream);
-            else
-                FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
+            copy_block_to_host(out, dout, nf, (int64_t)nt * per_tf, out_fs, drain && pinnable && pin.wait(), stream);
             FV_HIP(hipStreamSynchronize(stream));
             if (timing_level) ev_collect();
             check_errors();
@@ -2204,20 +2217,37 @@ class Sim : public SimBase {
             return (int)std::max(1u, std::min(16u, hw / 4));
         }
         void mark() { t0 = std::chrono::steady_clock::now(); }  // the clock of since() / t_pinned: the run's start
-        void start(int device, void *ptr, size_t bytes, bool keep_clock = false) {
+        // The destination is nseg runs of seg_bytes, seg_stride bytes apart (one run: a contiguous array; several: a
+        // block inside a larger array, fv_sim_run_into).  shared: other processes write between and around the runs --
+        // the first touch then only READS (a write could overwrite what another rank has already delivered; reading
+        // faults a shared mapping's pages in just as well) and every run is registered on its own.
+        void start(int device, void *ptr, size_t nseg, size_t seg_bytes, size_t seg_stride, bool shared, bool keep_clock = false) {
             if (!keep_clock) mark();
-            th = std::thread([this, device, ptr, bytes] {
+            if (nseg > 1 && seg_stride == seg_bytes) {
+                seg_bytes *= nseg;
+                nseg = 1;
+            }
+            th = std::thread([this, device, ptr, nseg, seg_bytes, seg_stride, shared] {
                 (void)hipSetDevice(device);
-                char *p = static_cast<char *>(ptr), *end = p + bytes;
-                {  // first touch, in parallel
+                char *base = static_cast<char *>(ptr);
+                {  // first touch, in parallel: thread i takes the i-th share of every run
                     const int nt = touch_threads();
                     std::vector<std::thread> pool;
-                    const size_t share = (bytes + nt - 1) / nt;
+                    const size_t share = (seg_bytes + nt - 1) / nt;
                     for (int i = 0; i < nt; ++i)
                         pool.emplace_back([=] {
-                            volatile char *q = p + std::min(bytes, share * i);
-                            volatile char *stop = p + std::min(bytes, share * (i + 1));
-                            for (; q < stop; q += 4096) *q = 0;
+                            for (size_t sg = 0; sg < nseg; ++sg) {
+                                char *p = base + sg * seg_stride;
+                                volatile char *q = p + std::min(seg_bytes, share * i);
+                                volatile char *stop = p + std::min(seg_bytes, share * (i + 1));
+                                if (shared) {
+                                    char sink = 0;
+                                    for (; q < stop; q += 4096) sink ^= *q;
+                                    (void)sink;
+                                } else {
+                                    for (; q < stop; q += 4096) *q = 0;
+                                }
+                            }
                         });
                     for (std::thread &t : pool) t.join();
                 }
@@ -2225,6 +2255,8 @@ class Sim : public SimBase {
                 // FFTVIS_HIP_PIN_FAIL_AFTER = n (tests): the (n + 1)-th registration is refused
                 const char *ef = std::getenv("FFTVIS_HIP_PIN_FAIL_AFTER");
                 const long fail_after = ef ? std::atol(ef) : -1;
+                for (size_t sg = 0; ok && sg < nseg; ++sg) {
+                char *p = base + sg * seg_stride, *end = p + seg_bytes;
                 while (ok && p < end) {
                     const uintptr_t stop = (reinterpret_cast<uintptr_t>(p) / PIECE + 1) * PIECE;
                     char *q = std::min(end, reinterpret_cast<char *>(stop));
@@ -2236,6 +2268,7 @@ class Sim : public SimBase {
                         (void)hipGetLastError();
                         ok = false;
                     }
+                }
                 }
                 if (!ok) {
                     // refused part-way (locked-memory limit): the caller's array must not stay HALF pinned -- the fallback
@@ -2263,7 +2296,7 @@ class Sim : public SimBase {
     };
     // queue the copies of the finished time steps items[done ...) behind their events
     void drain_flush(void *out, const cplx<T> *dout, int nt, int nf, int64_t per_tf, const std::vector<DrainItem> &items,
-                     size_t &done) {
+                     size_t &done, int64_t out_fs) {
         if (!copy_stream) FV_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         cplx<T> *hout = static_cast<cplx<T> *>(out);
         for (; done < items.size(); ++done) {
@@ -2272,7 +2305,7 @@ class Sim : public SimBase {
             for (int f = 0; f < nf; ++f) {
                 const int64_t off = ((int64_t)f * nt + it.t) * per_tf;
                 // split where the pinned pieces meet (HostPin): a copy must lie inside one registration
-                char *dst = reinterpret_cast<char *>(hout + off);
+                char *dst = reinterpret_cast<char *>(hout + (int64_t)f * out_fs + (int64_t)it.t * per_tf);
                 const char *src = reinterpret_cast<const char *>(dout + off);
                 size_t left = sizeof(cplx<T>) * (size_t)it.n * per_tf;
                 while (left) {
@@ -2288,6 +2321,24 @@ class Sim : public SimBase {
     }
 
     // one asynchronous copy of a whole block into a pinned caller array, split where the pinned pieces meet
+    // the same for a block whose channels are out_fs elements apart at the destination: one run per channel
+    void copy_block_to_host(void *out, const cplx<T> *dout, int nf, int64_t run_elems, int64_t out_fs, bool pinned, hipStream_t on) {
+        if (out_fs == run_elems) {
+            if (pinned)
+                copy_block_pinned(out, dout, sizeof(cplx<T>) * (size_t)nf * run_elems, on);
+            else
+                FV_HIP(hipMemcpyAsync(out, dout, sizeof(cplx<T>) * (size_t)nf * run_elems, hipMemcpyDeviceToHost, on));
+            return;
+        }
+        if (!pinned) {
+            FV_HIP(hipMemcpy2DAsync(out, sizeof(cplx<T>) * (size_t)out_fs, dout, sizeof(cplx<T>) * (size_t)run_elems,
+                                    sizeof(cplx<T>) * (size_t)run_elems, (size_t)nf, hipMemcpyDeviceToHost, on));
+            return;
+        }
+        for (int f = 0; f < nf; ++f)
+            copy_block_pinned(static_cast<cplx<T> *>(out) + (int64_t)f * out_fs, dout + (int64_t)f * run_elems,
+                              sizeof(cplx<T>) * (size_t)run_elems, on);
+    }
     void copy_block_pinned(void *out, const void *dout, size_t bytes, hipStream_t on) {
         char *dst = static_cast<char *>(out);
         const char *src = static_cast<const char *>(dout);
@@ -2315,6 +2366,12 @@ class Sim : public SimBase {
             return;
         }
         const int nt = t1 - t0, nf = f1 - f0;
+        // destination layout of this run (fv_sim_run_into), consumed here
+        const int64_t out_fs = out_f_stride ? out_f_stride : (int64_t)nt * tpol * nbls;
+        const bool shared = out_shared != 0;
+        out_f_stride = 0;
+        out_shared = 0;
+        FV_REQUIRE(out_fs >= (int64_t)nt * tpol * nbls, "fv_sim_run_into: the channel stride is shorter than a channel's run");
         // height terms instead of a third grid dimension (see wt_K)
         double xc[3], X[3];
         source_box(xc, X);
@@ -2355,7 +2412,11 @@ class Sim : public SimBase {
         // Baselines not covered by any pair stay zero (reference zero-initialises, :909-911).
         FV_HIP(hipMemsetAsync(dout, 0, out_bytes, stream));
         reserve_mhist(sizeof(int) * rots.size() * std::max(1, src_chunks));
-        const bool drain = !out_on_device && out_bytes >= drain_min_bytes();
+        const size_t run_bytes = sizeof(cplx<T>) * (size_t)nt * per_tf;
+        // (a block inside a larger array is pinned run by run: only worth it -- and only safe against two runs meeting in
+        // one page -- when the runs are long)
+        const bool pinnable = out_fs == (int64_t)nt * per_tf || (run_bytes >= ((size_t)1 << 20) && (size_t)(out_fs - (int64_t)nt * per_tf) * sizeof(cplx<T>) >= 8192);
+        const bool drain = !out_on_device && out_bytes >= drain_min_bytes() && pinnable;
         std::vector<DrainItem> drain_items;
         size_t drained = 0;
         // the helper touches and pins the caller's array once the first unit is queued: started at once, its sixteen page-
@@ -2366,7 +2427,7 @@ class Sim : public SimBase {
         bool pin_started = false;
         static const bool pin_early = std::getenv("FFTVIS_HIP_PIN_EARLY") != nullptr;
         if (drain && pin_early) {
-            pin.start(device, out, out_bytes, true);
+            pin.start(device, out, (size_t)nf, run_bytes, sizeof(cplx<T>) * (size_t)out_fs, shared, true);
             pin_started = true;
         }
 
@@ -2632,7 +2693,7 @@ class Sim : public SimBase {
                 const hipEvent_t ev = drain_event(drain_items.size());
                 FV_HIP(hipEventRecord(ev, stream));  // pipelined and single-lane runs: every big kernel is on `stream`
                 drain_items.push_back({ev, tu - t0, nm});
-                if (pin.pinned()) drain_flush(out, dout, nt, nf, per_tf, drain_items, drained);
+                if (pin.pinned()) drain_flush(out, dout, nt, nf, per_tf, drain_items, drained, out_fs);
             };
             if (nsrc == 0 || sn <= 0) {  // nothing above the horizon: the block stays zero (:945-946)
                 close_time();
@@ -2822,7 +2883,7 @@ class Sim : public SimBase {
             }
             if (dbg_t && tu == t0 && chunk == 0) std::fprintf(stderr, "run: first unit queued %.3f s\n", pin.since());
             if (drain && !pin_started) {
-                pin.start(device, out, out_bytes, true);
+                pin.start(device, out, (size_t)nf, run_bytes, sizeof(cplx<T>) * (size_t)out_fs, shared, true);
                 pin_started = true;
             }
             close_time();
@@ -2836,7 +2897,7 @@ class Sim : public SimBase {
                 const bool dbg = std::getenv("FFTVIS_HIP_DEBUG_DRAIN") != nullptr;
                 const double t_queued = pin.since();
                 const size_t early = drained;
-                drain_flush(out, dout, nt, nf, per_tf, drain_items, drained);
+                drain_flush(out, dout, nt, nf, per_tf, drain_items, drained, out_fs);
                 if (dbg) {
                     FV_HIP(hipStreamSynchronize(stream));
                     std::fprintf(stderr, "drain: run queued %.3f s, pinned %.3f s, kernels done %.3f s, ", t_queued,
@@ -2855,7 +2916,7 @@ class Sim : public SimBase {
                     std::fprintf(stderr, "\n");
                 }
             } else {
-                FV_HIP(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, stream));
+                copy_block_to_host(out, dout, nf, (int64_t)nt * per_tf, out_fs, false, stream);
                 FV_HIP(hipStreamSynchronize(stream));
             }
             if (timing_level) ev_collect();

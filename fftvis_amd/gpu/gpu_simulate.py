@@ -206,10 +206,26 @@ class SimHandle:
     def out_shape(self, nt, nf):
         return (nf, nt, 2, 2, self.nbls) if self.polarized else (nf, nt, self.nbls)
 
-    def run(self, t0, t1, f0, f1):
-        """Times [t0,t1) x freqs [f0,f1) -> host array in the reference's final layout."""
-        out = np.empty(self.out_shape(t1 - t0, f1 - f0), dtype=self.cdt)
-        _lib.check(self._L.fv_sim_run(self._h, t0, t1, f0, f1, _lib.ptr(out), 0))
+    def run(self, t0, t1, f0, f1, out=None, shared=False):
+        """Times [t0,t1) x freqs [f0,f1) -> host array in the reference's final layout.
+
+        ``out``: deliver into this array instead of a new one -- a block of a larger result, e.g.
+        ``vis[fsl, tsl]`` (reference cpu_simulate.py:846-847): shape ``out_shape``, this engine's dtype, every axis
+        but the first (channels) contiguous (``fv_sim_run_into``).  ``shared``: other processes fill the rest of the
+        underlying array (a result in shared memory, one block per rank)."""
+        shape = self.out_shape(t1 - t0, f1 - f0)
+        if out is None:
+            out = np.empty(shape, dtype=self.cdt)
+            _lib.check(self._L.fv_sim_run(self._h, t0, t1, f0, f1, _lib.ptr(out), 0))
+            return out
+        if out.shape != shape or out.dtype != self.cdt or not out.flags.writeable:
+            raise ValueError(f"out must be a writeable {np.dtype(self.cdt).name} array of shape {shape}, got {out.dtype} {out.shape}")
+        inner = np.empty(shape[1:], dtype=self.cdt).strides
+        if out.size and (out.strides[1:] != inner or out.strides[0] % out.itemsize or out.strides[0] < inner[0] * shape[1]):
+            raise ValueError("out: only the first (channel) axis may be strided; the rest must be C-contiguous")
+        if out.size:
+            _lib.check(self._L.fv_sim_run_into(self._h, t0, t1, f0, f1, ctypes.c_void_p(out.ctypes.data),
+                                               out.strides[0] // out.itemsize, int(bool(shared))))
         return out
 
     def run_device(self, t0, t1, f0, f1, out_ptr):
@@ -330,6 +346,8 @@ class GPUSimulationEngine(SimulationEngine):
         reference_compat: bool = True,
         astrom: np.ndarray = None,
         device_astrometry: bool = False,
+        out: np.ndarray = None,
+        out_shared: bool = False,
     ) -> np.ndarray:
         """Simulate visibilities on the GPU.
 
@@ -382,7 +400,12 @@ class GPUSimulationEngine(SimulationEngine):
         * ``time_idx`` / ``freq_idx`` (extra) restrict the run to a block, which is how ranks
           shard a simulation across GPUs; ``catalog_device`` (extra; ``parallel.DeviceCatalog``) is a
           catalog already resident on this GPU -- e.g. received by an RCCL broadcast -- used instead
-          of ``ra / dec / fluxes`` (which may then be None).
+          of ``ra / dec / fluxes`` (which may then be None);
+        * ``out`` (extra): deliver the block into this array -- typically a view ``vis[freq_idx, time_idx]`` of the
+          whole result, the reference's ``vis[tc][..., fc] = future`` (cpu_simulate.py:846-847) without the copy --
+          of the block's shape and dtype, only its channel axis strided; it is pinned in place and filled while the
+          run computes.  ``out_shared`` (extra): the underlying array is shared memory that other ranks fill too
+          (``parallel.simulate_vis_sharded``).
         """
         beam_order = checked_spline_order(beam_spline_opts)
         if interpolation_function not in ("az_za_map_coordinates", "az_za_simple"):
@@ -509,24 +532,29 @@ class GPUSimulationEngine(SimulationEngine):
                                  nsrc if coord_mgr is not None else 0)
             if coord_mgr is not None:
                 coord_mgr.setup()
+            if out is not None and (out.shape != h.out_shape(t1 - t0, f1 - f0) or out.dtype != complex_dtype):
+                raise ValueError(f"out must be a {np.dtype(complex_dtype).name} array of shape "
+                                 f"{h.out_shape(t1 - t0, f1 - f0)}, got {out.dtype} {out.shape}")
             if nblk_t >= t1 - t0 and coord_mgr is None:
-                vis = h.run(t0, t1, f0, f1)
+                vis = h.run(t0, t1, f0, f1, out=out, shared=out_shared)
             else:
-                vis = np.empty(h.out_shape(t1 - t0, f1 - f0), dtype=complex_dtype)
+                # every time block lands in its slice of the result (fv_sim_run_into): no block-sized temporary, no
+                # second host copy
+                vis = out if out is not None else np.empty(h.out_shape(t1 - t0, f1 - f0), dtype=complex_dtype)
                 for tb in range(t0, t1, max(nblk_t, 1)):
                     te = min(t1, tb + max(nblk_t, 1))
                     if coord_mgr is not None:
                         h.set_topo(_topo_from_coord_mgr(coord_mgr, range(tb, te)))
-                        vis[:, tb - t0:te - t0] = h.run(0, te - tb, f0, f1)
+                        h.run(0, te - tb, f0, f1, out=vis[:, tb - t0:te - t0], shared=out_shared)
                     else:
-                        vis[:, tb - t0:te - t0] = h.run(tb, te, f0, f1)
+                        h.run(tb, te, f0, f1, out=vis[:, tb - t0:te - t0], shared=out_shared)
             ok = True
         finally:
             if ok:
                 _return_handle(key, h)
             else:  # an error may have left it half configured
                 h.close()
-        return vis.astype(complex_dtype, copy=False)
+        return vis if out is not None else vis.astype(complex_dtype, copy=False)
 
     def _evaluate_vis_chunk(self, time_idx: slice, freq_idx: slice, **kw) -> np.ndarray:
         """One (time x freq) block in the reference's scratch layout

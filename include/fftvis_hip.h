@@ -225,6 +225,14 @@ int fv_sim_set_chunking(fv_sim *h, int nchunks, double source_buffer);
  * synchronisation -- this call for a host `out`, fv_sim_sync() otherwise -- with FV_ERR_ARG /
  * FV_ERR_INTERNAL; the output of that run is invalid.                                          */
 int fv_sim_run(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int out_on_device);
+/* The same into a block INSIDE a larger host array in the final layout: channel f of the block starts
+ * f * out_f_stride elements after `out` (0: contiguous, = fv_sim_run with a host `out`); its times are contiguous.
+ * This is the reference's `vis[tc][..., fc] = future` (src/fftvis/cpu/cpu_simulate.py:843-847) without the copy: the
+ * time blocks of a run that does not fit the device, and the ranks of a sharded run, deliver straight into their
+ * slice of the result -- pinned in place run by run and filled from a copy stream while later time steps compute.
+ * shared != 0: other processes write the rest of the array (one result in shared memory for all ranks of a node): the
+ * pinning helper then only reads the block's pages when it touches them and registers nothing beyond its runs.        */
+int fv_sim_run_into(fv_sim *h, int t0, int t1, int f0, int f1, void *out, int64_t out_f_stride, int shared);
 int fv_sim_sync(fv_sim *h);
 
 /* Introspection for bench/roofline: fills up to n doubles:

@@ -23,13 +23,16 @@ def main():
     cfg["beam"] = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=46, naz=90), freqs)
     if rank != 0:  # only rank 0 holds the catalog; the others receive it into device memory
         cfg["ra"] = cfg["dec"] = cfg["fluxes"] = None
+    # one node: every rank delivers its block straight into ONE result in shared memory ...
     vis = parallel.simulate_vis_sharded(device=0, gather_to=0, via_host=True, **cfg)
+    # ... and the route ranks on several hosts take: blocks travel to rank 0 as point-to-point tensors
+    vis_p2p = parallel.simulate_vis_sharded(device=0, gather_to=0, via_host=True, gather="p2p", **cfg)
     if rank == 0:
         blocks = parallel.shard_blocks_weighted(world, freqs, 6)
         flat = [(b[0][0].start, b[0][0].stop, b[0][1].start, b[0][1].stop) for b in blocks if b]
-        np.savez(sys.argv[1], vis=vis, blocks=np.array(flat))
+        np.savez(sys.argv[1], vis=np.array(vis), vis_p2p=vis_p2p, blocks=np.array(flat))
     else:
-        assert vis is None
+        assert vis is None and vis_p2p is None
     dist.barrier()
     dist.destroy_process_group()
 

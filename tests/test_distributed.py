@@ -47,6 +47,65 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _shm_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert parallel._all_ranks_on_one_host()
+        blocks = parallel.shard_blocks_weighted(world, np.linspace(1e8, 2e8, 6), 4)
+
+        def one_call(scale):
+            res = parallel._SharedResult((6, 4, 2, 2, 5), np.complex128, owner=0)
+            assert not os.path.exists(res.path) and res.array.shape == (6, 4, 2, 2, 5)  # mapped by all, name gone
+            for tsl, fsl in blocks[rank]:  # every rank fills its own slice of the ONE array
+                f, t = np.meshgrid(np.arange(6)[fsl], np.arange(4)[tsl], indexing="ij")
+                res.array[fsl, tsl] = scale * (100 * f + t)[:, :, None, None, None] * (1 + 1j)
+            return res.path, res.seal()
+
+        p1, out1 = one_call(1.0)
+        first = np.array(out1) if rank == 0 else None
+        p2, out2 = one_call(2.0)   # the caller still holds out1: a NEW segment
+        assert p2 != p1
+        if rank == 0:
+            assert np.array_equal(out1, first)  # untouched by the second call
+        del out1, out2
+        p3, out3 = one_call(3.0)   # the previous result was dropped: ITS segment is delivered into again (warm pages)
+        assert p3 == p2
+        if rank == 0:
+            q.put((first, np.array(out3), os.path.exists(p1) or os.path.exists(p2)))
+        else:
+            assert out3 is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shared_result_is_filled_by_every_rank_and_leaves_no_file():
+    """N > 1, one node: the result of a sharded run is ONE array in shared memory; every rank delivers its blocks into
+    its own slice, rank 0 ends up with the assembled array, the /dev/shm name is gone as soon as every rank has mapped
+    it, and a later call of the same shape reuses the segment (warm pages) once the earlier result has been dropped --
+    never while the caller still holds it."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    vis, vis3, still_there = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert not still_there
+    f, t = np.meshgrid(np.arange(6), np.arange(4), indexing="ij")
+    want = np.broadcast_to((100 * f + t)[:, :, None, None, None] * (1 + 1j), vis.shape)
+    np.testing.assert_array_equal(vis, want)
+    np.testing.assert_array_equal(vis3, 3.0 * want)
+
+
 def test_two_rank_sharding_matches_single_process():
     import torch.multiprocessing as mp
 

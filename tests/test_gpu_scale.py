@@ -296,7 +296,8 @@ def test_sharded_run_two_ranks_on_the_gpu(gpu, tmp_path):
     cfg["beam"] = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=46, naz=90), freqs)
     single = fftvis_amd.simulate_vis(**cfg)
     assert z["vis"].shape == single.shape == (12, 6, 2, 2, 666)
-    assert rel_l2(z["vis"], single) < 1e-12
+    assert rel_l2(z["vis"], single) < 1e-12      # blocks delivered straight into one shared-memory result
+    assert rel_l2(z["vis_p2p"], single) < 1e-12  # blocks sent to rank 0 point to point
     assert [tuple(b) for b in z["blocks"]] == [(0, 3, 0, 12), (3, 6, 0, 12)]
 
 
