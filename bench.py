@@ -670,11 +670,25 @@ def main():
                 "avg_launch_ms": tm["spread"] / timed,
                 "launches_timed": timed,
                 "launches_in_timed_region": launches,
+                "lanes": int(st.get("lanes", 1)),
+                "note": ("timed region: consecutive time steps run on two streams of equal priority, so this kernel shares the "
+                         "GPU with the other time step's row passes / gather while it runs -- its duration here is that of a "
+                         "kernel with part of the chip; `roofline_single_stream` is the same kernel with the chip to itself")
+                        if int(st.get("lanes", 1)) > 1 and int(st.get("lane_mode", 1)) == 0 else None,
             },
             "roofline_fft": fft,
             "roofline_interp": interp_rf,
             "kernels": kern,
         }
+        if breakdown and tm_all["spread"] > 0 and a.path == "type3":
+            # the spread kernel with the chip to itself (the extra single-stream step): same launches, same bytes
+            l2 = max(st_all["spread_launches"], 1.0)
+            g1 = (spread_bytes / launches) / (tm_all["spread"] / l2 * 1e-3) / 1e9
+            res["roofline_single_stream"] = {"kernel": spread_kernel, "bound": "hbm", "achieved": g1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": g1 / HBM_PEAK_GBS, "avg_launch_ms": tm_all["spread"] / l2,
+                                             "traffic": traffic,
+                                             "what": "one extra step on ONE stream with event records around every launch (the step "
+                                                     "`kernels`, `roofline_fft` and `roofline_interp` come from)"}
         if not a.no_e2e and world == 1 and a.as_rank is None:
             # ---- host to host: what a caller of simulate_vis() waits for (never `value`) -----------------
             # numpy in, numpy out (reference wrapper.py:85-336 -> cpu_simulate.py:843-854 returns a host array):

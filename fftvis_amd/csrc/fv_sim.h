@@ -1223,7 +1223,7 @@ class Sim : public SimBase {
     std::vector<std::pair<int, double>> mhist_log;  // (time index, transforms spread) per processed time
 
     // stats / timing
-    double st[16] = {0};
+    double st[24] = {0};
     int timing_level = 0;  // 1: spread only, sampled (events ride on the dispatches); 3: the same on every spread launch; 2: every kernel family
     int64_t targets_serial = 1;  // version of the device-side target data (baselines, frequencies, pair lists)
     struct Ev {
@@ -1300,7 +1300,10 @@ class Sim : public SimBase {
         FV_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         FV_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_greatest));
         lanes[0].stream = stream;
-        FV_HIP(hipStreamCreateWithFlags(&lanes[1].stream, hipStreamNonBlocking));
+        // the second lane's stream has the main stream's priority: two free-running lanes then share the dispatcher like two
+        // processes do (with a lower priority the second lane only ever filled the first one's tails)
+        FV_HIP(hipStreamCreateWithPriority(&lanes[1].stream, hipStreamNonBlocking,
+                                           std::getenv("FFTVIS_HIP_LANE1_LOW") ? (prio_least + prio_greatest) / 2 : prio_greatest));
         lanes[1].own_stream = true;
         FV_HIP(hipStreamCreateWithPriority(&prep_stream, hipStreamNonBlocking, prio_least));
         FV_HIP(hipEventCreateWithFlags(&lanes[1].done, hipEventDisableTiming));
@@ -2552,9 +2555,22 @@ class Sim : public SimBase {
         // two lanes while a group's grid buffers are small (launch-bound regime), else one
         int max_ntrans = 1;
         for (const auto &grp : groups) max_ntrans = std::max(max_ntrans, (grp.second - grp.first) * tg_max);
+        // Two lanes always (two sets of per-time scratch and grid buffers; consecutive time steps alternate), memory
+        // permitting.  Small grids (launch-bound) run them pipelined, see below.  Large grids (C3: 6 GiB of grid per
+        // launch) run them FREELY on two streams of equal priority: the kernels of two time steps then share the
+        // dispatcher like the kernels of two processes do -- a row pass of one step beside the spread or the gather of
+        // the other, compute-bound waves beside memory-bound ones -- which is what two ranks on one GPU had over one
+        // (843 against 883 ms per C3 step): 883 -> 844 ms in-process.  (With the second stream at a lower priority it
+        // only ever filled the first one's tails: 868.)  Kernel durations measured in this mode are those of kernels
+        // sharing the GPU.  FFTVIS_HIP_LANES=1: one stream.
+        const bool big_grids = cells_top * sizeof(cplx<T>) * max_ntrans > 1.5 * 1024 * 1024 * 1024;
         const char *el = std::getenv("FFTVIS_HIP_LANES");
-        int nlanes = el ? std::atoi(el)
-                        : (cells_top * sizeof(cplx<T>) * max_ntrans <= 1.5 * 1024 * 1024 * 1024 ? 2 : 1);
+        int nlanes = el ? std::atoi(el) : 2;
+        if (!el && big_grids) {  // a second set of grid buffers must fit comfortably
+            size_t mfree = 0, mtotal = 0;
+            FV_HIP(hipMemGetInfo(&mfree, &mtotal));
+            if (4.0 * cells_top * sizeof(cplx<T>) * max_ntrans > 0.5 * (double)mtotal) nlanes = 1;
+        }
         nlanes = std::max(1, std::min(2, std::min(nlanes, nt)));
         if (timing_level == 2) nlanes = 1;  // per-family event brackets only make sense on one stream
         // Two lanes, pipelined (default): every big kernel runs on the main (high-priority) stream,
@@ -2563,7 +2579,7 @@ class Sim : public SimBase {
         // tables) run on a low-priority stream beside step t's big kernels and fill their ramps
         // and tails.  FFTVIS_HIP_PIPE=0: the two lanes run freely on two streams instead.
         const char *ep = std::getenv("FFTVIS_HIP_PIPE");
-        const bool pipe = nlanes > 1 && !(ep && std::atoi(ep) == 0);
+        const bool pipe = nlanes > 1 && (ep ? std::atoi(ep) != 0 : !big_grids);
         // Gang mode (pipelined 2-D runs): two consecutive time steps share one launch each of the
         // spread and of every FFT pass (grid.y = 2: same geometry, their own sources and grids), which
         // halves the kernel boundaries per time step and doubles the workgroups that hide each other's
@@ -2578,6 +2594,8 @@ class Sim : public SimBase {
         // run stopped -- its first unit then takes the lanes that have been idle longest and prepares
         // beside the previous run's last big kernels.  A change of mode drains the streams instead.
         const int mode = gang ? 2 : pipe ? 1 : 0;
+        st[16] = nlanes;
+        st[17] = mode;
         if (mode != lane_mode) {
             FV_HIP(hipStreamSynchronize(stream));
             FV_HIP(hipStreamSynchronize(prep_stream));
@@ -2704,8 +2722,12 @@ class Sim : public SimBase {
             if (gang) {
                 Ls[0] = &lanes[(unit % 2) * 2];
                 Ls[1] = &lanes[(unit % 2) * 2 + 1];
-            } else {
+            } else if (pipe) {
                 Ls[0] = Ls[1] = &lanes[unit % nlanes];
+            } else {
+                // free-running lanes: the source chunks of one time step ADD to one another's visibilities, so they stay
+                // on one stream, in order
+                Ls[0] = Ls[1] = &lanes[tu % nlanes];
             }
             Lane &L0 = *Ls[0];
             const hipStream_t ls = pipe ? stream : L0.stream;        // big kernels
@@ -3027,7 +3049,7 @@ class Sim : public SimBase {
     }
     void stats(double *v, int n) override {
         fold_mhist();
-        for (int i = 0; i < n && i < 16; ++i) v[i] = st[i];
+        for (int i = 0; i < n && i < 24; ++i) v[i] = st[i];
     }
     void reset_stats() override {
         for (double &x : st) x = 0;

@@ -245,7 +245,10 @@ int fv_sim_sync(fv_sim *h);
  * passes priced as plain transforms (5 n2 log2 n2 per line transformed), [13] last n2 of the third dimension (1 for
  * 2-D runs), [14] last na of the third dimension, [15] height terms of the last run (K > 0: a non-coplanar array ran
  * as K 2-D transforms per slice, the expansion of exp(i z s_z) about the middle of the sources' height range; 0: no
- * expansion -- coplanar, or the 3-D transform).   */
+ * expansion -- coplanar, or the 3-D transform), [16] lanes of the last type-3 run (2: consecutive time steps alternate
+ * between two sets of scratch and grid buffers), [17] how they ran: 0 freely on two streams of equal priority (large
+ * grids: the kernels of two time steps share the GPU, and kernel durations are those of kernels sharing it), 1
+ * pipelined (big kernels in order on one stream, the next step's preparation beside them), 2 pipelined gangs.   */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,
