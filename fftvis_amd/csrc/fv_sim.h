@@ -1305,9 +1305,12 @@ class Sim : public SimBase {
         FV_HIP(hipStreamCreateWithPriority(&lanes[1].stream, hipStreamNonBlocking,
                                            std::getenv("FFTVIS_HIP_LANE1_LOW") ? (prio_least + prio_greatest) / 2 : prio_greatest));
         lanes[1].own_stream = true;
+        for (int li = 2; li < 4; ++li) {  // (free-running runs may use up to four lanes, FFTVIS_HIP_LANES)
+            FV_HIP(hipStreamCreateWithPriority(&lanes[li].stream, hipStreamNonBlocking, prio_greatest));
+            lanes[li].own_stream = true;
+        }
         FV_HIP(hipStreamCreateWithPriority(&prep_stream, hipStreamNonBlocking, prio_least));
-        FV_HIP(hipEventCreateWithFlags(&lanes[1].done, hipEventDisableTiming));
-        FV_HIP(hipEventCreateWithFlags(&lanes[0].done, hipEventDisableTiming));
+        for (Lane &L : lanes) FV_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
         for (Lane &L : lanes) {
             FV_HIP(hipEventCreateWithFlags(&L.prep_done, hipEventDisableTiming));
             FV_HIP(hipEventCreateWithFlags(&L.heavy_done, hipEventDisableTiming));
@@ -2571,15 +2574,16 @@ class Sim : public SimBase {
             FV_HIP(hipMemGetInfo(&mfree, &mtotal));
             if (4.0 * cells_top * sizeof(cplx<T>) * max_ntrans > 0.5 * (double)mtotal) nlanes = 1;
         }
-        nlanes = std::max(1, std::min(2, std::min(nlanes, nt)));
+        const char *ep = std::getenv("FFTVIS_HIP_PIPE");
+        const bool pipe_wanted = ep ? std::atoi(ep) != 0 : !big_grids;
+        nlanes = std::max(1, std::min(pipe_wanted ? 2 : 4, std::min(nlanes, nt)));
         if (timing_level == 2) nlanes = 1;  // per-family event brackets only make sense on one stream
         // Two lanes, pipelined (default): every big kernel runs on the main (high-priority) stream,
         // one time step after the other, so kernel durations stay uncontended; the dozen tiny
         // latency-bound preparation kernels of step t+1 (rotation, horizon cut, bin sort, weight
         // tables) run on a low-priority stream beside step t's big kernels and fill their ramps
         // and tails.  FFTVIS_HIP_PIPE=0: the two lanes run freely on two streams instead.
-        const char *ep = std::getenv("FFTVIS_HIP_PIPE");
-        const bool pipe = nlanes > 1 && (ep ? std::atoi(ep) != 0 : !big_grids);
+        const bool pipe = nlanes > 1 && pipe_wanted;
         // Gang mode (pipelined 2-D runs): two consecutive time steps share one launch each of the
         // spread and of every FFT pass (grid.y = 2: same geometry, their own sources and grids), which
         // halves the kernel boundaries per time step and doubles the workgroups that hide each other's
@@ -2599,7 +2603,8 @@ class Sim : public SimBase {
         if (mode != lane_mode) {
             FV_HIP(hipStreamSynchronize(stream));
             FV_HIP(hipStreamSynchronize(prep_stream));
-            if (lanes[1].stream) FV_HIP(hipStreamSynchronize(lanes[1].stream));
+            for (int li = 1; li < 4; ++li)
+                if (lanes[li].stream && lanes[li].own_stream) FV_HIP(hipStreamSynchronize(lanes[li].stream));
             for (Lane &L : lanes) L.heavy_pending = false;
             lane_mode = mode;
             lane_serial = 0;
@@ -2610,7 +2615,7 @@ class Sim : public SimBase {
             // at eps / e^a so that the sum keeps eps
             const double eps_plan = wt_K ? std::max(eps * std::exp(-wt_a), sizeof(T) == 8 ? 1e-14 : 1e-7) : eps;
             if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma || L.nufft->eps != eps_plan)
-                L.nufft.reset(new Nufft3<T>(D, eps_plan, sigma, li < 2 ? L.stream : stream));
+                L.nufft.reset(new Nufft3<T>(D, eps_plan, sigma, li < 2 || !pipe ? L.stream : stream));
             L.nufft->err_oob = d_err.as<int>();
             // the sources are 2 pi x (projections of unit vectors onto the array plane): inside a disc whatever the box
             L.nufft->disc_radius = D == 2 && !std::getenv("FFTVIS_HIP_NO_DISC") ? 2.0 * M_PI : 0.0;
@@ -2675,9 +2680,9 @@ class Sim : public SimBase {
             }
         }
         if (dbg_t) std::fprintf(stderr, "run: buffers and column plans %.3f s\n", pin.since());
-        if (nlanes > 1 && !pipe) {  // lane 1 starts after the output memset queued on the main stream
+        if (nlanes > 1 && !pipe) {  // the other lanes start after the output memset queued on the main stream
             FV_HIP(hipEventRecord(ev_start, stream));
-            FV_HIP(hipStreamWaitEvent(lanes[1].stream, ev_start, 0));
+            for (int li = 1; li < nlanes; ++li) FV_HIP(hipStreamWaitEvent(lanes[li].stream, ev_start, 0));
         }
 
         const int sample_step = std::min(TIMING_STRIDE / 2, nt - 1);  // level-1 timing: this step of every 16
@@ -2702,14 +2707,14 @@ class Sim : public SimBase {
                 tnext += nm;
             }
             // host output: once the last chunk of these time steps is queued, an event marks them finished
+            hipStream_t unit_stream = stream;  // where this unit's big kernels run (free-running lanes: the lane's own)
             auto close_time = [&]() {
                 if (!drain || chunk != nch - 1) return;
-                if (nlanes > 1 && !pipe) {  // free-running lanes: the step's chunks may sit on either stream
-                    FV_HIP(hipEventRecord(lanes[1].done, lanes[1].stream));
-                    FV_HIP(hipStreamWaitEvent(stream, lanes[1].done, 0));
-                }
                 const hipEvent_t ev = drain_event(drain_items.size());
-                FV_HIP(hipEventRecord(ev, stream));  // pipelined and single-lane runs: every big kernel is on `stream`
+                // pipelined and single-lane runs: every big kernel is on `stream`; free-running lanes: all chunks of a time
+                // step ran, in order, on its lane's stream -- the copy stream waits for THAT (the lanes never wait for
+                // each other)
+                FV_HIP(hipEventRecord(ev, unit_stream));
                 drain_items.push_back({ev, tu - t0, nm});
                 if (pin.pinned()) drain_flush(out, dout, nt, nf, per_tf, drain_items, drained, out_fs);
             };
@@ -2728,6 +2733,7 @@ class Sim : public SimBase {
                 // free-running lanes: the source chunks of one time step ADD to one another's visibilities, so they stay
                 // on one stream, in order
                 Ls[0] = Ls[1] = &lanes[tu % nlanes];
+                unit_stream = Ls[0]->stream;
             }
             Lane &L0 = *Ls[0];
             const hipStream_t ls = pipe ? stream : L0.stream;        // big kernels
@@ -2910,9 +2916,11 @@ class Sim : public SimBase {
             }
             close_time();
         }
-        if (nlanes > 1 && !pipe) {  // join: everything queued on the main stream afterwards sees both lanes
-            FV_HIP(hipEventRecord(lanes[1].done, lanes[1].stream));
-            FV_HIP(hipStreamWaitEvent(stream, lanes[1].done, 0));
+        if (nlanes > 1 && !pipe) {  // join: everything queued on the main stream afterwards sees every lane
+            for (int li = 1; li < nlanes; ++li) {
+                FV_HIP(hipEventRecord(lanes[li].done, lanes[li].stream));
+                FV_HIP(hipStreamWaitEvent(stream, lanes[li].done, 0));
+            }
         }
         if (!out_on_device) {
             if (drain && pin.wait()) {
