@@ -936,7 +936,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
     const int *__restrict__ bin_start, const cplx<T> *__restrict__ cs, int ntrans, int tbegin,
     int nchunk, const T *__restrict__ decx, const T *__restrict__ decy,
     const T *__restrict__ decz, cplx<T> *__restrict__ grid, int nax, int nay, int naz, int nbx,
-    int nby, int w) {
+    int nby, int w, const int *__restrict__ row_ext) {
     __shared__ cplx<T> s_str[SPREAD_THREADS / 64][SPREAD_CHUNK][TCH];
     __shared__ T s_kw[SPREAD_THREADS / 64][SPREAD_CHUNK][2][MAX_W];
     __shared__ int s_i0[SPREAD_THREADS / 64][SPREAD_CHUNK][2];
@@ -944,6 +944,9 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
     const int lane = threadIdx.x & 63;
     const int bx = blockIdx.x * 4 + wave, by = blockIdx.y;
     if (bx >= nbx) return;  // wave-uniform
+    // source disc (Nufft3::build_block_order): blocks outside the block row's extent are never touched by a source and
+    // never read by the x-pass -- not written either (whole 4-block groups, as in the 2-D launch list)
+    if (row_ext && (32 * (int)blockIdx.x >= row_ext[2 * by + 1] || 32 * (int)blockIdx.x + 32 <= row_ext[2 * by])) return;
     const int cz = blockIdx.z / nchunk;
     const int tbase = tbegin + (blockIdx.z % nchunk) * TCH;
     const int cx = (bx << BINLOG) + (lane & 7), cy = (by << BINLOG) + (lane >> 3);
@@ -996,7 +999,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_spread3d(
             }
         }
     }
-    const T f = decx[cx] * decy[cy] * decz[cz];
+    const T f = decx[cx] * decy[cy] * (decz ? decz[cz] : T(1));  // (no inner kernel along z when the targets sum the planes directly)
     const int64_t plane = (int64_t)naz * nay * nax;
     cplx<T> *o = grid + (int64_t)tbase * plane + ((int64_t)cz * nay + cy) * nax + cx;
 #pragma unroll
@@ -1383,6 +1386,9 @@ __device__ unsigned int fv_stamp_count;
 #ifndef FV_PAIR_DEFAULT
 #define FV_PAIR_DEFAULT 1
 #endif
+#ifndef FV_ST_TW2_LDS
+#define FV_ST_TW2_LDS 1  // pass-2 twiddles from a small LDS table (k_rowfft_st, TW2)
+#endif
 #ifndef FV_ST_CX32
 #define FV_ST_CX32 0  // fp32: whole complex values through the LDS exchange (k_rowfft_st, CX): measured slower, see there
 #endif
@@ -1651,9 +1657,19 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     constexpr bool CX = FV_ST_CX32 && sizeof(T) == 4 && !DUAL;
     using ST = std::conditional_t<CX, cplx<T>, T>;  // what an exchange slot holds
     __shared__ __attribute__((aligned(16))) ST smem[(DUAL ? 2 : 1) * RPW * ROW];
+    // Pass-2 twiddles w_{Q/R1}^{j3 k2} = tw[j3 k2 P R1] (j3 < R3, k2 < R2) from a table in LDS, R3 R2 entries (2-4 KB),
+    // filled from the global table at the start: the chain of R2 - 2 complex products per pass-2 item that formed the
+    // powers in registers -- 56 of a thread's ~930 fp64 instructions per job at Q = 2048 -- becomes R2 - 1 reads.
+    constexpr bool TW2 = FV_ST_TW2_LDS != 0;
+    __shared__ __attribute__((aligned(16))) cplx<T> s_tw2[TW2 ? R3 * R2 : 1];
 
     const int tid = threadIdx.x;
     const int vb = blockIdx.x;
+    if constexpr (TW2) {
+        // (before the early exits: every thread that stays reads the table after at least one workgroup barrier)
+        for (int e = tid; e < R3 * R2; e += THREADS) s_tw2[e] = tw[mul24(mul24(e / R2, e % R2), a.P * R1)];
+        if constexpr (WAVE) __syncthreads();  // rows of one wave synchronise by wave barriers only
+    }
     // line = the data row / column of this thread inside the workgroup, g = its residue group (PAIR), r = its exchange row
     const int line = COL ? tid % NL : (PAIR ? (tid / TPR) >> 1 : tid / TPR);
     const int u = COL ? (tid / NL) % TPR : tid % TPR;
@@ -2090,7 +2106,12 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     for (int i = 0; i < NI2; ++i) {
         const int j3 = (u + i * TPR) / R1;
         dif_regs<T, R2>(vb2[i]);
-        st_twiddle<T, R2>(vb2[i], tw[mul24(j3, a.P * R1)]);  // w_{Q/R1}^{j3 k2}
+        if constexpr (TW2) {
+#pragma unroll
+            for (int k = 1; k < R2; ++k) vb2[i][bitrev_small(k, L2)] = xmul(vb2[i][bitrev_small(k, L2)], s_tw2[j3 * R2 + k]);
+        } else {
+            st_twiddle<T, R2>(vb2[i], tw[mul24(j3, a.P * R1)]);  // w_{Q/R1}^{j3 k2}
+        }
     }
 
     // ---- exchange 2 -> pass 3 (pass-2 items write back to the slots they read: no sync before) --
@@ -2363,6 +2384,13 @@ struct InterpArgs {
     int wt_k;
     double wt_zc, wt_zh;
     const void *wt_bz;
+    // Direct third dimension (Nufft3::zdirect; the 2-D instantiations): the grid holds, per transform, zd_n (x, y)
+    // transforms -- one per z-plane of the spread grid, plane k at z_k = xc_z + (k - zd_n / 2) h_z -- and the target sums
+    // them with their exact phases,  sum_k exp(i (k - zd_n / 2) theta_z) G_k(s_x, s_y),  theta_z = h_z (s_z - s_c,z),
+    // divided by the kernel's transform at theta_z like every dimension: no transform pass and no interpolation along z
+    // (bt2 = the targets' third coordinate).  0: off.
+    int zd_n;
+    double zd_h, zd_btc, zd_xc;
 };
 
 // exp(i zc zq) (i zh zq)^k / k!
@@ -2439,25 +2467,38 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
         sv[d] = sc * sg * (double)bt[d][k];                     // actual target coordinate
         th[d] = a.h[d] * (sv[d] - sc * a.btc[d]);               // theta = h (s - s_c)
     }
+    // direct third dimension (2-D instantiations, see InterpArgs::zd_n): the target's third coordinate
+    const bool zd = DIM == 2 && a.zd_n > 0;  // uniform
+    double svz = 0.0, thz = 0.0;
+    if (zd) {
+        svz = sc * sg * (double)bt2[k];
+        thz = a.zd_h * (svz - sc * a.zd_btc);
+    }
     // psi_1_hat at every theta (an even function: the mirror target shares it): quadrature nodes split
     // over the 16 lanes
-    double hh[DIM];
+    double hh[DIM], hhz = 0.0;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) hh[d] = 0.0;
     for (int q = g; q < ker.nq; q += GROUP) {
 #pragma unroll
         for (int d = 0; d < DIM; ++d) hh[d] += ker.glf[q] * cos(th[d] * ker.glz[q]);
+        if (zd) hhz += ker.glf[q] * cos(thz * ker.glz[q]);
     }
 #pragma unroll
     for (int off = GROUP / 2; off > 0; off >>= 1) {
 #pragma unroll
         for (int d = 0; d < DIM; ++d) hh[d] += __shfl_xor(hh[d], off, 64);
+        if (zd) hhz += __shfl_xor(hhz, off, 64);
     }
     double den = 1.0, ph = 0.0;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
         den *= hh[d];
         ph += sv[d] * a.xc[d];  // post-phase exp(i s . x_c)
+    }
+    if (zd) {
+        den *= hhz;
+        ph += svz * a.zd_xc;
     }
     double pr = 1.0 / den, pi_ = 0.0;
     if (ph != 0.0) {
@@ -2517,9 +2558,36 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
         constexpr int RUNROLL = HERM ? NVAL : 1;  // HERM: two transforms, compile-time indexed results
 #pragma unroll RUNROLL
         for (int r = 0; r < (HERM ? NVAL : a.tpol); ++r) {
-            const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * plane_sz + gcol;
+            const cplx<T> *plane = grid + ((int64_t)fg * a.tpol + r) * (zd ? plane_sz * a.zd_n : plane_sz) + gcol;
             T sr = T(0), si = T(0);
-            for (int ro = 0; ro < nouter; ++ro) {
+            if (zd) {
+                // the zd_n planes of this transform, each gathered like a 2-D transform and turned by its phase
+                // exp(i (k - zd_n / 2) theta_z) (at the mirror target: -theta_z); the rotation walks from plane to plane
+                double er, ei, dr, di;
+                sincos(sgn * thz, &di, &dr);
+                sincos(-sgn * thz * (double)(a.zd_n / 2), &ei, &er);
+                double ar_ = 0.0, ai_ = 0.0;
+                for (int zk = 0; zk < a.zd_n; ++zk) {
+                    const cplx<T> *slab = plane + (int64_t)zk * plane_sz;
+                    cplx<T> v[NR];
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) v[rr] = slab[roff[rr]];
+                    T tr = T(0), ti = T(0);
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) {
+                        tr += v[rr].re * k1[rr];
+                        ti += v[rr].im * k1[rr];
+                    }
+                    ar_ += (double)tr * er - (double)ti * ei;
+                    ai_ += (double)tr * ei + (double)ti * er;
+                    const double e2 = er * dr - ei * di;
+                    ei = er * di + ei * dr;
+                    er = e2;
+                }
+                sr = (T)ar_;
+                si = (T)ai_;
+            }
+            for (int ro = 0; ro < (zd ? 0 : nouter); ++ro) {
                 T k2 = T(1);
                 const cplx<T> *slab = plane;
                 if (DIM == 3) {
@@ -2805,7 +2873,7 @@ class Nufft3 {
     double col_out_cells = 0;  // cells of C per transform the masked y-pass stores (0: all)
     void arm_columns(const int *tab, const int *xtab, int tpol, int ncc, int *err = nullptr, const unsigned long long *omask = nullptr,
                      int omask_nblk = 0) {
-        col_tab = tab && xtab && dim == 2 && b_block_log() ? tab : nullptr;
+        col_tab = tab && xtab && (dim == 2 || zdirect) && b_block_log() ? tab : nullptr;
         col_xtab = col_tab ? xtab : nullptr;
         col_tab_tpol = tpol;
         col_ncc = ncc;
@@ -2842,7 +2910,8 @@ class Nufft3 {
     }
     int xcols() const { return col_tab ? col_ncc : geo.d[0].nos(); }  // columns of B / rows of C per transform
     int b_block_log_public() const { return b_block_log(); }
-    bool columns_possible() const { return dim == 2 && b_block_log() != 0 && y_reads_columns() && !fused_possible(); }
+    // (3-D with the direct third dimension: every (transform, z) plane is a 2-D transform read by the same targets)
+    bool columns_possible() const { return (dim == 2 || zdirect) && b_block_log() != 0 && y_reads_columns() && !fused_possible(); }
     bool fused_possible() const;
     // Arms the fused gather for the next fft() (which then leaves no grid for interp()); false when the
     // configuration does not qualify and the caller must use interp().
@@ -2871,8 +2940,18 @@ class Nufft3 {
     DevBuf buf0, buf1;  // ping-pong: A -> (x-pass) B -> (transpose) Bt -> (y-pass) Ct
     DevBuf strengths;   // [M][ntrans] sorted order
 
+    // Direct third dimension (3-D): the spread grid is na_z planes along z -- for arrays that are anywhere near flat
+    // nearly all of them kernel width, not source range -- and the targets are few (10^4 - 10^5) against the 10^7
+    // (x, y) columns of the transform.  A z-pass would transform EVERY column (read na_z planes, write no_z: at C3z
+    // 14 GB per transform, two thirds of the whole 3-D FFT's time) for the gather to read a w_z-wide sliver of a
+    // thousandth of them; instead the x- and y-passes run per (transform, z) plane exactly as in 2-D and every target
+    // sums the na_z planes itself with their exact phases (InterpArgs::zd_n): na_z / w_z times the gather's loads, no
+    // z-pass, no inner kernel along z (one approximation less), and na_z no longer rounded up to whole bins.
+    // FFTVIS_HIP_NO_ZDIRECT=1: the three-pass transform.
+    bool zdirect = false;
     Nufft3(int dim_, double eps_, double sigma_, hipStream_t s, int w_override = 0)
         : dim(dim_), eps(eps_), sigma(sigma_), stream(s) {
+        zdirect = dim_ == 3 && !std::getenv("FFTVIS_HIP_NO_ZDIRECT");
         FV_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
         FV_REQUIRE(sigma == 2.0 || sigma == 1.25, "upsample factor must be 2 or 1.25");
         FV_REQUIRE(eps > 0 && eps < 1, "eps must be in (0, 1)");
@@ -2919,7 +2998,8 @@ class Nufft3 {
     static constexpr double disc_margin() { return sizeof(T) == 4 ? 1e-5 : 1e-6; }
     void build_block_order() {
         const int nbx = geo.nbin[0], nby = geo.nbin[1], ngx = (int)cdiv(nbx, 4);
-        const bool disc = disc_radius > 0.0 && dim == 2 && rowfft_uses_st(geo.d[0], false);  // (the LDS kernel reads whole rows)
+        // (3-D with the direct third dimension: the (x, y) projections of the sources lie in the same disc on every z-plane)
+        const bool disc = disc_radius > 0.0 && (dim == 2 || zdirect) && rowfft_uses_st(geo.d[0], false);  // (the LDS kernel reads whole rows)
         OrderKey key{(double)nbx, (double)nby, 0, 0, 0, 0, 0, 0, 0};
         if (disc) key = {(double)nbx, (double)nby, geo.d[0].xc, geo.d[1].xc, geo.d[0].h, geo.d[1].h, (double)geo.d[0].na, (double)ker.w, disc_radius};
         auto hit = order_cache->find(key);
@@ -3011,13 +3091,15 @@ class Nufft3 {
         for (int d = 0; d < dim; ++d) {
             g[d].X = X[d];
             g[d].B = B[d];
-            set_dim_geom(g[d], sigma, ker.w, scale_max, d == dim - 1, slack);
+            const bool last = zdirect ? d == 1 : d == dim - 1;  // the dimension the gather reads contiguously
+            set_dim_geom(g[d], sigma, ker.w, scale_max, last || d == 2, slack);
             if (d > 0) cap_column_q(g[d]);
-            g[d].rm = d != dim - 1 && !debug_switch_natural_order();
+            g[d].rm = !last && !debug_switch_natural_order();
+            if (zdirect && d == 2) g[d].na = g[d].n1;  // planes, not bins
             if (na_max) na_max[d] = std::max(na_max[d], g[d].na);
             if (n2_max) n2_max[d] = std::max(n2_max[d], g[d].n2);
         }
-        const int64_t zin = dim > 2 ? g[2].na : 1, zout = dim > 2 ? g[2].nos() : 1;
+        const int64_t zin = dim > 2 ? g[2].na : 1, zout = dim > 2 ? (zdirect ? g[2].na : g[2].nos()) : 1;
         const int64_t pitch = (g[0].nos() + 7) / 8 * 8;
         return std::max({zin * g[1].na * g[0].na, zin * g[1].na * pitch, zin * pitch * g[1].nos(), zout * pitch * g[1].nos()});
     }
@@ -3040,16 +3122,26 @@ class Nufft3 {
             geo.d[d].X = X[d];
             geo.d[d].btc = btc[d];
             geo.d[d].B = B[d];
-            set_dim_geom(geo.d[d], sigma, ker.w, scale_max, d == dim - 1, slack);
+            const bool last = zdirect ? d == 1 : d == dim - 1;  // the dimension the gather reads contiguously
+            set_dim_geom(geo.d[d], sigma, ker.w, scale_max, last || d == 2, slack);
             if (d > 0) cap_column_q(geo.d[d]);
             // (residue-major storage of the last dimension as well: C3's FFT passes -2.5 %, its gather +41 %)
-            geo.d[d].rm = d != dim - 1 && !debug_switch_natural_order();
+            geo.d[d].rm = !last && !debug_switch_natural_order();
             geo.nbin[d] = geo.d[d].na >> BINLOG;
+            if (zdirect && d == 2) {  // planes the sources can touch (even), in bins of eight, the last one short
+                geo.d[d].na = geo.d[d].n1;
+                geo.nbin[d] = (int)cdiv(geo.d[d].na, 1 << BINLOG);
+            }
         for (int d = dim; d < 3; ++d) geo.nbin[d] = 1;
         }
         if (first || old.nbin[0] != geo.nbin[0] || old.nbin[1] != geo.nbin[1] || disc_radius > 0.0) build_block_order();
         for (int d = 0; d < dim; ++d) {
             const DimGeom &g = geo.d[d];
+            if (zdirect && d == 2) {  // no transform along z: neither an inner kernel to undo nor twiddles
+                dec_cur[d] = nullptr;
+                tw_cur[d] = nullptr;
+                continue;
+            }
             if (old.d[d].na == g.na && old.d[d].n2 == g.n2 && dec_cur[d] && !first) continue;
             std::unique_ptr<DimTables> &e = tab_cache[d][{g.na, g.n2}];
             if (!e) {
@@ -3233,10 +3325,12 @@ class Nufft3 {
         const double zin = dim > 2 ? z.na : 1;
         auto f = [](const DimGeom &g) { return 5.0 * g.n2 * std::log2((double)g.n2); };
         double c = zin * y.na * f(x) + zin * (double)xcols() * f(y);
-        if (dim > 2) c += (double)x.nos() * y.nos() * f(z);
+        if (dim > 2 && !zdirect) c += (double)x.nos() * y.nos() * f(z);
         return c;
     }
-    int64_t spread_cells() const { return dim == 2 ? order_cells : geo.cells_a(); }  // cells of A the spread writes, per transform
+    int64_t spread_cells() const {  // cells of A the spread writes, per transform
+        return dim == 2 ? order_cells : row_ext_ptr ? order_cells * geo.d[2].na : geo.cells_a();
+    }
     // Targets: base coordinates bt* (device, indexed by global baseline id), optional subset
     // index list / flip flags of length N, per-group scale (device, nfg doubles).
     void interp(int64_t N, const T *btx, const T *bty, const T *btz, const int *bl_idx,
@@ -3305,7 +3399,7 @@ int Nufft3<T>::launch_spread(int ntrans, int tbegin, hipEvent_t e0, hipEvent_t e
                               (const cplx<T> *)strengths.as<cplx<T>>(), ntrans, tbegin, nchunk,
                               dec_cur[0], dec_cur[1],
                               dec_cur[2], buf0.as<cplx<T>>(), x.na, y.na, z.na,
-                              geo.nbin[0], geo.nbin[1], ker.w);
+                              geo.nbin[0], geo.nbin[1], ker.w, row_ext_ptr);
     }
     return tbegin + nchunk * TCH;
 }
@@ -3362,7 +3456,10 @@ int Nufft3<T>::b_block_log() const {
     const DimGeom &x = geo.d[0], &y = geo.d[1];
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
-    if (off || dim != 2 || !rowfft_uses_st(x, false) || !rowfft_uses_st(y, true) || !y_reads_columns()) return 0;
+    // (3-D: B sits between the x- and the y-pass of every (transform, z) plane exactly as in 2-D; FFTVIS_HIP_NO_BLOCKED_B3=1
+    // keeps the plain planes there)
+    static const bool off3 = std::getenv("FFTVIS_HIP_NO_BLOCKED_B3") != nullptr;
+    if (off || (dim != 2 && off3) || !rowfft_uses_st(x, false) || !rowfft_uses_st(y, true) || !y_reads_columns()) return 0;
     static const int force = std::getenv("FFTVIS_HIP_B_BLOCK_LOG") ? std::atoi(std::getenv("FFTVIS_HIP_B_BLOCK_LOG")) : 0;
     if (force) return force;
     return sizeof(cplx<T>) == 16 && rpw < 8 ? 2 : 3;  // 64-B pieces (fp32, and 8-column workgroups: 8 elements)
@@ -3371,7 +3468,7 @@ int Nufft3<T>::b_block_log() const {
 template <typename T>
 void Nufft3<T>::buffer_cells(int64_t &c0, int64_t &c1) const {
     const DimGeom &x = geo.d[0], &y = geo.d[1], &z = geo.d[2];
-    const int64_t zin = dim > 2 ? z.na : 1, zout = dim > 2 ? z.nos() : 1;
+    const int64_t zin = dim > 2 ? z.na : 1, zout = dim > 2 ? (zdirect ? z.na : z.nos()) : 1;
     const int64_t A = zin * y.na * x.na, B = zin * y.na * b_pitch(), C = zin * x.nos() * y.nos(),
                   D = zout * x.nos() * y.nos();
     c0 = std::max({A, B, C, D});  // either buffer may end up holding any stage (transpose or not)
@@ -3429,16 +3526,17 @@ void Nufft3<T>::rowfft(const cplx<T> *in, cplx<T> *out, const DimGeom &g, const 
     a.cnt = g.sP() > 1 ? g.cnt() : 0;
     a.in_blk = in_blk;
     a.out_blk = out_blk;
+    const int planes_per_trans = dim > 2 ? geo.d[2].na : 1;  // (3-D, direct third dimension: the z-planes of a transform share its plan)
     if (a.colmode && in_blk && col_tab && col_omask && !fused && g.logQ <= 11) {  // the y-pass of a column plan
         a.omask = col_omask;
-        a.omask_tpol = col_tab_tpol;
+        a.omask_tpol = col_tab_tpol * planes_per_trans;
         a.omask_nblk = col_omask_nblk;
     }
     if (first_pass_ext) a.row_ext = first_pass_ext;  // (row mode, register-resident kernels: fft() only sets it there)
     if (out_blk && col_tab) {  // the x-pass of a column plan
         a.ctab = col_xtab;
         a.ctab_stride = g.nos();
-        a.ctab_tpol = col_tab_tpol;
+        a.ctab_tpol = col_tab_tpol * planes_per_trans;
     }
     FV_REQUIRE((!in_blk && !out_blk) || rowfft_uses_st(g, a.colmode != 0), "blocked planes: register-resident passes only");
     // column-mode and blocked accesses are 32-bit byte offsets from a plane's base (buffer descriptors)
@@ -3564,11 +3662,11 @@ double Nufft3<T>::fft_traffic_cells() const {
     int tpr, rpw;
     rowfft_shape(y, true, tpr, rpw);
     const double xo = col_tab ? (double)col_ncc : (double)x.no;          // columns stored by the x-pass (column plan: those a target reads)
-    const double ain = dim == 2 && row_ext_ptr ? (double)order_cells : (double)x.na * y.na;  // cells of A inside the source disc
+    const double ain = row_ext_ptr ? (double)order_cells : (double)x.na * y.na;  // cells of A inside the source disc
     double c = zin * (ain + xo * y.na);                                  // x-pass
     if (!y_reads_columns()) c += zin * 2.0 * x.no * y.na;                 // transpose
     c += zin * (xo * y.na + (last_fft_fused ? 0.0 : col_tab && col_omask && col_out_cells > 0 ? col_out_cells : xo * y.no));  // y-pass (no C when fused)
-    if (dim > 2) c += (double)x.no * y.no * (z.na + z.no);               // z-pass
+    if (dim > 2 && !zdirect) c += (double)x.no * y.no * (z.na + z.no);   // z-pass
     return c;
 }
 
@@ -3613,7 +3711,7 @@ void Nufft3<T>::fft(int ntrans, Nufft3 *mate) {
         rowfft(oth, cur, y, tw_cur[1], np, x.nos(), (int64_t)x.nos() * y.na, y.na, 1, 0, 0, nullptr,
                oth1, cur1);
     }
-    if (dim > 2) {
+    if (dim > 2 && !zdirect) {
         // z-pass: C [t][na_z][nc] (nc = no_x no_y) -> D [t][nc][no_z]; adjacent (lx, ly) columns
         // are adjacent in memory, so the column-mode load is coalesced whenever rpw >= 4.
         const int64_t nc = (int64_t)x.nos() * y.nos();
@@ -3746,12 +3844,22 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.tpol = tpol;
     a.nfg = nfg;
     for (int i = 0; i < 3; ++i) a.P[i] = a.cnt[i] = 1;
-    // grid dimensions from fastest to slowest: 2-D (y, x), 3-D (z, y, x)
+    // grid dimensions from fastest to slowest: 2-D (y, x), 3-D (z, y, x); direct third dimension: (y, x) per z-plane
     const int map2[3] = {1, 0, 0}, map3[3] = {2, 1, 0};
-    const int *map = dim == 2 ? map2 : map3;
+    const bool zd = dim == 3 && zdirect;
+    const int gdim = zd ? 2 : dim;
+    const int *map = gdim == 2 ? map2 : map3;
     const T *bts[3] = {btx, bty, btz};
     const T *bt[3] = {nullptr, nullptr, nullptr};
-    for (int i = 0; i < dim; ++i) {
+    if (zd) {
+        FV_REQUIRE(btz, "3-D targets need their third coordinate");
+        a.zd_n = geo.d[2].na;
+        a.zd_h = geo.d[2].h;
+        a.zd_btc = geo.d[2].btc;
+        a.zd_xc = geo.d[2].xc;
+        bt[2] = btz;
+    }
+    for (int i = 0; i < gdim; ++i) {
         const DimGeom &g = geo.d[map[i]];
         a.n2[i] = g.n2;
         a.no[i] = g.no;
@@ -3770,7 +3878,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     for (int r = 0; r < 16; ++r) a.out_pol_off[r] = out_pol_off ? out_pol_off[r] : 0;
     a.accumulate = accumulate ? 1 : 0;
     if (col_tab) {
-        FV_REQUIRE(dim == 2, "column plan: 2-D transforms");
+        FV_REQUIRE(gdim == 2, "column plan: 2-D transforms (or 3-D ones with the direct third dimension)");
         a.ctab = col_tab;
         a.ctab_stride = geo.d[0].nos();
         a.ncc = col_ncc;
@@ -3791,7 +3899,7 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.items_per_xcd = cdiv(cdiv(items, 8), IPW) * IPW;  // whole workgroups
     const dim3 grid((unsigned)(8 * (a.items_per_xcd / IPW)));
     const bool r9 = ker.w <= 9;
-    auto kern = dim == 2 ? (herm ? (r9 ? k_interp<T, 2, true, 9> : k_interp<T, 2, true, 16>)
+    auto kern = gdim == 2 ? (herm ? (r9 ? k_interp<T, 2, true, 9> : k_interp<T, 2, true, 16>)
                                  : (r9 ? k_interp<T, 2, false, 9> : k_interp<T, 2, false, 16>))
                          : (herm ? (r9 ? k_interp<T, 3, true, 9> : k_interp<T, 3, true, 16>)
                                  : (r9 ? k_interp<T, 3, false, 9> : k_interp<T, 3, false, 16>));

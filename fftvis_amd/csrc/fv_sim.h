@@ -2618,7 +2618,7 @@ class Sim : public SimBase {
                 L.nufft.reset(new Nufft3<T>(D, eps_plan, sigma, li < 2 || !pipe ? L.stream : stream));
             L.nufft->err_oob = d_err.as<int>();
             // the sources are 2 pi x (projections of unit vectors onto the array plane): inside a disc whatever the box
-            L.nufft->disc_radius = D == 2 && !std::getenv("FFTVIS_HIP_NO_DISC") ? 2.0 * M_PI : 0.0;
+            L.nufft->disc_radius = (D == 2 || L.nufft->zdirect) && !std::getenv("FFTVIS_HIP_NO_DISC") ? 2.0 * M_PI : 0.0;
             L.nufft->transpose_flipped = !reference_compat;
             if (li > 0) L.nufft->order_cache = lanes[0].nufft->order_cache;  // one table per grid size for all lanes
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
@@ -2662,7 +2662,7 @@ class Sim : public SimBase {
                 FV_HIP(hipDeviceSynchronize());
                 col_plans.clear();
             }
-            if (D == 2 && !std::getenv("FFTVIS_HIP_NO_COLUMN_PLAN")) {
+            if ((D == 2 || lanes[0].nufft->zdirect) && !std::getenv("FFTVIS_HIP_NO_COLUMN_PLAN")) {
                 Nufft3<T> *n0 = lanes[0].nufft.get();
                 for (size_t gi = 0; gi < groups.size(); ++gi) {
                     double smax = 0;
