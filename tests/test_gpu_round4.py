@@ -279,3 +279,40 @@ def test_blocks_are_delivered_straight_into_a_slice_of_the_result(gpu, monkeypat
         eng.simulate(time_idx=slice(1, 4), freq_idx=slice(2, 5), out=fs[2:4, 1:4], **ks)
     del shared
     mm.close()
+
+
+def test_direct_third_dimension_equals_the_three_pass_transform(gpu, monkeypatch):
+    """The 3-D transform (arrays whose heights are too large for the height-term expansion) runs x- and y-passes per
+    (transform, z) plane and every target sums the planes with their exact phases; FFTVIS_HIP_NO_ZDIRECT=1 keeps the
+    z-pass + 3-D gather.  Both against the oracle's exact sums and each other: HERA-7 with 1.5 m of scatter (small grids),
+    HERA-350 with 1 m (8192^2-class planes: blocked B, column plan, source disc on every plane), packed and unpacked."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    c1 = synth.make_config("C1")
+    hrng = np.random.default_rng(5)
+    rough = {k: np.array([v[0], v[1], 1.5 * hrng.normal()]) for k, v in c1["ants"].items()}
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(c1["freqs"]), c1["freqs"])
+    big = _top_of_band(synth.make_config("C3", nsrc=20_000, ntimes=1, z_scatter=1.0), 2)
+    cases = {
+        "hera7 unpolarized": (dict(c1, ants=rough), None),
+        "hera7 polarized table": (dict(c1, ants=rough, polarized=True, beam=tab), None),
+        "hera350 1 m": (big, sorted(np.random.default_rng(2).choice(61075, 24, replace=False))),
+    }
+    monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+    for name, (cfg, sub) in cases.items():
+        got = {}
+        for mode in ("direct", "three-pass"):
+            gpu_simulate.release_handles()
+            if mode == "three-pass":
+                monkeypatch.setenv("FFTVIS_HIP_NO_ZDIRECT", "1")
+            got[mode] = fftvis_amd.simulate_vis(**cfg)
+            st = _last_handle_stats()
+            assert st["height_terms"] == 0 and st["n2_3"] > 1, (name, mode, st)  # a 3-D run, not the expansion
+            monkeypatch.delenv("FFTVIS_HIP_NO_ZDIRECT", raising=False)
+        gpu_simulate.release_handles()
+        sel = cfg if sub is None else dict(cfg, baselines=[cfg["baselines"][i] for i in sub])
+        exact = oracle_simulate(sel)
+        for mode, v in got.items():
+            vs = v if sub is None else v[..., sub]
+            assert rel_l2(vs, exact) < TOL, (name, mode)
+        assert rel_l2(got["direct"], got["three-pass"]) < 2 * TOL, name

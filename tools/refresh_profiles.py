@@ -1,20 +1,23 @@
 """Copies the outputs of tools/collect_profiles.sh (gpurun_out/final) into profiles/ under the round's names,
-rebuilds the PMC traffic summary and prints the numbers DESIGN.md quotes.  usage: python tools/refresh_profiles.py r03"""
+rebuilds the PMC traffic summary and prints the numbers DESIGN.md quotes.  usage: python tools/refresh_profiles.py r04"""
 import collections, csv, glob, json, os, re, shutil, sys
 
-tagr = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tagr = sys.argv[1] if len(sys.argv) > 1 else "r04"
 O = "gpurun_out/final"
 names = {"bench_c3": "c3_bench", "bench_c3_auto": "c3_bench_upsample_auto", "bench_c3_type1": "c3_bench_type1",
          "bench_c3_four_transforms": "c3_bench_four_transforms", "bench_c2": "c2_bench", "bench_c5": "c5_bench",
          "bench_c4slice": "c4slice_bench", "bench_c4_full": "c4_full_one_gpu_bench", "bench_c5_full": "c5_full_one_gpu_bench",
-         "bench_c3_two_ranks_one_gpu": "c3_two_ranks_on_one_gpu_rehearsal_bench"}
+         "bench_c3_two_ranks_one_gpu": "c3_two_ranks_on_one_gpu_rehearsal_bench",
+         "bench_c3_one_lane": "c3_bench_one_lane", "bench_c3_scattered": "c3_scattered_bench", "bench_c3z": "c3z_bench",
+         "bench_c3z_grid": "c3z_bench_grid_path", "bench_c3z_grid_three_pass": "c3z_bench_grid_path_three_pass",
+         "bench_c3z_1m": "c3z_1m_scatter_bench"}
 for w in ("C3", "C4"):
     for r in (0, 1):
         names[f"bench_{w}_rank{r}of8"] = f"{w.lower()}_rank{r}_of_8_block_bench"
 for src, dst in names.items():
     if os.path.exists(f"{O}/{src}.json") and os.path.getsize(f"{O}/{src}.json") > 10:
         shutil.copy(f"{O}/{src}.json", f"profiles/{tagr}_{dst}.json")
-TAGS = ("c3", "c2", "c4slice", "c3type1")
+TAGS = ("c3", "c2", "c4slice", "c3type1", "c3scattered", "c3z", "c3onelane", "c3zgrid")
 for tag in TAGS:
     f = sorted(glob.glob(f"{O}/prof_{tag}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
     if f:  # merged gpurun_out directories keep earlier runs' files: newest wins
@@ -55,7 +58,9 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
                "MI355X_MICROARCH.md (HBM section) FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950: "
                "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024.  c3 = bench.py --ntimes 1 (full-size launches of the "
                "default workload), c2 = --workload C2, c4slice = --workload C4 --nfreq 32 --ntimes 1, c3type1 = --path type1 "
-               "--ntimes 1.  k_rowfft_st sums every row / column pass.",
+               "--ntimes 1, c3zgrid = --workload C3z --nfreq 4 --ntimes 1 with FFTVIS_HIP_NO_WTERM=1 (the 3-D transform).  All "
+               "passes with FFTVIS_HIP_LANES=1: one stream, every kernel with the chip to itself.  k_rowfft_st sums every row / "
+               "column pass.",
        "counters": {}}
 for tag in TAGS:
     F, W = agg(f"{O}/pmc_FETCH_SIZE_{tag}"), agg(f"{O}/pmc_WRITE_SIZE_{tag}")
@@ -65,7 +70,7 @@ for tag in TAGS:
     out["counters"][tag] = {"logical_launches": nlog}
     fam = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for k in F:
-        base = "k_spread2d" if k == "k_spread2d" else k
+        base = k
         if k in W:
             fam[base][0] += F[k][0]
             fam[base][1] += W[k][0]
