@@ -1384,7 +1384,12 @@ __device__ unsigned int fv_stamp_count;
 #define FV_STAMP(slot)
 #endif
 #ifndef FV_PAIR_DEFAULT
-#define FV_PAIR_DEFAULT 1
+#define FV_PAIR_DEFAULT 0  // paired residue jobs (k_rowfft_st, PAIR): off since round 4 -- with the pass-2 table and two lanes the
+                           // unpaired jobs run C3 3 % faster (843 -> 816, 863 -> 837, 869 -> 841 ms per step), C4 2 %, C5 and the
+                           // scattered array 1 %; FFTVIS_HIP_PAIR = 1 (row mode) | 2 (column mode too) turn it on
+#endif
+#ifndef FV_ST_FOLD_SWEEPS3
+#define FV_ST_FOLD_SWEEPS3 1  // three sweeps of a fold chunk in one round trip where it has exactly three (k_rowfft_st, FOLD)
 #endif
 #ifndef FV_ST_TW2_LDS
 #define FV_ST_TW2_LDS 1  // pass-2 twiddles from a small LDS table (k_rowfft_st, TW2)
@@ -1945,6 +1950,23 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
                     }
                 }
             };
+            // sweeps per round trip: two (8 loads in flight), or -- row mode, fp64 -- three where a chunk has exactly three
+            // sweeps to make (rows of 2 Q < n_in < 3 Q: the first and last chunk of C3's 4 688-long rows at Q = 2048),
+            // which then take one round trip instead of two (12 loads in flight; the chunks' results va[] are still few
+            // when the first chunk runs, and the last chunk is the one register the allocation is sized by anyway)
+            constexpr int NSW = FV_ST_FOLD_SWEEPS3 && !COL && sizeof(T) == 8 ? 3 : 2;
+            if (NSW == 3 && m_hi - m_lo == 2) {
+                cplx<T> x[3][CH];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int off = (m_lo + t) * Q + hshift;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) x[t][j] = load_in(u + (h + j) * S1 + off);
+                }
+                accumulate(x[0]);
+                accumulate(x[1]);
+                accumulate(x[2]);
+            } else
             for (int m = m_lo; m <= m_hi; m += 2) {
                 cplx<T> x[2][CH];
 #pragma unroll
