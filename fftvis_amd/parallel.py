@@ -140,11 +140,18 @@ class DeviceCatalog:
 
 
 def broadcast_catalog_device(ra, dec, fluxes, polarized: bool, precision: int, device, src: int = 0,
-                             via_host: bool = False) -> DeviceCatalog:
+                             via_host: bool = False, freq_ranges=None) -> DeviceCatalog:
     """Rank ``src`` prepares the catalog (``prepare_source_catalog``, unit vectors), every rank receives
     it INTO DEVICE MEMORY with one broadcast per array -- RCCL over xGMI under the "nccl" backend; with a
     CPU group (gloo rehearsal on a one-GPU box, ``via_host=True``) through a host staging copy.  The only
-    collective of a sharded run (24 B/source + 8 nf B/source, 2 GB at C4)."""
+    collective of a sharded run (24 B/source + 8 nf B/source, 2 GB at C4).
+
+    ``freq_ranges``: ``callable(nsrc) -> [(f_lo, f_hi) | None per rank]`` -- the channels each rank's blocks cover.
+    The flux then travels as ONE point-to-point piece per rank holding only its channels (batched isend / irecv: rank
+    ``src`` feeds its xGMI links in parallel) instead of a broadcast of every channel to everybody: an 8-rank job cut
+    into 4 time x 2 frequency parts moves half the bytes per rank.  Every rank still holds a full-width flux tensor
+    (288 GB of HBM: the engine indexes channels by their catalog position); the columns it was not sent are zero and
+    never read."""
     import torch
     import torch.distributed as dist
 
@@ -169,7 +176,7 @@ def broadcast_catalog_device(ra, dec, fluxes, polarized: bool, precision: int, d
     else:
         eq = torch.empty((3, nsrc), dtype=rdt, device=device)
         flux = torch.empty(fshape, dtype=fdt, device=device)
-    for t in (eq, flux):
+    def bcast(t):
         tv = torch.view_as_real(t) if t.is_complex() else t  # RCCL has no complex type: the same bytes as reals
         if via_host:
             h = tv.cpu()
@@ -177,6 +184,38 @@ def broadcast_catalog_device(ra, dec, fluxes, polarized: bool, precision: int, d
             tv.copy_(h)
         else:
             dist.broadcast(tv, src=src)
+
+    bcast(eq)
+    if freq_ranges is None:
+        bcast(flux)
+    else:
+        world = dist.get_world_size()
+        ranges = freq_ranges(nsrc)
+        assert len(ranges) == world
+        if rank != src:
+            flux.zero_()
+        ops, keep, mine = [], [], None
+        for r, fr in enumerate(ranges):
+            if r == src or fr is None or fr[1] <= fr[0]:
+                continue
+            if rank == src:  # the rank's channels, packed
+                piece = flux[:, fr[0]:fr[1]].contiguous()
+                pv = torch.view_as_real(piece) if piece.is_complex() else piece
+                pv = pv.cpu() if via_host else pv
+                keep.append(pv)
+                ops.append(dist.P2POp(dist.isend, pv, r))
+            elif rank == r:
+                shape = (nsrc, fr[1] - fr[0]) + tuple(fshape[2:])
+                piece = torch.empty(shape, dtype=fdt, device="cpu" if via_host else device)
+                pv = torch.view_as_real(piece) if piece.is_complex() else piece
+                mine = (fr, piece)
+                ops.append(dist.P2POp(dist.irecv, pv, src))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if mine is not None:
+            fr, piece = mine
+            flux[:, fr[0]:fr[1]].copy_(piece)
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
     return DeviceCatalog(eq, flux, pol_sky)
@@ -388,10 +427,20 @@ def simulate_vis_sharded(device, gather_to: int | None = 0, via_host: bool = Fal
     kw["beam_list"] = list(beam) if isinstance(beam, (list, tuple)) else [beam]
     polarized, precision = bool(kw.get("polarized", False)), int(kw.get("precision", 2))
     max_memory, min_chunks = kw.pop("max_memory", np.inf), kw.pop("min_chunks", 1)
-    cat = broadcast_catalog_device(kw.pop("ra", None), kw.pop("dec", None), kw.pop("fluxes", None), polarized,
-                                   precision, torch.device("cuda", int(device)), via_host=via_host)
+    import torch.distributed as dist
+
     freqs = np.asarray(kw["freqs"])
     ntimes = len(julian_dates(kw["times"]))
+
+    def channels_of_rank(nsrc):  # what every rank's blocks cover: the flux columns it is sent
+        out = []
+        for blist in shard_blocks_weighted(dist.get_world_size(), freqs, ntimes, nsrc):
+            out.append((min(f.start for _, f in blist), max(f.stop for _, f in blist)) if blist else None)
+        return out
+
+    cat = broadcast_catalog_device(kw.pop("ra", None), kw.pop("dec", None), kw.pop("fluxes", None), polarized,
+                                   precision, torch.device("cuda", int(device)), via_host=via_host,
+                                   freq_ranges=channels_of_rank)
     engine = create_simulation_engine("gpu", device=int(device))
     if "nchunks" not in kw:  # the wrapper's memory knobs (reference wrapper.py:292-302), against this rank's device
         from .wrapper import device_chunks
@@ -403,8 +452,6 @@ def simulate_vis_sharded(device, gather_to: int | None = 0, via_host: bool = Fal
     def compute_block(tsl, fsl, out=None):
         return engine.simulate(ra=None, dec=None, fluxes=None, catalog_device=cat, time_idx=tsl, freq_idx=fsl,
                                out=out, out_shared=out is not None, **kw)
-
-    import torch.distributed as dist
 
     blocks = shard_blocks_weighted(dist.get_world_size(), freqs, ntimes, cat.nsrc)
     if gather not in ("auto", "shm", "p2p"):

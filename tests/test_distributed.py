@@ -82,6 +82,54 @@ def _shm_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _flux_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for pol_sky in (False, True):
+            cfg = synth.make_config("C1", nsrc=50, nfreq=10, ntimes=2)
+            _, _, fl = synth.catalog(50, cfg["freqs"], 3, polarized_sky=pol_sky)
+            ranges = [(0, 10), (4, 9), None][:world]
+            args = (cfg["ra"], cfg["dec"], fl) if rank == 0 else (None, None, None)
+            cat = parallel.broadcast_catalog_device(*args, True, 2, torch.device("cpu"), freq_ranges=lambda n: ranges)
+            full = parallel.broadcast_catalog_device(*args, True, 2, torch.device("cpu"))
+            assert torch.equal(cat.eq, full.eq) and cat.flux.shape == full.flux.shape
+            fr = ranges[rank]
+            if fr is not None:
+                assert torch.equal(cat.flux[:, fr[0]:fr[1]], full.flux[:, fr[0]:fr[1]])
+            if rank != 0:  # nothing else arrived
+                mask = torch.ones(10, dtype=torch.bool)
+                if fr is not None:
+                    mask[fr[0]:fr[1]] = False
+                assert not cat.flux[:, mask].any()
+        q.put(rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flux_travels_as_the_channels_each_rank_needs():
+    """SURVEY 8e / VERDICT r3 missing #5: the catalog's unit vectors are broadcast, the flux goes to every rank as one
+    point-to-point piece holding only the channels its blocks cover (real and 2 x 2 complex coherencies): those columns
+    equal the broadcast's, the rest of the rank's full-width tensor stays zero."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flux_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [0, 1, 2]
+
+
 def test_shared_result_is_filled_by_every_rank_and_leaves_no_file():
     """N > 1, one node: the result of a sharded run is ONE array in shared memory; every rank delivers its blocks into
     its own slice, rank 0 ends up with the assembled array, the /dev/shm name is gone as soon as every rank has mapped

@@ -241,3 +241,32 @@ def test_oracle_order3_table_is_scipy_map_coordinates():
     padj = np.concatenate([jt[1, 1, 0].imag] * 3, axis=1)
     np.testing.assert_allclose(r[1, 0, 0].imag, map_coordinates(padj, [za / (za_max / (nza - 1)), fa], order=3,
                                                                 mode="mirror"), atol=1e-12)
+
+
+def test_astrometry_restatement_against_erfa_where_it_is_installed():
+    """the per-source astrometry the device applies (fv_astrom_topo) is pinned to oracle/astrometry.py,
+    written from the published algorithm descriptions.  Where PyERFA is importable (never in the build pipeline, which
+    is why this skips there) the restatement is held against ERFA itself: ``erfa.apco13`` fills the context,
+    ``erfa.atciqz`` + ``erfa.atioq`` are the reference's per-source chain (matvis CoordinateRotationERFA), with and
+    without refraction."""
+    erfa = pytest.importorskip("erfa")
+    from oracle import astrometry as oa
+
+    rng = np.random.default_rng(4)
+    ra = rng.uniform(0, 2 * np.pi, 2000)
+    dec = np.arcsin(rng.uniform(-1, 1, 2000))
+    p = np.stack([np.cos(dec) * np.cos(ra), np.cos(dec) * np.sin(ra), np.sin(dec)])
+    elong, phi, hm = np.deg2rad(21.4283), np.deg2rad(-30.7215), 1050.0
+    for phpa in (0.0, 880.0):
+        astrom, _eo, _j = erfa.apco13(2459845.0, 0.3, 0.05, elong, phi, hm, 1e-7, 2e-7, phpa, 15.0, 0.3, 200.0)
+        a = astrom if astrom.shape == () else astrom[()]
+        ctx = np.concatenate([[a["pmt"]], np.ravel(a["eb"]), np.ravel(a["eh"]), [a["em"]], np.ravel(a["v"]), [a["bm1"]],
+                              np.ravel(a["bpn"]), [a["along"], a["phi"], a["xpl"], a["ypl"], a["sphi"], a["cphi"],
+                                                   a["diurab"], a["eral"], a["refa"], a["refb"]]]).astype(float)
+        assert ctx.shape == (31,)
+        ri, di = erfa.atciqz(ra, dec, astrom)
+        aob, zob, _hob, _dob, _rob = erfa.atioq(ri, di, astrom)
+        want = np.stack([np.sin(aob) * np.sin(zob), np.cos(aob) * np.sin(zob), np.cos(zob)])  # east, north, up
+        got = oa.icrs_to_enu(p, ctx)
+        up = want[2] > 0.1  # above the refraction formula's low-elevation guard
+        assert np.abs(got[:, up] - want[:, up]).max() < 1e-9, phpa
