@@ -2445,7 +2445,9 @@ __device__ inline cplx<double> wterm_factor(int k, double zc, double zh, double 
 // loads are in flight per lane group.  (With a uniform `if (rr < w)` around each row the compiler put every
 // load in a basic block of its own, followed by s_waitcnt vmcnt(0): one load in flight per wave, and the
 // gather spent 70 % of its time waiting for them one at a time.)
-template <typename T, int DIM, bool HERM, int NR>
+// ZD (direct third dimension, InterpArgs::zd_n) and WT (height terms, InterpArgs::wt_k) are compile-time: carried as run-time
+// branches they cost the plain 2-D gather 47 registers (146 -> 193 fp64, 98 -> 177 fp32: a wave per SIMD, 11-24 % of its time).
+template <typename T, int DIM, bool HERM, int NR, bool ZD = false, bool WT = false>
 __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
     const cplx<T> *__restrict__ grid, int64_t N, const T *__restrict__ bt0,
     const T *__restrict__ bt1, const T *__restrict__ bt2, const int *__restrict__ bl_idx,
@@ -2490,7 +2492,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
         th[d] = a.h[d] * (sv[d] - sc * a.btc[d]);               // theta = h (s - s_c)
     }
     // direct third dimension (2-D instantiations, see InterpArgs::zd_n): the target's third coordinate
-    const bool zd = DIM == 2 && a.zd_n > 0;  // uniform
+    constexpr bool zd = ZD && DIM == 2;
     double svz = 0.0, thz = 0.0;
     if (zd) {
         svz = sc * sg * (double)bt2[k];
@@ -2646,7 +2648,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                 const int64_t km = bl_idx ? bl_idx[m] : m;
                 const bool neg = (flip && flip[m]) != (a.negate_all != 0);
                 double vr = vr0, vi = vi0;
-                if (a.wt_k >= 0) {  // uniform: this member's height factor, before the conjugation
+                if constexpr (WT) {  // this member's height factor, before the conjugation
                     const cplx<double> f = wterm_factor(a.wt_k, a.wt_zc, a.wt_zh, sc * (neg ? -1.0 : 1.0) * (double)((const T *)a.wt_bz)[km]);
                     vr = vr0 * f.re - vi0 * f.im;
                     vi = vr0 * f.im + vi0 * f.re;
@@ -2730,7 +2732,7 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_interp(
                 }
             }
             cplx<double> wf = {1.0, 0.0};
-            if (a.wt_k >= 0)  // uniform: this member's height factor, applied before the conjugation
+            if constexpr (WT)  // this member's height factor, applied before the conjugation
                 wf = wterm_factor(a.wt_k, a.wt_zc, a.wt_zh, sc * (neg ? -1.0 : 1.0) * (double)((const T *)a.wt_bz)[km]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -3921,10 +3923,17 @@ void Nufft3<T>::interp(int64_t N, const T *btx, const T *bty, const T *btz, cons
     a.items_per_xcd = cdiv(cdiv(items, 8), IPW) * IPW;  // whole workgroups
     const dim3 grid((unsigned)(8 * (a.items_per_xcd / IPW)));
     const bool r9 = ker.w <= 9;
+    FV_REQUIRE(!(zd && wt), "height terms ride on 2-D runs, the direct third dimension on 3-D ones");
     auto kern = gdim == 2 ? (herm ? (r9 ? k_interp<T, 2, true, 9> : k_interp<T, 2, true, 16>)
                                  : (r9 ? k_interp<T, 2, false, 9> : k_interp<T, 2, false, 16>))
                          : (herm ? (r9 ? k_interp<T, 3, true, 9> : k_interp<T, 3, true, 16>)
                                  : (r9 ? k_interp<T, 3, false, 9> : k_interp<T, 3, false, 16>));
+    if (zd)
+        kern = herm ? (r9 ? k_interp<T, 2, true, 9, true, false> : k_interp<T, 2, true, 16, true, false>)
+                    : (r9 ? k_interp<T, 2, false, 9, true, false> : k_interp<T, 2, false, 16, true, false>);
+    if (wt)
+        kern = herm ? (r9 ? k_interp<T, 2, true, 9, false, true> : k_interp<T, 2, true, 16, false, true>)
+                    : (r9 ? k_interp<T, 2, false, 9, false, true> : k_interp<T, 2, false, 16, false, true>);
     hipLaunchKernelGGL(kern, grid, dim3(INTERP_THREADS), 0, stream, (const cplx<T> *)grid_out, N, bt[0], bt[1], bt[2],
                        bl_idx, flip, scale_dev, a, ker, out, coef, ant1, ant2, ustart, upairs);
 }
