@@ -402,6 +402,13 @@ class _SharedResult:
         return out
 
 
+def release_shared_results():
+    """Drop this process's mappings of the shared results of earlier sharded calls (the segments kept warm for the
+    next call of the same shape).  An array the owner still holds keeps its pages; everything else is returned to the
+    system.  Call it on every rank, or on none: the next call re-creates what is missing."""
+    _WARM.clear()
+
+
 def simulate_vis_sharded(device, gather_to: int | None = 0, via_host: bool = False, gather: str = "auto", **kw):
     """``simulate_vis`` across the ranks of the initialised process group, one GPU per rank.
 
