@@ -749,6 +749,20 @@ def main():
     # every rank: catalog broadcast from rank 0 into device memory, its block through the engine, delivered straight
     # into its slice of ONE shared-memory result while later time steps compute (parallel.simulate_vis_sharded)
     if dist is not None and not a.no_e2e and a.as_rank is None:
+        # (a safety net around a part no 8-GPU node has run yet: if the host-to-host calls have not finished after
+        # FFTVIS_BENCH_E2E_TIMEOUT seconds -- a collective stuck on some rank -- every rank leaves, rank 0 after printing
+        # the line it already has, with the timeout recorded instead of `e2e_sharded`)
+        import threading
+
+        def give_up(why="timed out: the sharded host-to-host calls did not finish"):
+            if rank == 0:
+                res["e2e_sharded"] = {"error": why}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(float(os.environ.get("FFTVIS_BENCH_E2E_TIMEOUT", "240")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
         h.close()
         outs.clear()
         del cat
@@ -757,16 +771,20 @@ def main():
         if rank != 0:
             kw["ra"] = kw["dec"] = kw["fluxes"] = None
         walls = []
-        for _ in range(2):
-            dist.barrier()
-            torch.cuda.synchronize()
-            t_e = time.perf_counter()
-            v = parallel.simulate_vis_sharded(device=local_rank, gather_to=0, via_host=backend != "nccl", **kw)
-            dist.barrier()
-            walls.append(time.perf_counter() - t_e)
-            nbytes = v.nbytes if v is not None else 0
-            fin = bool(np.isfinite(v[::max(1, v.shape[0] // 4)]).all()) if v is not None else True
-            del v
+        try:
+            for _ in range(2):
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_e = time.perf_counter()
+                v = parallel.simulate_vis_sharded(device=local_rank, gather_to=0, via_host=backend != "nccl", **kw)
+                dist.barrier()
+                walls.append(time.perf_counter() - t_e)
+                nbytes = v.nbytes if v is not None else 0
+                fin = bool(np.isfinite(v[::max(1, v.shape[0] // 4)]).all()) if v is not None else True
+                del v
+        except Exception as e:  # (a rank that failed, or a peer that left: the timed line is still printed)
+            give_up("failed on rank %d: %r" % (rank, e))
+        watchdog.cancel()
         if rank == 0:
             res["e2e_sharded"] = {
                 "what": "parallel.simulate_vis_sharded(**cfg) on all ranks: host arrays in on rank 0 (catalog broadcast into "
