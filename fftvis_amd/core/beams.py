@@ -42,12 +42,28 @@ def spline_order(spline_opts) -> int:
 
 
 def checked_spline_order(spline_opts) -> int:
-    """The orders the device interpolates: 1 (bilinear) and 3 (cubic B-spline, the reference CLI's
-    default, cli.py:50,146); anything else fails loudly."""
+    """The orders the device interpolates: everything scipy.ndimage.map_coordinates takes, 0 .. 5 (1 = bilinear
+    and 3 = cubic B-spline, the reference CLI's default, cli.py:50,146, have unrolled kernels; 0, 2, 4, 5 share
+    a general path); anything else fails loudly, as scipy does."""
     order = spline_order(spline_opts)
-    if order not in (1, 3):
-        raise NotImplementedError(f"GPU beam interpolation supports spline orders 1 and 3, not {order}")
+    if not 0 <= order <= 5:
+        raise ValueError(f"spline order not supported: {order} (beam interpolation takes orders 0 .. 5)")
     return order
+
+
+def bspline_weights(order: int, t):
+    """Values of the order + 1 cardinal B-splines of degree ``order`` that are non-zero at position ``t`` in [0, 1]
+    of a knot span (Cox - de Boor on uniform knots; the device's ``bspline_weights``, fv_sim.h)."""
+    t = np.asarray(t, dtype=float)
+    w = [np.ones_like(t)]
+    for j in range(1, order + 1):
+        saved = np.zeros_like(t)
+        for r in range(j):
+            tmp = w[r] / j
+            w[r] = saved + (r + 1 - t) * tmp
+            saved = (t + (j - r - 1)) * tmp
+        w.append(saved)
+    return w
 
 
 class AiryBeam:
@@ -64,7 +80,7 @@ class AiryBeam:
 
 
 class TabulatedBeam:
-    """Beam sampled on a regular (za, az) grid, interpolated on the device (order 1 or 3).
+    """Beam sampled on a regular (za, az) grid, interpolated on the device (orders 0 .. 5).
 
     data : (nfreq_tab, 2, 2, nza, naz) complex E-field Jones [vector axis, feed]  -- or --
            (nfreq_tab, nza, naz) real power.  nfreq_tab is 1 (achromatic) or the number of
@@ -166,37 +182,31 @@ def response_at(beam, polarized: bool, freq: float, az, za, use_feed: str = "x")
 
 def _interp_table(tab, za_max, az, za, order):
     """Host twin of the device interpolant (fv_sim.h eval_jones / eval_power) for ONE (nza, naz) plane, used
-    only to measure a sampled table's error: az periodic, za mirrored at both ends, order 1 bilinear or
-    order 3 interpolating cubic B-spline (scipy's ``spline_filter1d`` makes the coefficients, as pyuvdata's
-    az_za_map_coordinates -> scipy.ndimage.map_coordinates does for the reference, cpu/beams.py:69-74)."""
+    only to measure a sampled table's error: az periodic, za mirrored at both ends, order 1 bilinear, orders
+    2 .. 5 interpolating B-splines (scipy's ``spline_filter1d`` makes the coefficients, as pyuvdata's
+    az_za_map_coordinates -> scipy.ndimage.map_coordinates does for the reference, cpu/beams.py:69-74), 0 nearest."""
     nza, naz = tab.shape
-    fa = np.mod(az, 2 * np.pi) / (2 * np.pi / naz)
-    fz = np.clip(za / (za_max / (nza - 1)), 0, nza - 1)
+    half = 0.0 if order & 1 else 0.5  # even orders: the centred B-spline's knots sit at half-integers
+    fa = np.mod(az, 2 * np.pi) / (2 * np.pi / naz) + half
+    fz = np.clip(za / (za_max / (nza - 1)), 0, nza - 1) + half
     ia = np.floor(fa).astype(int)
-    iz = np.minimum(np.floor(fz).astype(int), nza - 2)
+    iz = np.minimum(np.floor(fz).astype(int), nza - 2) if order & 1 else np.floor(fz).astype(int)
     ta, tz = fa - ia, fz - iz
-    if order == 1:
-        ia1 = (ia + 1) % naz
-        ia = ia % naz
-        return (tab[iz, ia] * (1 - tz) * (1 - ta) + tab[iz, ia1] * (1 - tz) * ta
-                + tab[iz + 1, ia] * tz * (1 - ta) + tab[iz + 1, ia1] * tz * ta)
-    from scipy.ndimage import spline_filter1d
+    c = tab
+    if order >= 2:
+        from scipy.ndimage import spline_filter1d
 
-    def coefs(x):
-        return spline_filter1d(spline_filter1d(x, order=3, axis=0, mode="mirror"), order=3, axis=1, mode="grid-wrap")
+        def coefs(x):
+            return spline_filter1d(spline_filter1d(x, order=order, axis=0, mode="mirror"), order=order, axis=1, mode="grid-wrap")
 
-    c = coefs(tab.real) + 1j * coefs(tab.imag) if np.iscomplexobj(tab) else coefs(np.asarray(tab, float))
-
-    def bw(t):
-        return [(1 - t) ** 3 / 6, (4 - 6 * t**2 + 3 * t**3) / 6, (1 + 3 * t + 3 * t**2 - 3 * t**3) / 6, t**3 / 6]
-
-    wa, wz, per = bw(ta), bw(tz), 2 * (nza - 1)
+        c = coefs(tab.real) + 1j * coefs(tab.imag) if np.iscomplexobj(tab) else coefs(np.asarray(tab, float))
+    wa, wz, per = bspline_weights(order, ta), bspline_weights(order, tz), 2 * (nza - 1)
     out = 0
-    for k in range(4):
-        jz = np.mod(iz - 1 + k, per)
+    for k in range(order + 1):
+        jz = np.mod(iz - order // 2 + k, per)
         jz = np.where(jz < nza, jz, per - jz)
-        for m in range(4):
-            out = out + c[jz, np.mod(ia - 1 + m, naz)] * (wz[k] * wa[m])
+        for m in range(order + 1):
+            out = out + c[jz, np.mod(ia - order // 2 + m, naz)] * (wz[k] * wa[m])
     return out
 
 
@@ -251,8 +261,7 @@ def sample_response(beam, polarized: bool, freqs, use_feed: str = "x", order: in
     (measured, see the note above SAMPLED_START); raises ValueError when no table within the byte limit does.
     Returns (table, za_max)."""
     freqs = np.atleast_1d(np.asarray(freqs, dtype=float))
-    order = 3 if order == 3 else 1
-    nza, naz = SAMPLED_START[order]
+    nza, naz = SAMPLED_START[3 if order >= 2 else 1]  # (the refinement below measures the order actually used)
     rng = np.random.default_rng(0)
     f2 = np.unique([freqs.min(), freqs.max()])
     # azimuth-independent response?  (probed at the top frequency on a coarse (za, az) lattice)

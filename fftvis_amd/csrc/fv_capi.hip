@@ -245,7 +245,7 @@ static void beam_eval_host(int device, int polarized, int kind, double diameter,
                            int naz, double za_max, const void *table, int order, int fidx, double freq,
                            int64_t n, const void *az, const void *za, void *out) {
     FV_REQUIRE(kind == 0 || kind == 1, "beam kind must be 0 (Airy) or 1 (table)");
-    FV_REQUIRE(order == 1 || order == 3, "beam interpolation order must be 1 or 3");
+    FV_REQUIRE(order >= 0 && order <= 5, "beam interpolation order must be 0 .. 5");
     FV_REQUIRE(n >= 0 && (n == 0 || (az && za && out)), "bad beam_eval arrays");
     FV_HIP(hipSetDevice(device));
     if (n == 0) return;
@@ -275,7 +275,8 @@ static void beam_eval_host(int device, int polarized, int kind, double diameter,
             hipLaunchKernelGGL(k_jones_interleave, dim3((unsigned)cdiv(nodes * nft, 256)), dim3(256), 0, sg.s,
                                dtab_in.as<cplx<double>>(), dtab.as<cplx<double>>(), nodes, (int64_t)nft);
         }
-        if (order == 3) bspline3_prefilter(dtab.as<double>(), nft, nza, naz, polarized ? 8 : 1, sg.s);
+        bspline_prefilter(dtab.as<double>(), nft, nza, naz, polarized ? 8 : 1, order, sg.s);
+        b.order = order;
         b.table = dtab.p;
         b.nfreq_tab = nft;
         b.nza = nza;
@@ -290,7 +291,7 @@ static void beam_eval_host(int device, int polarized, int kind, double diameter,
     dout.reserve(sizeof(cplx<T>) * nout);
     FV_HIP(hipMemcpyAsync(daz.p, az, sizeof(T) * n, hipMemcpyHostToDevice, sg.s));
     FV_HIP(hipMemcpyAsync(dza.p, za, sizeof(T) * n, hipMemcpyHostToDevice, sg.s));
-    hipLaunchKernelGGL((order == 3 ? k_beam_eval<T, 3> : k_beam_eval<T, 1>), dim3(cdiv(n, 256)), dim3(256), 0, sg.s, b, polarized, fidx,
+    hipLaunchKernelGGL((order == 3 ? k_beam_eval<T, 3> : order == 1 ? k_beam_eval<T, 1> : k_beam_eval<T, 0>), dim3(cdiv(n, 256)), dim3(256), 0, sg.s, b, polarized, fidx,
                        freq, n, daz.as<T>(), dza.as<T>(), dout.as<cplx<T>>());
     FV_HIP(hipMemcpyAsync(out, dout.p, sizeof(cplx<T>) * nout, hipMemcpyDeviceToHost, sg.s));
     FV_HIP(hipStreamSynchronize(sg.s));

@@ -24,6 +24,7 @@ constexpr double SPEED_OF_LIGHT = 299792458.0;  // core/utils.py:9
 
 struct BeamDesc {
     int kind;            // 0 Airy, 1 table
+    int order;           // tables: interpolation order 0..5 (read by the general-order path only, eval_* <ORD = 0>)
     double diameter;     // Airy
     double js[8];        // Airy: complex factor per Jones slot A[ax][feed] = js . 2 J1(x)/x  (re, im pairs)
     double ps;           // Airy: factor of the power beam, ps . (2 J1(x)/x)^2
@@ -177,11 +178,61 @@ __device__ inline Cubic cubic_setup(const BeamDesc &b, double az, double za) {
     return o;
 }
 
-// scipy.ndimage.spline_filter1d(order = 3) in place, one line per thread, on a table stored as
+// Any order 0 .. 5 (beam_spline_opts {"order": n}; scipy.ndimage.map_coordinates semantics as for order 3): the
+// n + 1 nodes start at floor(x) - n / 2 (odd n) or floor(x + 1/2) - n / 2 (even n: the centred B-spline's knots sit
+// at half-integers) and carry the cardinal B-spline's values, built by the Cox - de Boor triangle on uniform knots
+// (every denominator is the level j).  Orders 1 and 3 have their own unrolled paths above; this one runs the
+// others (0: nearest node; 2, 4, 5: on coefficients from k_bspline_prefilter) with the order read at run time.
+struct SplineN {
+    int n;  // order
+    int ia[6], iz[6];
+    double wa[6], wz[6];
+};
+
+__device__ inline void bspline_weights(int n, double t, double w[6]) {  // t in [0, 1]: position inside the knot span
+    w[0] = 1.0;
+    for (int j = 1; j <= n; ++j) {
+        double saved = 0.0;
+        const double inv = 1.0 / j;
+        for (int r = 0; r < j; ++r) {
+            const double right = r + 1 - t, left = t + (j - r - 1);
+            const double tmp = w[r] * inv;
+            w[r] = saved + right * tmp;
+            saved = left * tmp;
+        }
+        w[j] = saved;
+    }
+}
+
+__device__ inline SplineN spline_setup(const BeamDesc &b, double az, double za) {
+    SplineN o;
+    const int n = o.n = b.order;
+    const double half = n & 1 ? 0.0 : 0.5;
+    const double twopi = 2.0 * M_PI;
+    double a = fmod(az, twopi);
+    if (a < 0) a += twopi;
+    const double fa = a / (twopi / b.naz) + half;
+    const int ia0 = (int)floor(fa);
+    bspline_weights(n, fa - ia0, o.wa);
+    for (int k = 0; k <= n; ++k) o.ia[k] = ((ia0 - n / 2 + k) % b.naz + b.naz) % b.naz;
+    double fz = za / (b.za_max / (b.nza - 1));
+    fz = fmin(fmax(fz, 0.0), (double)(b.nza - 1)) + half;
+    const int iz0 = n & 1 ? min((int)floor(fz), b.nza - 2) : (int)floor(fz);
+    bspline_weights(n, fz - iz0, o.wz);
+    const int per = 2 * (b.nza - 1);
+    for (int k = 0; k <= n; ++k) {
+        const int j = ((iz0 - n / 2 + k) % per + per) % per;
+        o.iz[k] = j < b.nza ? j : per - j;
+    }
+    return o;
+}
+
+// scipy.ndimage.spline_filter1d(order) in place, one line per thread, on a table stored as
 // [freq][za][az][C] doubles: axis 0 = za lines (mode "mirror"), axis 1 = az lines ("grid-wrap").
-// Pole z = sqrt(3) - 2, gain 6; boundary sums run over the whole line (exact, as scipy's).
-__global__ void k_bspline3_prefilter(double *__restrict__ data, int64_t nfreq, int nza, int naz, int C,
-                                     int axis) {
+// One causal + anticausal sweep per pole (order 2: sqrt(8) - 3; 3: sqrt(3) - 2; 4 and 5: two poles each), after the
+// gain prod (1 - z)(1 - 1 / z); boundary sums run over the whole line (exact, as scipy's).
+__global__ void k_bspline_prefilter(double *__restrict__ data, int64_t nfreq, int nza, int naz, int C,
+                                    int axis, int order) {
     const int nother = axis == 0 ? naz : nza;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nfreq * nother * C) return;
@@ -202,8 +253,28 @@ __global__ void k_bspline3_prefilter(double *__restrict__ data, int64_t nfreq, i
         n = naz;
     }
     if (n < 2) return;
-    const double z = sqrt(3.0) - 2.0;
-    for (int i = 0; i < n; ++i) p[i * st] *= 6.0;
+    double poles[2];
+    int npoles = 1;
+    switch (order) {
+        case 2: poles[0] = sqrt(8.0) - 3.0; break;
+        case 3: poles[0] = sqrt(3.0) - 2.0; break;
+        case 4:
+            npoles = 2;
+            poles[0] = sqrt(664.0 - sqrt(438976.0)) + sqrt(304.0) - 19.0;
+            poles[1] = sqrt(664.0 + sqrt(438976.0)) - sqrt(304.0) - 19.0;
+            break;
+        case 5:
+            npoles = 2;
+            poles[0] = sqrt(67.5 - sqrt(4436.25)) + sqrt(26.25) - 6.5;
+            poles[1] = sqrt(67.5 + sqrt(4436.25)) - sqrt(26.25) - 6.5;
+            break;
+        default: return;  // orders 0 and 1 interpolate the samples themselves
+    }
+    double gain = 1.0;
+    for (int q = 0; q < npoles; ++q) gain *= (1.0 - poles[q]) * (1.0 - 1.0 / poles[q]);
+    for (int i = 0; i < n; ++i) p[i * st] *= gain;
+    for (int q = 0; q < npoles; ++q) {
+    const double z = poles[q];
     if (axis == 0) {  // mirror
         const double zn1 = pow(z, (double)(n - 1));
         double c0 = p[0] + zn1 * p[(n - 1) * st], zi = z;
@@ -240,6 +311,7 @@ __global__ void k_bspline3_prefilter(double *__restrict__ data, int64_t nfreq, i
         next = z * (next - p[i * st]);
         p[i * st] = next;
     }
+    }  // poles
 }
 
 // [freq][4][za][az] (caller's layout) -> [freq][za][az][4] (device layout of Jones tables)
@@ -251,14 +323,17 @@ __global__ void k_jones_interleave(const cplx<double> *__restrict__ in, cplx<dou
     for (int j = 0; j < 4; ++j) out[(f * nodes + nd) * 4 + j] = in[(f * 4 + j) * nodes + nd];
 }
 
-// samples -> cubic B-spline coefficients, both axes (order-3 tables only; once per upload)
-inline void bspline3_prefilter(double *table, int64_t nfreq, int nza, int naz, int C, hipStream_t s) {
+// samples -> B-spline coefficients of the given order, both axes (orders >= 2; once per upload)
+inline void bspline_prefilter(double *table, int64_t nfreq, int nza, int naz, int C, int order, hipStream_t s) {
+    if (order < 2) return;
     for (int axis = 0; axis < 2; ++axis) {
         const int64_t lines = nfreq * (axis == 0 ? naz : nza) * C;
-        hipLaunchKernelGGL(k_bspline3_prefilter, dim3((unsigned)cdiv(lines, 64)), dim3(64), 0, s, table, nfreq,
-                           nza, naz, C, axis);
+        hipLaunchKernelGGL(k_bspline_prefilter, dim3((unsigned)cdiv(lines, 64)), dim3(64), 0, s, table, nfreq,
+                           nza, naz, C, axis, order);
     }
 }
+// kernel variant for an order: 1 and 3 unrolled, everything else through the general path (template value 0)
+inline int beam_order_variant(int order) { return order == 1 || order == 3 ? order : 0; }
 
 // Jones matrix A[ax][feed] (row-major, 4 complex) of one beam at one (source, frequency).
 template <int ORD>
@@ -270,6 +345,22 @@ __device__ inline void eval_jones(const BeamDesc &b, int fidx, double freq, doub
         return;
     }
     const int ft = b.nfreq_tab > 1 ? fidx : 0;
+    if (ORD == 0) {
+        const SplineN w = spline_setup(b, az, za);
+        const cplx<double> *tab = (const cplx<double> *)b.table + (int64_t)ft * 4 * b.nza * b.naz;
+        for (int i = 0; i < 4; ++i) A[i] = {0.0, 0.0};
+        for (int k = 0; k <= w.n; ++k)
+            for (int l = 0; l <= w.n; ++l) {
+                const double wt = w.wz[k] * w.wa[l];
+                const cplx<double> *nd = tab + ((int64_t)w.iz[k] * b.naz + w.ia[l]) * 4;
+                for (int i = 0; i < 4; ++i) {
+                    const cplx<double> v = nd[i];
+                    A[i].re += v.re * wt;
+                    A[i].im += v.im * wt;
+                }
+            }
+        return;
+    }
     if (ORD == 3) {
         const Cubic w = cubic_setup(b, az, za);
         const cplx<double> *tab = (const cplx<double> *)b.table + (int64_t)ft * 4 * b.nza * b.naz;
@@ -311,6 +402,13 @@ __device__ inline double eval_power(const BeamDesc &b, int fidx, double freq, do
     }
     const int ft = b.nfreq_tab > 1 ? fidx : 0;
     const double *p = (const double *)b.table + (int64_t)ft * b.nza * b.naz;
+    if (ORD == 0) {
+        const SplineN w = spline_setup(b, az, za);
+        double acc = 0.0;
+        for (int k = 0; k <= w.n; ++k)
+            for (int l = 0; l <= w.n; ++l) acc += w.wz[k] * w.wa[l] * p[(int64_t)w.iz[k] * b.naz + w.ia[l]];
+        return acc;
+    }
     if (ORD == 3) {
         const Cubic w = cubic_setup(b, az, za);
         double acc = 0.0;
@@ -1463,7 +1561,7 @@ class Sim : public SimBase {
         FV_HIP(hipSetDevice(device));
         FV_REQUIRE(b >= 0 && b < (int)beams.size(), "beam index out of range");
         FV_REQUIRE(nza >= 2 && naz >= 1 && nft >= 1 && za_max > 0, "bad beam table shape");
-        FV_REQUIRE(order == 1 || order == 3, "beam interpolation order must be 1 or 3");
+        FV_REQUIRE(order >= 0 && order <= 5, "beam interpolation order must be 0 .. 5");
         for (size_t i = 0; i < beams.size(); ++i)  // one spline_opts per simulation (cpu_simulate.py:557)
             FV_REQUIRE((int)i == b || beams[i].kind != 1 || beam_order == order,
                        "all tabulated beams of a handle share one interpolation order");
@@ -1493,7 +1591,7 @@ class Sim : public SimBase {
                                tmp.as<cplx<double>>(), bm.table->template as<cplx<double>>(), nodes, (int64_t)nft);
             FV_HIP(hipStreamSynchronize(stream));  // tmp goes out of scope
         }
-        if (order == 3) bspline3_prefilter(bm.table->template as<double>(), nft, nza, naz, polarized ? 8 : 1, stream);
+        bspline_prefilter(bm.table->template as<double>(), nft, nza, naz, polarized ? 8 : 1, order, stream);
     }
     std::vector<int> in_bi, in_bj, in_idx;  // the caller's last pair lists, as given
     std::vector<int64_t> in_off;
@@ -2041,7 +2139,7 @@ class Sim : public SimBase {
                     sa.dim = 2;
                     sa.bi = desc(pr.bi);
                     sa.bj = desc(pr.bj);
-                    hipLaunchKernelGGL((beam_order == 3 ? k_t1_strengths<T, 3> : k_t1_strengths<T, 1>),
+                    hipLaunchKernelGGL((beam_order == 3 ? k_t1_strengths<T, 3> : beam_order == 1 ? k_t1_strengths<T, 1> : k_t1_strengths<T, 0>),
                                        dim3(cdiv(ecap, 256)), dim3(256), 0, stream,
                                        sa, nent, ecap, (const unsigned char *)recs.as<unsigned char>(), rec,
                                        d_srcidx.as<int>(),
@@ -2990,7 +3088,7 @@ class Sim : public SimBase {
         sa.wt_zc = wt_zc;
         sa.wt_inv = wt_zh > 0 ? 1.0 / wt_zh : 0.0;
         cplx<T> *cs = nufft->strengths_buffer(nfg * (pr.herm ? 2 : tpol));
-        hipLaunchKernelGGL((beam_order == 3 ? k_strengths<T, 3> : k_strengths<T, 1>),
+        hipLaunchKernelGGL((beam_order == 3 ? k_strengths<T, 3> : beam_order == 1 ? k_strengths<T, 1> : k_strengths<T, 0>),
                            dim3(cdiv((int64_t)M * nfg, 256)), dim3(256), 0, on, sa, Mp,
                            nufft->perm.template as<int>(), L.d_srcidx.template as<int>(),
                            L.d_az.template as<T>(), L.d_za.template as<T>(), d_flux.p, d_freqs.as<double>(),
@@ -3004,6 +3102,7 @@ class Sim : public SimBase {
         const Beam &bm = beams[b];
         BeamDesc d{};
         d.kind = bm.kind;
+        d.order = beam_order;
         d.diameter = bm.diameter;
         for (int i = 0; i < 8; ++i) d.js[i] = bm.js[i];
         d.ps = bm.ps;

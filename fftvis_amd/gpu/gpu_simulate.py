@@ -388,10 +388,10 @@ class GPUSimulationEngine(SimulationEngine):
           exact forms -- flipped baselines of a two-beam polarized pair become V_ij(-b)^H (conjugated AND feed
           block transposed; the reference only conjugates, cpu_simulate.py:298), and the eigenbeam (l, k) term
           becomes conj(V_kl(-b))^T (one more gather at -b; exact for complex basis beams too);
-        * ``beam_spline_opts``: order 1 (bilinear, also when None) or 3 (cubic B-spline; ``kx/ky``
-          of ``az_za_simple`` are read the same way -- both interpolation functions of the reference
-          are regular-grid splines of that order and map onto the same device interpolant); other
-          orders raise NotImplementedError;
+        * ``beam_spline_opts``: orders 0 .. 5 as scipy.ndimage.map_coordinates takes them (1 = bilinear, also when
+          None; 3 = cubic B-spline; ``kx/ky`` of ``az_za_simple`` are read the same way -- both interpolation
+          functions of the reference are regular-grid splines of that order and map onto the same device
+          interpolant); other orders raise ValueError;
         * ``use_feed`` (extra; the reference's wrapper applies it before the engine,
           wrapper.py:278-279): the feed whose power pattern an unpolarized run takes from an E-field beam;
         * ``upsample_factor``: 2 (default, as the reference) or 1.25 are used as given; ``None`` /

@@ -163,8 +163,9 @@ int fv_sim_set_array_type1(fv_sim *h, const double *basis_matrix, int64_t nbls, 
  *   unpolarized: (nfreq_tab, nza, naz) float64 power
  * with az periodic over 2 pi, za in [0, za_max] inclusive; nfreq_tab is 1 or nfreq.
  * order = beam_spline_opts["order"] (cpu/beams.py:69-74 -> pyuvdata az_za_map_coordinates ->
- * scipy.ndimage.map_coordinates): 1 = bilinear; 3 = interpolating cubic B-spline (the table is
- * turned into spline coefficients on the device at upload; periodic in az, mirrored in za).
+ * scipy.ndimage.map_coordinates): 0 = nearest node; 1 = bilinear; 2 .. 5 = interpolating B-spline of that
+ * degree (the table is turned into spline coefficients on the device at upload; periodic in az,
+ * mirrored in za).  1 and 3 have unrolled kernels, the others share one general path.
  * One order per handle.                                                                       */
 int fv_sim_set_nbeams(fv_sim *h, int nbeams);
 int fv_sim_set_beam_airy(fv_sim *h, int beam, double diameter);

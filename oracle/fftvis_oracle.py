@@ -417,7 +417,7 @@ class AiryBeam:
 
 
 class TabulatedBeam:
-    """A UVBeam-like table on a regular (za, az) grid, order-1 or order-3 interpolation.
+    """A UVBeam-like table on a regular (za, az) grid, interpolation order 0 .. 5 (1: bilinear, 3: cubic).
 
     data[freq, ax, feed, iza, iaz] complex (efield) or data[freq, iza, iaz]
     real (power).  az is periodic with period 2*pi (naz cells of width
@@ -434,42 +434,68 @@ class TabulatedBeam:
         self.za_max = float(za_max)
         self.beam_type = beam_type
         self.nza, self.naz = self.data.shape[-2:]
-        if order not in (1, 3):
-            raise ValueError("order must be 1 or 3")
+        if order not in (0, 1, 2, 3, 4, 5):
+            raise ValueError("order must be 0 .. 5 (scipy.ndimage.map_coordinates' range)")
         self.order = order
         self._coef = None
 
-    def _cubic(self, fi, az, za):
+    @staticmethod
+    def _basis(n, x):
+        """Centred cardinal B-spline of degree n at x (the closed piecewise polynomials scipy.ndimage
+        interpolates with; written out per degree, independently of the device's recurrence)."""
+        x = np.abs(np.asarray(x, float))
+        if n == 0:
+            return np.where(x < 0.5, 1.0, np.where(x == 0.5, 0.5, 0.0))
+        if n == 1:
+            return np.clip(1 - x, 0, None)
+        if n == 2:
+            return np.where(x < 0.5, 0.75 - x**2, np.where(x < 1.5, 0.5 * (1.5 - x) ** 2, 0.0))
+        if n == 3:
+            return np.where(x < 1, (4 - 6 * x**2 + 3 * x**3) / 6, np.where(x < 2, (2 - x) ** 3 / 6, 0.0))
+        if n == 4:
+            return np.where(x < 0.5, x**4 / 4 - 5 * x**2 / 8 + 115 / 192,
+                            np.where(x < 1.5, (-16 * x**4 + 80 * x**3 - 120 * x**2 + 20 * x + 55) / 96,
+                                     np.where(x < 2.5, (2.5 - x) ** 4 / 24, 0.0)))
+        return np.where(x < 1, (-10 * x**5 + 30 * x**4 - 60 * x**2 + 66) / 120,
+                        np.where(x < 2, (5 * x**5 - 45 * x**4 + 150 * x**3 - 210 * x**2 + 75 * x + 51) / 120,
+                                 np.where(x < 3, (3 - x) ** 5 / 120, 0.0)))
+
+    def _spline(self, fi, az, za):
+        """Orders 0 and 2 .. 5 (and 3): coefficients by scipy's spline_filter1d (za "mirror", az "grid-wrap"), then the
+        order + 1 nodes around each point -- from floor(x) - n // 2 (odd n) or floor(x + 1/2) - n // 2 (even n), as
+        scipy.ndimage.map_coordinates places them -- weighted by the centred B-spline."""
         from scipy.ndimage import spline_filter1d
 
+        n = self.order
         if self._coef is None:
             self._coef = {}
         if fi not in self._coef:
             t = self.data[fi]
-            parts = []
-            for comp in ((t.real, t.imag) if np.iscomplexobj(t) else (t,)):
-                c = spline_filter1d(np.asarray(comp, float), order=3, axis=-2, mode="mirror")
-                parts.append(spline_filter1d(c, order=3, axis=-1, mode="grid-wrap"))
-            self._coef[fi] = parts[0] + 1j * parts[1] if len(parts) == 2 else parts[0]
+            if n < 2:
+                self._coef[fi] = t
+            else:
+                parts = []
+                for comp in ((t.real, t.imag) if np.iscomplexobj(t) else (t,)):
+                    c = spline_filter1d(np.asarray(comp, float), order=n, axis=-2, mode="mirror")
+                    parts.append(spline_filter1d(c, order=n, axis=-1, mode="grid-wrap"))
+                self._coef[fi] = parts[0] + 1j * parts[1] if len(parts) == 2 else parts[0]
         coef = self._coef[fi]
-
-        def bw(t):
-            return [(1 - t) ** 3 / 6, (4 - 6 * t**2 + 3 * t**3) / 6,
-                    (1 + 3 * t + 3 * t**2 - 3 * t**3) / 6, t**3 / 6]
-
         fa = np.mod(az, 2 * np.pi) / (2 * np.pi / self.naz)
-        ia = np.floor(fa).astype(int)
-        wa = bw(fa - ia)
         fz = np.clip(za / (self.za_max / (self.nza - 1)), 0, self.nza - 1)
-        iz = np.minimum(np.floor(fz).astype(int), self.nza - 2)
-        wz = bw(fz - iz)
+        if n & 1:
+            ia = np.floor(fa).astype(int) - n // 2
+            iz = np.minimum(np.floor(fz).astype(int), self.nza - 2) - n // 2
+        else:
+            ia = np.floor(fa + 0.5).astype(int) - n // 2
+            iz = np.floor(fz + 0.5).astype(int) - n // 2
         per = 2 * (self.nza - 1)
         v = 0
-        for k in range(4):
-            jz = np.mod(iz - 1 + k, per)
+        for k in range(n + 1):
+            jz = np.mod(iz + k, per)
             jz = np.where(jz < self.nza, jz, per - jz)
-            for l in range(4):
-                v = v + coef[..., jz, np.mod(ia - 1 + l, self.naz)] * (wz[k] * wa[l])
+            wz = self._basis(n, fz - (iz + k))
+            for l in range(n + 1):
+                v = v + coef[..., jz, np.mod(ia + l, self.naz)] * (wz * self._basis(n, fa - (ia + l)))
         return v
 
     def _weights(self, az, za):
@@ -486,8 +512,8 @@ class TabulatedBeam:
     def compute_response(self, az_array, za_array, freq_array, **_):
         f = float(np.atleast_1d(freq_array)[0])
         fi = int(np.argmin(np.abs(self.freqs - f)))
-        if self.order == 3:
-            v = self._cubic(fi, np.asarray(az_array, float), np.asarray(za_array, float))
+        if self.order != 1:
+            v = self._spline(fi, np.asarray(az_array, float), np.asarray(za_array, float))
         else:
             ia0, ia1, wa, iz0, iz1, wz = self._weights(
                 np.asarray(az_array, float), np.asarray(za_array, float)

@@ -298,8 +298,8 @@ def test_evaluate_beam(gpu):
             got = ev.evaluate_beam(tab, az, za, pol, freqs[fi], freq_index=fi)
             exp = orc.evaluate_beam(oracle_beam(tab, pol, freqs), az, za, pol, freqs[fi])
             np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-14)
-    with pytest.raises(NotImplementedError):
-        ev.evaluate_beam(tab, az, za, True, freqs[0], spline_opts={"order": 2})
+    with pytest.raises(ValueError, match="spline order not supported"):
+        ev.evaluate_beam(tab, az, za, True, freqs[0], spline_opts={"order": 6})
 
 
 def test_evaluate_beam_order3(gpu):
@@ -747,8 +747,8 @@ def test_sim_empty_sky_and_errors(gpu):
     assert v.shape == (8, 2, 21) and not v.any()  # cpu_simulate.py:945-946
     with pytest.raises(ValueError, match="requires sky_model to be 2D"):
         fftvis_amd.simulate_vis(**dict(cfg, fluxes=np.ones((20, 8, 4))))
-    with pytest.raises(NotImplementedError):
-        fftvis_amd.simulate_vis(**dict(cfg, beam_spline_opts={"order": 2}))
+    with pytest.raises(ValueError, match="spline order not supported"):
+        fftvis_amd.simulate_vis(**dict(cfg, beam_spline_opts={"order": 6}))
 
 
 def test_sim_type1_lattice_path(gpu):

@@ -11,7 +11,7 @@ import pytest
 import fftvis_amd
 from fftvis_amd import synth
 from oracle import fftvis_oracle as orc
-from tests.helpers import oracle_simulate, rel_l2
+from tests.helpers import oracle_beam, oracle_simulate, rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL = 5 * 6e-8
@@ -366,3 +366,41 @@ def test_fuzz_heights_from_millimetres_to_metres(gpu, monkeypatch):
         assert err < 10 * eps + 1e-12, (it, err, eps, zs, st["height_terms"], pol, nbeam)
     gpu_simulate.release_handles()
     assert kinds == {"K", "3-D", "2-D"} or kinds == {"K", "3-D"}, kinds
+
+
+@pytest.mark.parametrize("order", [0, 2, 4, 5])
+def test_beam_spline_orders_other_than_1_and_3(gpu, order):
+    """beam_spline_opts {"order": n} for the other orders scipy.ndimage.map_coordinates takes (the reference hands the
+    option to pyuvdata's az_za_map_coordinates, cpu/beams.py:69-74): the device's general path -- prefilter with
+    that order's poles, n + 1 nodes per axis weighted by the cardinal B-spline -- against the oracle (scipy's own
+    spline_filter1d + the closed piecewise polynomials), stand-alone and through a polarized simulation on both
+    engine paths."""
+    freqs = np.linspace(100e6, 120e6, 4)
+    tab = fftvis_amd.TabulatedBeam(synth.synthetic_efield_table(freqs, nza=46, naz=90), freqs)
+    rng = np.random.default_rng(order)
+    az, za = rng.uniform(0, 2 * np.pi, 3000), rng.uniform(0, np.pi / 2, 3000)
+    za[:3] = [0.0, np.pi / 2, 1e-12]
+    az[:3] = [0.0, 2 * np.pi - 1e-12, np.pi]
+    from fftvis_amd.gpu import GPUBeamEvaluator
+
+    ev = GPUBeamEvaluator()
+    opts = {"order": order}
+    for pol in (False, True):
+        for fi in (0, 3):
+            got = ev.evaluate_beam(tab, az, za, pol, freqs[fi], freq_index=fi, spline_opts=opts)
+            exp = orc.evaluate_beam(oracle_beam(tab, pol, freqs, order), az, za, pol, freqs[fi])
+            if order == 0:  # nearest node: a point within rounding of a cell edge may take either neighbour
+                frac = np.minimum(np.abs(np.mod(az / (2 * np.pi / 90), 1) - 0.5), np.abs(np.mod(za / (np.pi / 45), 1) - 0.5))
+                keep = frac > 1e-9
+                got, exp = got[..., keep], exp[..., keep]
+            np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+    cfg = synth.make_config("C1", nsrc=300, nfreq=4, ntimes=2)
+    cfg = dict(cfg, freqs=freqs, fluxes=cfg["fluxes"][:, :4], beam=tab, polarized=True, eps=1e-10, beam_spline_opts=opts)
+    for path in (True, False):
+        c = dict(cfg, force_use_type3=path)
+        got = fftvis_amd.simulate_vis(**c)
+        exp = oracle_simulate(c)
+        assert rel_l2(got, exp) < 2e-9, (order, path, rel_l2(got, exp))
+    if order in (2, 5):  # and it IS a different interpolant from its neighbours
+        other = fftvis_amd.simulate_vis(**dict(cfg, beam_spline_opts={"order": 3}))
+        assert rel_l2(other, exp) > 1e-7

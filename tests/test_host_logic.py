@@ -231,8 +231,10 @@ def test_spline_opts_orders():
     assert checked_spline_order(None) == 1 and checked_spline_order({"order": 3}) == 3
     cfg = synth.make_config("C1", nsrc=5, nfreq=2, ntimes=1)
     eng = GPUSimulationEngine()
-    for opts in ({"kx": 2, "ky": 2}, {"order": 5}, {"order": 0}):
-        with pytest.raises(NotImplementedError, match="spline orders 1 and 3"):
+    assert [checked_spline_order({"order": n}) for n in range(6)] == list(range(6))
+    assert checked_spline_order({"kx": 2, "ky": 2}) == 2
+    for opts in ({"kx": 6, "ky": 6}, {"order": 7}, {"order": -1}):
+        with pytest.raises(ValueError, match="spline order not supported"):
             eng.simulate(ants=cfg["ants"], freqs=cfg["freqs"], fluxes=cfg["fluxes"], beam_list=[cfg["beam"]],
                          ra=cfg["ra"], dec=cfg["dec"], times=cfg["times"], telescope_loc=cfg["telescope_loc"],
                          beam_spline_opts=opts, coord_method="SiderealRotation")

@@ -270,3 +270,30 @@ def test_astrometry_restatement_against_erfa_where_it_is_installed():
         got = oa.icrs_to_enu(p, ctx)
         up = want[2] > 0.1  # above the refraction formula's low-elevation guard
         assert np.abs(got[:, up] - want[:, up]).max() < 1e-9, phpa
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4, 5])
+def test_tabulated_beam_orders_against_scipy_map_coordinates(order):
+    """The oracle's table interpolant (and the product's host twin of the device interpolant) for every order
+    scipy.ndimage.map_coordinates takes -- what pyuvdata's az_za_map_coordinates runs for the reference
+    (cpu/beams.py:69-74).  scipy has one boundary mode for all axes, the table needs two (az periodic, za mirrored):
+    the table extended by its own mirror image in za is periodic in BOTH, so ``mode="grid-wrap"`` on it is exactly
+    the same interpolant."""
+    from scipy.ndimage import map_coordinates
+
+    from fftvis_amd.core.beams import _interp_table
+
+    rng = np.random.default_rng(3)
+    nza, naz = 37, 48
+    tab = rng.normal(size=(nza, naz)) + 1j * rng.normal(size=(nza, naz))
+    ext = np.concatenate([tab, tab[-2:0:-1]], axis=0)  # period 2 (nza - 1) in za
+    az, za = rng.uniform(-1, 8, 500), rng.uniform(0, np.pi, 500)
+    za[:5] = [0, np.pi, 1e-9, np.pi - 1e-9, np.pi / 2]
+    az[5:8] = [0.0, 2 * np.pi, 2 * np.pi / naz * 7]
+    fa, fz = np.mod(az, 2 * np.pi) / (2 * np.pi / naz), za / (np.pi / (nza - 1))
+    ref = (map_coordinates(ext.real, [fz, fa], order=order, mode="grid-wrap")
+           + 1j * map_coordinates(ext.imag, [fz, fa], order=order, mode="grid-wrap"))
+    beam = orc.TabulatedBeam(tab[None], [1e8], np.pi, "power", order)
+    got = beam.compute_response(az_array=az, za_array=za, freq_array=np.array([1e8]))[0, 0, 0]
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(_interp_table(tab, np.pi, az, za, order), ref, rtol=0, atol=1e-12)

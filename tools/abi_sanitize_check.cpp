@@ -78,7 +78,7 @@ int main() {
                             out.data()) == FV_ERR_ARG);
     EXPECT(fv_beam_eval(0, 2, 1, 2, 14.0, 0, 0, 0, 0.0, nullptr, 1, 0, 1.5e8, 4, x.data(), x.data(), out.data()) ==
            FV_ERR_ARG);
-    EXPECT(fv_beam_eval(0, 2, 1, 0, 14.0, 0, 0, 0, 0.0, nullptr, 2, 0, 1.5e8, 4, x.data(), x.data(), out.data()) ==
+    EXPECT(fv_beam_eval(0, 2, 1, 0, 14.0, 0, 0, 0, 0.0, nullptr, 6, 0, 1.5e8, 4, x.data(), x.data(), out.data()) ==
            FV_ERR_ARG);
     EXPECT(fv_apparent_coherency(0, 2, 7, 4, c.data(), c.data(), x.data(), out.data()) == FV_ERR_ARG);
     EXPECT(fv_apparent_coherency(0, 5, 0, 4, c.data(), c.data(), x.data(), out.data()) == FV_ERR_ARG);
