@@ -2983,6 +2983,16 @@ class Nufft3 {
         // 3-D transforms carry a larger error constant (seeded fuzzing: 12 eps on band-edge baselines of a
         // non-coplanar array at every eps, against <= 2 eps in 2-D): one more cell of kernel width there
         if (dim == 3 && !w_override && ker.w < (sigma == 2.0 ? MAX_W : 15)) ker = make_kernel(eps, sigma, ker.w + 1);
+        // fp32 at sigma = 1.25: beyond ten cells a wider kernel only amplifies rounding (the kernel's transform falls by
+        // ~e^{-w/2} per dimension across the band and fp32 has 7 digits to lose): measured rel. l2 against exact sums,
+        // eps asked 1e-4 / 2e-5 / 1e-6 / 6e-8 / 1e-9 -> 3.5e-6 / 3.1e-6 / 6.7e-6 / 4.6e-5 / 3.6e-4 (2-D; w = 8 .. 15) and
+        // 3.4e-6 / 6.7e-6 / 5.4e-5 / 5.7e-4 / 2.0e-3 (3-D) -- and 6e-8 is the fp32 DEFAULT tolerance.  sigma = 2 is flat at
+        // 2.8e-6 below eps = 1e-5 and needs no cap.  (finufft clamps eps to the type's epsilon, not the width.)
+        // Three dimensions lose e^{-w/2} three times: targets in the corners of the box sit at ~e^{-3w/2} of the centre --
+        // a non-coplanar array with 4.7 m of height range (fuzz seed 7000 / 346): w = 7 / 9 / 10 -> 2.4e-4 / 3.5e-4 /
+        // 1.8e-3; capped at 8 there (the sigma = 1.25 floor of fp32 in 3-D is the 1e-3 the automatic choice assumes).
+        const int w_cap32 = dim == 3 ? 8 : 10;
+        if (sizeof(T) == 4 && sigma != 2.0 && !w_override && ker.w > w_cap32) ker = make_kernel(eps, sigma, w_cap32);
         geo.dim = dim;
     }
 
