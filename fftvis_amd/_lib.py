@@ -63,6 +63,11 @@ SYMBOLS = {
     "fv_sim_set_chunking": (c_int, [c_void_p, c_int, c_double]),
     "fv_sim_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "fv_sim_run_into": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int]),
+    "fv_comm_unique_id": (c_int, [c_void_p]),
+    "fv_comm_init": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    "fv_comm_destroy": (c_int, [c_void_p]),
+    "fv_bcast_catalog": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64]),
+    "fv_scatter_flux_columns": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, POINTER(c_int), c_void_p]),
     "fv_sim_sync": (c_int, [c_void_p]),
     "fv_sim_stats": (c_int, [c_void_p, c_void_p, c_int]),
     "fv_sim_reset_stats": (c_int, [c_void_p]),
@@ -93,6 +98,36 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own ROCm runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7, and
+    libhsa-runtime64.so) and load it by path; libfftvis_hip.so asks for the soname and, loaded FIRST, gets the system's
+    /opt/rocm copy.  A later ``import torch`` then brings a second HIP runtime into the process, and the second one
+    sees no GPU ("No HIP GPUs are available"; RCCL: "unhandled cuda error").  Loading torch's copy first -- the file,
+    without importing torch -- makes either import order end with ONE runtime: ours binds to the loaded soname, torch's
+    later load of the same file is a no-op.  FFTVIS_HIP_NO_TORCH_RUNTIME=1 leaves it out."""
+    if os.environ.get("FFTVIS_HIP_NO_TORCH_RUNTIME"):
+        return
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # already in: its runtime is the loaded one
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return  # (a wheel whose runtime does not load by itself: leave the system's in charge)
+
+
 def lib() -> ctypes.CDLL:
     """Load the library (fails loudly if it has not been built)."""
     global _lib
@@ -102,6 +137,7 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950).  fftvis_amd has no CPU fallback."
             )
+        _preload_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol

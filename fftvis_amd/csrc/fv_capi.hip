@@ -592,6 +592,177 @@ int fv_sim_timing(fv_sim *h, double *ms, int n) { FV_SIM_CALL(h->impl->timing(ms
 
 }  // extern "C"
 
+// ---------------------------------------------------------------------------------------------------------------
+// Catalog exchange over RCCL for hosts without torch.distributed (SURVEY 8 b / 8 e: one broadcast of the catalog
+// from rank 0 at start, optionally only the frequency columns a rank's block needs; there is no other collective on
+// the path -- every rank copies its own block of visibilities out).  librccl is opened on first use: the library
+// loads, and everything else in it works, on a box without RCCL.
+// ---------------------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace fv {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    static Rccl &get() {
+        static Rccl *r = [] {
+            Rccl *o = new Rccl();  // never destroyed (no static destructor may call into a runtime that is gone)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                o->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (o->lib) break;
+            }
+            if (!o->lib) return o;
+            auto sym = [&](const char *n) { return dlsym(o->lib, n); };
+            o->GetUniqueId = reinterpret_cast<decltype(o->GetUniqueId)>(sym("ncclGetUniqueId"));
+            o->CommInitRank = reinterpret_cast<decltype(o->CommInitRank)>(sym("ncclCommInitRank"));
+            o->CommDestroy = reinterpret_cast<decltype(o->CommDestroy)>(sym("ncclCommDestroy"));
+            o->Broadcast = reinterpret_cast<decltype(o->Broadcast)>(sym("ncclBroadcast"));
+            o->Send = reinterpret_cast<decltype(o->Send)>(sym("ncclSend"));
+            o->Recv = reinterpret_cast<decltype(o->Recv)>(sym("ncclRecv"));
+            o->GroupStart = reinterpret_cast<decltype(o->GroupStart)>(sym("ncclGroupStart"));
+            o->GroupEnd = reinterpret_cast<decltype(o->GroupEnd)>(sym("ncclGroupEnd"));
+            o->GetErrorString = reinterpret_cast<decltype(o->GetErrorString)>(sym("ncclGetErrorString"));
+            return o;
+        }();
+        if (!r->lib || !r->GetUniqueId || !r->CommInitRank || !r->CommDestroy || !r->Broadcast || !r->Send || !r->Recv ||
+            !r->GroupStart || !r->GroupEnd)
+            throw Error(FV_ERR_INTERNAL, "librccl.so.1 could not be opened (or lacks the nccl* entry points): no RCCL on this host");
+        return *r;
+    }
+    void check(ncclResult_t rc, const char *what) const {
+        if (rc == ncclSuccess) return;
+        throw Error(FV_ERR_INTERNAL, std::string(what) + ": " + (GetErrorString ? GetErrorString(rc) : "RCCL error") + " (" +
+                                         std::to_string((int)rc) + ")");
+    }
+};
+
+// flux (nsrc, nfreq) of elem_words 4-byte words per entry -> the columns [f0, f1) of every source, contiguous
+__global__ void k_pack_columns(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t nsrc, int nfreq,
+                               int elem_words, int f0, int f1) {
+    const int64_t row_words = (int64_t)(f1 - f0) * elem_words;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsrc * row_words) return;
+    const int64_t s = i / row_words, r = i % row_words;
+    dst[i] = src[(s * nfreq + f0) * elem_words + r];
+}
+}  // namespace fv
+
+struct fv_comm {
+    ncclComm_t comm = nullptr;
+    int device = 0, rank = 0, nranks = 1;
+    hipStream_t stream = nullptr;
+    fv::DevBuf staging;
+};
+
+extern "C" {
+
+int fv_comm_unique_id(void *id_bytes) {
+    return fv::guarded([&] {
+        FV_REQUIRE(id_bytes, "null id buffer");
+        static_assert(sizeof(ncclUniqueId) == FV_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+        ncclUniqueId id;
+        fv::Rccl &r = fv::Rccl::get();
+        r.check(r.GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(id_bytes, &id, sizeof(id));
+    });
+}
+
+int fv_comm_init(fv_comm **c, int device, int rank, int nranks, const void *id_bytes) {
+    return fv::guarded([&] {
+        FV_REQUIRE(c && id_bytes, "null argument");
+        FV_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "rank outside [0, nranks)");
+        *c = nullptr;
+        fv::Rccl &r = fv::Rccl::get();
+        FV_HIP(hipSetDevice(device));
+        std::unique_ptr<fv_comm> o(new fv_comm());
+        o->device = device;
+        o->rank = rank;
+        o->nranks = nranks;
+        ncclUniqueId id;
+        std::memcpy(&id, id_bytes, sizeof(id));
+        r.check(r.CommInitRank(&o->comm, nranks, id, rank), "ncclCommInitRank");
+        FV_HIP(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+        *c = o.release();
+    });
+}
+
+int fv_comm_destroy(fv_comm *c) {
+    return fv::guarded([&] {
+        if (!c) return;
+        (void)hipSetDevice(c->device);
+        if (c->stream) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamDestroy(c->stream);
+        }
+        if (c->comm) (void)fv::Rccl::get().CommDestroy(c->comm);
+        delete c;
+    });
+}
+
+int fv_bcast_catalog(fv_comm *c, int root, void *eq_dev, int64_t eq_bytes, void *flux_dev, int64_t flux_bytes) {
+    return fv::guarded([&] {
+        FV_REQUIRE(c && c->comm, "null communicator");
+        FV_REQUIRE(root >= 0 && root < c->nranks, "root outside [0, nranks)");
+        FV_REQUIRE(eq_bytes >= 0 && flux_bytes >= 0 && (eq_dev || !eq_bytes) && (flux_dev || !flux_bytes), "bad buffers");
+        fv::Rccl &r = fv::Rccl::get();
+        FV_HIP(hipSetDevice(c->device));
+        if (eq_bytes) r.check(r.Broadcast(eq_dev, eq_dev, (size_t)eq_bytes, ncclChar, root, c->comm, c->stream), "ncclBroadcast (positions)");
+        if (flux_bytes) r.check(r.Broadcast(flux_dev, flux_dev, (size_t)flux_bytes, ncclChar, root, c->comm, c->stream), "ncclBroadcast (flux)");
+        FV_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int fv_scatter_flux_columns(fv_comm *c, int root, int64_t nsrc, int nfreq, int elem_bytes, const void *flux_root_dev,
+                            const int *ranges, void *out_dev) {
+    return fv::guarded([&] {
+        FV_REQUIRE(c && c->comm, "null communicator");
+        FV_REQUIRE(root >= 0 && root < c->nranks, "root outside [0, nranks)");
+        FV_REQUIRE(nsrc >= 0 && nfreq >= 1 && elem_bytes >= 4 && elem_bytes % 4 == 0, "bad catalog shape");
+        FV_REQUIRE(ranges, "null column ranges");
+        for (int q = 0; q < c->nranks; ++q)
+            FV_REQUIRE(ranges[2 * q] >= 0 && ranges[2 * q] <= ranges[2 * q + 1] && ranges[2 * q + 1] <= nfreq, "column range outside [0, nfreq]");
+        const int64_t mine = (int64_t)(ranges[2 * c->rank + 1] - ranges[2 * c->rank]) * nsrc * elem_bytes;
+        FV_REQUIRE(out_dev || !mine, "null output");
+        FV_REQUIRE(c->rank != root || flux_root_dev || !nsrc, "the root holds the catalog");
+        fv::Rccl &r = fv::Rccl::get();
+        FV_HIP(hipSetDevice(c->device));
+        const int ew = elem_bytes / 4;
+        std::vector<int64_t> off(c->nranks + 1, 0);
+        if (c->rank == root) {  // pack every rank's columns (one contiguous piece each), then send them in one group
+            for (int q = 0; q < c->nranks; ++q) off[q + 1] = off[q] + (int64_t)(ranges[2 * q + 1] - ranges[2 * q]) * nsrc * elem_bytes;
+            c->staging.reserve(std::max<size_t>((size_t)off[c->nranks], 16));
+            for (int q = 0; q < c->nranks; ++q) {
+                const int64_t words = (off[q + 1] - off[q]) / 4;
+                if (!words) continue;
+                hipLaunchKernelGGL(fv::k_pack_columns, dim3((unsigned)fv::cdiv(words, 256)), dim3(256), 0, c->stream,
+                                   static_cast<const uint32_t *>(flux_root_dev),
+                                   reinterpret_cast<uint32_t *>(static_cast<char *>(c->staging.p) + off[q]), nsrc, nfreq, ew,
+                                   ranges[2 * q], ranges[2 * q + 1]);
+            }
+            FV_HIP(hipGetLastError());
+        }
+        r.check(r.GroupStart(), "ncclGroupStart");
+        if (c->rank == root)
+            for (int q = 0; q < c->nranks; ++q)
+                if (off[q + 1] > off[q])
+                    r.check(r.Send(static_cast<char *>(c->staging.p) + off[q], (size_t)(off[q + 1] - off[q]), ncclChar, q, c->comm, c->stream), "ncclSend");
+        if (mine) r.check(r.Recv(out_dev, (size_t)mine, ncclChar, root, c->comm, c->stream), "ncclRecv");
+        r.check(r.GroupEnd(), "ncclGroupEnd");
+        FV_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+}  // extern "C"
+
 #ifdef FV_FFT_STAMPS
 // diagnostic builds only (see fv_nufft.h): copies out up to max_waves records of 10 values and resets the counter
 extern "C" int fv_debug_stamps(unsigned long long *out, int max_waves) {

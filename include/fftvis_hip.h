@@ -262,6 +262,31 @@ int fv_sim_reset_stats(fv_sim *h);
 int fv_sim_enable_timing(fv_sim *h, int level);
 int fv_sim_timing(fv_sim *h, double *ms, int n);
 
+/* ---- catalog exchange over RCCL (optional; SURVEY 8 b "fv_comm_init / fv_bcast_catalog", 8 e) ---------------------
+ * For hosts that do not bring torch.distributed: the path's only exchange step is one broadcast of the catalog from the
+ * rank that read it (the reference ships it to its Ray workers as a whole, cpu_simulate.py:711-847 via core/utils.py:
+ * 122-187) -- positions to everyone, flux either whole (fv_bcast_catalog) or only the frequency columns of each rank's
+ * block (fv_scatter_flux_columns: one packed ncclSend per rank in one group; C3 on 8 ranks: 32 instead of 250 MB per
+ * rank).  Buffers are DEVICE pointers on the communicator's GPU; what arrives goes to fv_sim_set_sources(...,
+ * on_device = 1).  Visibilities are never exchanged: every rank copies its own block out (fv_sim_run / fv_sim_run_into).
+ * librccl.so.1 is opened on first use: without it these five entries fail with FV_ERR_INTERNAL and nothing else changes.
+ *   fv_comm_unique_id : rank 0 fills FV_COMM_ID_BYTES bytes (ncclGetUniqueId); the host carries them to the other ranks
+ *   fv_comm_init      : collective over the nranks processes (ncclCommInitRank), one process per GPU
+ *   fv_bcast_catalog  : eq (3, nsrc) and flux as fv_sim_set_sources lays them out, as bytes; in place on every rank
+ *   fv_scatter_flux_columns : flux_root_dev (nsrc, nfreq) entries of elem_bytes (8: float64, 4: float32, 64 / 32:
+ *       2 x 2 complex) on the root; ranges = nranks pairs [f0, f1); out_dev (nsrc, f1 - f0) of THIS rank
+ * Both transfers return after the data has arrived (the communicator's stream is synchronised).
+ * Verified on hardware with one rank only (a one-GPU box cannot host two RCCL ranks); the Python host's
+ * torch.distributed path (parallel.broadcast_catalog_device) is the one the multi-process tests cover.            */
+#define FV_COMM_ID_BYTES 128
+typedef struct fv_comm fv_comm;
+int fv_comm_unique_id(void *id_bytes);
+int fv_comm_init(fv_comm **c, int device, int rank, int nranks, const void *id_bytes);
+int fv_comm_destroy(fv_comm *c);
+int fv_bcast_catalog(fv_comm *c, int root, void *eq_dev, int64_t eq_bytes, void *flux_dev, int64_t flux_bytes);
+int fv_scatter_flux_columns(fv_comm *c, int root, int64_t nsrc, int nfreq, int elem_bytes, const void *flux_root_dev,
+                            const int *ranges, void *out_dev);
+
 #ifdef __cplusplus
 }
 #endif

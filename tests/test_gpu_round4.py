@@ -453,3 +453,75 @@ def test_fuzz_with_every_spline_order(gpu):
             err = rel_l2(fftvis_amd.simulate_vis(**cfg), oracle_simulate(cfg))
         lim = 10 * cfg["eps"] + (1e-12 if cfg.get("precision", 2) == 2 else 2e-6)
         assert err < lim, (it, err, cfg["eps"], cfg.get("beam_spline_opts"), cfg.get("precision", 2), cfg.get("upsample_factor"))
+
+
+def test_c_abi_catalog_exchange_over_rccl_one_rank(gpu):
+    """The optional RCCL entry points of the C ABI (SURVEY 8 b: fv_comm_init / fv_bcast_catalog; 8 e: only the
+    frequency columns a rank needs), as far as one GPU can exercise them: a communicator of ONE rank, the broadcast
+    in place, and the packed column transfer (root = the only rank: its send meets its own receive inside one group)
+    for real and for 2 x 2 complex flux entries -- the columns must arrive bit for bit.  More ranks need more GPUs:
+    the multi-process tests cover the torch.distributed twin (parallel.broadcast_catalog_device)."""
+    import ctypes
+
+    import torch
+
+    from fftvis_amd import _lib
+
+    L = _lib.lib()
+    ident = (ctypes.c_ubyte * 128)()
+    _lib.check(L.fv_comm_unique_id(ident))
+    assert any(ident)
+    comm = ctypes.c_void_p()
+    _lib.check(L.fv_comm_init(ctypes.byref(comm), 0, 0, 1, ident))
+    try:
+        g = torch.Generator(device="cpu").manual_seed(5)
+        nsrc, nfreq = 1000, 12
+        eq = torch.randn(3, nsrc, dtype=torch.float64, generator=g).cuda()
+        for shape, dtype in (((nsrc, nfreq), torch.float64), ((nsrc, nfreq), torch.float32), ((nsrc, nfreq, 2, 2), torch.complex128)):
+            flux = torch.randn(*shape, dtype=torch.float64, generator=g).to(dtype).cuda()
+            if dtype == torch.complex128:
+                flux = flux + 1j * torch.randn(*shape, dtype=torch.float64, generator=g).cuda()
+            keep_eq, keep_flux = eq.clone(), flux.clone()
+            _lib.check(L.fv_bcast_catalog(comm, 0, eq.data_ptr(), eq.numel() * eq.element_size(), flux.data_ptr(),
+                                          flux.numel() * flux.element_size()))
+            assert torch.equal(eq, keep_eq) and torch.equal(flux, keep_flux)
+            f0, f1 = 3, 9
+            out = torch.zeros((nsrc, f1 - f0) + tuple(shape[2:]), dtype=dtype, device="cuda")
+            ranges = (ctypes.c_int * 2)(f0, f1)
+            elem = flux.element_size() * (4 if len(shape) == 4 else 1)
+            _lib.check(L.fv_scatter_flux_columns(comm, 0, nsrc, nfreq, elem, flux.data_ptr(), ranges, out.data_ptr()))
+            assert torch.equal(out, flux[:, f0:f1])
+        # arguments are checked before anything is sent
+        bad = (ctypes.c_int * 2)(5, 20)
+        assert L.fv_scatter_flux_columns(comm, 0, nsrc, nfreq, 8, eq.data_ptr(), bad, eq.data_ptr()) == 1  # FV_ERR_ARG
+        assert L.fv_bcast_catalog(comm, 3, eq.data_ptr(), 8, None, 0) == 1
+    finally:
+        _lib.check(L.fv_comm_destroy(comm))
+
+
+def test_either_import_order_leaves_one_hip_runtime(gpu):
+    """The library first, PyTorch afterwards (a host that only later reaches for torch.distributed): PyTorch-ROCm wheels
+    bring their own HIP runtime, and two of them in one process leave the second without a GPU.  ``_lib.lib()`` loads
+    the wheel's copy before the library, so that both bind to one runtime whichever comes first."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from fftvis_amd import _lib\n"
+        "assert 'torch' not in sys.modules\n"
+        "assert _lib.device_count() >= 1\n"
+        "from fftvis_amd.gpu import gpu_nufft2d\n"
+        "x = np.linspace(-1, 1, 50); c = np.ones(50, complex)\n"
+        "v = gpu_nufft2d(x, x, c, np.array([0.0, 1.0]), np.array([0.0, 2.0]), 1e-9)\n"
+        "assert abs(v.ravel()[0] - 50) < 1e-6\n"
+        "import torch\n"
+        "assert torch.cuda.is_available(), 'a second HIP runtime came in with torch'\n"
+        "assert float(torch.ones(4, device='cuda').sum()) == 4.0\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "libs = {l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}\n"
+        "assert len(libs) == 1, libs\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

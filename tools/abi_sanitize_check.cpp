@@ -84,6 +84,18 @@ int main() {
     EXPECT(fv_apparent_coherency(0, 5, 0, 4, c.data(), c.data(), x.data(), out.data()) == FV_ERR_ARG);
     EXPECT(fv_inplace_rot(0, 2, nullptr, x.data(), 2) == FV_ERR_ARG);
     EXPECT(fv_inplace_rot(0, 9, d9, x.data(), 2) == FV_ERR_ARG);
+    // catalog exchange: argument checks come before RCCL is opened
+    {
+        fv_comm *cm = reinterpret_cast<fv_comm *>(0x1);
+        unsigned char id[FV_COMM_ID_BYTES] = {0};
+        EXPECT(fv_comm_unique_id(nullptr) == FV_ERR_ARG);
+        EXPECT(fv_comm_init(nullptr, 0, 0, 1, id) == FV_ERR_ARG);
+        EXPECT(fv_comm_init(&cm, 0, 0, 1, nullptr) == FV_ERR_ARG);
+        EXPECT(fv_comm_init(&cm, 0, 2, 2, id) == FV_ERR_ARG);
+        EXPECT(fv_comm_destroy(nullptr) == FV_OK);
+        EXPECT(fv_bcast_catalog(nullptr, 0, v, 8, v, 8) == FV_ERR_ARG);
+        EXPECT(fv_scatter_flux_columns(nullptr, 0, 1, 1, 8, v, i2, v) == FV_ERR_ARG);
+    }
     EXPECT(fv_release_workspaces() == FV_OK);
     // a call that gets past the argument checks reports the missing device as a HIP error, not a crash
     if (ndev == 0) {
