@@ -2415,13 +2415,28 @@ struct InterpArgs {
     double zd_h, zd_btc, zd_xc;
 };
 
-// exp(i zc zq) (i zh zq)^k / k!
+// Bessel function of the first kind and integer order k >= 0 by its power series, (x / 2)^k / k! sum_m (-x^2 / 4)^m /
+// (m! (k + 1)_m): the arguments here are the height phases of a nearly flat array (|x| below ~4 while the expansion is
+// taken at all), where the series loses at most a digit to cancellation and needs a dozen terms.
+__device__ inline double bessel_j_series(int k, double x) {
+    double lead = 1.0;
+    for (int i = 1; i <= k; ++i) lead *= 0.5 * x / (double)i;
+    const double q = -0.25 * x * x;
+    double term = 1.0, sum = 1.0;
+    for (int m = 1; m < 60; ++m) {
+        term *= q / ((double)m * (double)(m + k));
+        sum += term;
+        if (fabs(term) < 1e-17 * fabs(sum)) break;
+    }
+    return lead * sum;
+}
+
+// exp(i zc zq) c_k(zh zq),  c_0 = J_0, c_k = 2 i^k J_k: the Chebyshev (Jacobi - Anger) coefficients of
+// exp(i a t) = J_0(a) + 2 sum_k i^k J_k(a) T_k(t) on t in [-1, 1]
 __device__ inline cplx<double> wterm_factor(int k, double zc, double zh, double zq) {
     double sn, cs;
     sincos(zc * zq, &sn, &cs);
-    double mag = 1.0;
-    const double a = zh * zq;
-    for (int i = 1; i <= k; ++i) mag *= a / (double)i;
+    const double mag = (k ? 2.0 : 1.0) * bessel_j_series(k, zh * zq);
     const cplx<double> e = {cs * mag, sn * mag};
     switch (k & 3) {  // times i^k
         case 0: return e;

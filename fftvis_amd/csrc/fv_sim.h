@@ -699,9 +699,14 @@ __global__ void k_strengths(StrengthArgs a, const int *__restrict__ Mp, const in
     cplx<T> *dst = cs + (p * a.nfg + fgi) * tp;
     strength_eval<T, ORD>(a, perm[p], fidx, pre, src_idx, az, za, flux, freqs, dst);
     if (a.wt_k > 0) {  // uniform
+        // T_k(t), t = (z - zc) / zh in [-1, 1]: the Chebyshev polynomial of term k (three-term recurrence)
         const double t = ((double)zsrc[perm[p]] - a.wt_zc) * a.wt_inv;
-        double sc = t;
-        for (int i = 1; i < a.wt_k; ++i) sc *= t;
+        double sc = t, prev = 1.0;
+        for (int i = 1; i < a.wt_k; ++i) {
+            const double nx = 2.0 * t * sc - prev;
+            prev = sc;
+            sc = nx;
+        }
         for (int r = 0; r < tp; ++r) dst[r] = {(T)((double)dst[r].re * sc), (T)((double)dst[r].im * sc)};
     }
 }
@@ -1341,13 +1346,15 @@ class Sim : public SimBase {
     int dim() const { return coplanar ? 2 : 3; }
     // Height terms ("w-term expansion", run()): a non-coplanar array whose heights are small against the wavelength --
     // every surveyed real array: centimetres to decimetres after the plane fit -- does not need a third grid dimension.
-    // exp(i z s_z), z the sources' height coordinate in [zc - zh, zc + zh], s_z = nu b_z, is expanded about zc:
-    //     V(s) = sum_k  exp(i zc s_z) (i zh s_z)^k / k!  F_k(s_x, s_y),   F_k = 2-D transform of c_j ((z_j - zc) / zh)^k,
-    // K terms with (zh |s_z|)^K / K! <= eps / 10: K 2-D transforms (8 for 3 cm of scatter at 200 MHz) with all of the 2-D
+    // exp(i z s_z), z the sources' height coordinate in [zc - zh, zc + zh], s_z = nu b_z, is expanded in Chebyshev
+    // polynomials of t = (z - zc) / zh (Jacobi - Anger: exp(i a t) = J_0(a) + 2 sum_k i^k J_k(a) T_k(t)):
+    //     V(s) = sum_k  exp(i zc s_z) c_k(zh s_z)  F_k(s_x, s_y),   c_0 = J_0, c_k = 2 i^k J_k,   F_k = 2-D transform of c_j T_k(t_j),
+    // K terms with 2 (a / 2)^K / K! <= eps / 10, a = zh max|s_z| (|J_k(a)| <= (a / 2)^k / k!): K 2-D transforms (7 for 3 cm of
+    // scatter at 200 MHz; the Taylor series about zc this replaced needed a^K / K! <= eps / 10: 8) with all of the 2-D
     // machinery (Hermitian packing, column plan, source disc) instead of a 3-D grid whose third dimension is all kernel
     // width (16 planes for a source range of 1.4 cells) plus a z-pass.  The terms carry the transform's relative error
-    // each, summed with weights a^k / k!: the 2-D plans run at eps / e^a.  Taken while K <= 16 (|b_z| up to metres);
-    // beyond, or with FFTVIS_HIP_NO_WTERM=1, the 3-D transform runs.
+    // each, |T_k| <= 1, summed with weights |c_k| (sum <= 2 e^{a/2} - 1): the 2-D plans run at eps / (2 e^{a/2} - 1).
+    // Taken while K <= 16 (|b_z| up to metres); beyond, or with FFTVIS_HIP_NO_WTERM=1, the 3-D transform runs.
     int wt_K = 0;   // terms of the current run (0: no expansion)
     double wt_zc = 0.0, wt_zh = 0.0, wt_a = 0.0;
     int run_D = 2;  // dimensions of the current run's transforms
@@ -2487,10 +2494,10 @@ class Sim : public SimBase {
                 if (p.n) bz = std::max(bz, p.Bs[2]);
             const double a = X[2] * fmax * bz;  // largest |(z - zc) s_z|
             int K = 1;
-            double term = a;  // a^K / K!
+            double term = a;  // 2 (a / 2)^K / K!: bound of the first neglected coefficient 2 |J_K|
             while (term > 0.1 * eps && K < 64) {
                 ++K;
-                term *= a / K;
+                term *= 0.5 * a / K;
             }
             const char *ek = std::getenv("FFTVIS_HIP_WTERM_MAX");
             if (K <= (ek ? std::atoi(ek) : 16)) {
@@ -2719,7 +2726,7 @@ class Sim : public SimBase {
             Lane &L = lanes[li];
             // height terms: term k enters with weight a^k / k!, each with the transform's relative error -- the plans run
             // at eps / e^a so that the sum keeps eps
-            const double eps_plan = wt_K ? std::max(eps * std::exp(-wt_a), sizeof(T) == 8 ? 1e-14 : 1e-7) : eps;
+            const double eps_plan = wt_K ? std::max(eps / (2.0 * std::exp(0.5 * wt_a) - 1.0), sizeof(T) == 8 ? 1e-14 : 1e-7) : eps;
             if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma || L.nufft->eps != eps_plan)
                 L.nufft.reset(new Nufft3<T>(D, eps_plan, sigma, li < 2 || !pipe ? L.stream : stream));
             L.nufft->err_oob = d_err.as<int>();
