@@ -391,7 +391,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # FFTVIS_BENCH_FORCE_DIST=1: take the N > 1 code path with ONE rank -- RCCL itself, its process group, barriers,
+    # object collectives and the sharded host-to-host calls as an 8-GPU node will run them, as far as one GPU can
+    force_dist = world == 1 and os.environ.get("FFTVIS_BENCH_FORCE_DIST") == "1" and a.as_rank is None
+    if force_dist:
+        import socket
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         if backend == "nccl":
@@ -538,7 +552,7 @@ def main():
         # the file still describes THIS run: same kernel family, same launches per time step, bytes that can belong
         # to the launches timed here.  A file that no longer matches fails the run instead of going quietly to null.
         traffic, traffic_src = None, None
-        default_shape = not (a.nsrc or a.nfreq or a.ntimes) and a.upsample == 2.0 and world == 1 and a.path == "type3" \
+        default_shape = not (a.nsrc or a.nfreq or a.ntimes) and a.upsample == 2.0 and dist is None and a.path == "type3" \
             and "FFTVIS_HIP_NO_HERMITIAN" not in os.environ and a.as_rank is None and a.array is None and a.z_scatter == 0
         pmf = pmc_file()
         if a.workload in ("C2", "C3") and default_shape and pmf and not os.environ.get("FFTVIS_BENCH_NO_PMC_CHECK"):
@@ -689,7 +703,7 @@ def main():
                                              "traffic": traffic,
                                              "what": "one extra step on ONE stream with event records around every launch (the step "
                                                      "`kernels`, `roofline_fft` and `roofline_interp` come from)"}
-        if not a.no_e2e and world == 1 and a.as_rank is None:
+        if not a.no_e2e and dist is None and a.as_rank is None:
             # ---- host to host: what a caller of simulate_vis() waits for (never `value`) -----------------
             # numpy in, numpy out (reference wrapper.py:85-336 -> cpu_simulate.py:843-854 returns a host array):
             # catalog / beam / baseline upload, per-geometry tables, the step itself, and the visibilities' way
@@ -743,7 +757,7 @@ def main():
             c2 = mini_run(synth.make_config("C2"), local_rank, steps=50, warmup=20, settle_s=0.04)
             res["c2_ms_per_step"] = c2["ms_per_step"]
             res["c2"] = c2
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and dist is None:
             res["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
     # ---- N > 1, host to host: what a caller of the sharded simulate_vis waits for (never `value`) -----------------
     # every rank: catalog broadcast from rank 0 into device memory, its block through the engine, delivered straight

@@ -685,3 +685,26 @@ def test_paired_residue_jobs_leave_the_result_unchanged(gpu, tmp_path):
         res[mode] = np.load(out)
         assert rel_l2(res[mode], exact) < 5e-9, mode
     assert rel_l2(res["1"], res["0"]) < 1e-13 and rel_l2(res["2"], res["0"]) < 1e-13
+
+
+@pytest.mark.gpu
+def test_bench_takes_the_rccl_code_path_with_one_rank(gpu):
+    """What the driver's N > 1 runs do that no one-GPU box can: RCCL.  `FFTVIS_BENCH_FORCE_DIST=1` sends ONE rank down
+    the N > 1 code path with the real backend ("nccl" = RCCL): process group on the device, catalog broadcast into device
+    memory, barriers, MAX-reduce and object collectives of the timing, and the sharded host-to-host calls
+    (`e2e_sharded`: per-rank flux columns, shared-memory result) -- everything but a second rank."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, FFTVIS_BENCH_FORCE_DIST="1", FFTVIS_BENCH_NO_PMC_CHECK="1")
+    env.pop("FFTVIS_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--nsrc", "3000", "--nfreq", "8",
+                        "--ntimes", "2", "--steps", "1", "--warmup", "1", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["finite_output"]
+    e = line["e2e_sharded"]
+    assert "error" not in e and e["finite_output"] and e["second_call_s"] > 0, e
+    assert "cpu_baseline" in line
