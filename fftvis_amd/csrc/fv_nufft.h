@@ -1394,6 +1394,9 @@ __device__ unsigned int fv_stamp_count;
 #ifndef FV_ST_TW2_LDS
 #define FV_ST_TW2_LDS 1  // pass-2 twiddles from a small LDS table (k_rowfft_st, TW2)
 #endif
+#ifndef FV_ST_MAP2
+#define FV_ST_MAP2 1  // pass-2 items assigned so that 16 contiguous lanes use 16 bank classes (k_rowfft_st, MAP2)
+#endif
 #ifndef FV_ST_CX32
 #define FV_ST_CX32 0  // fp32: whole complex values through the LDS exchange (k_rowfft_st, CX): measured slower, see there
 #endif
@@ -1666,13 +1669,32 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     // filled from the global table at the start: the chain of R2 - 2 complex products per pass-2 item that formed the
     // powers in registers -- 56 of a thread's ~930 fp64 instructions per job at Q = 2048 -- becomes R2 - 1 reads.
     constexpr bool TW2 = FV_ST_TW2_LDS != 0;
-    __shared__ __attribute__((aligned(16))) cplx<T> s_tw2[TW2 ? R3 * R2 : 1];
+    // (rows of R2 + 1 entries: the lanes of one LDS lane group read entry k of two or more different rows j3, and rows
+    // R2 entries apart -- 256 B for fp64 -- sit on the same banks)
+    constexpr int TW2S = R2 + 1;
+    __shared__ __attribute__((aligned(16))) cplx<T> s_tw2[TW2 ? R3 * TW2S : 1];
+    // Which pass-2 item (k1, j3) a thread takes is free (an item reads and rewrites its own R2 slots); the exchange slots
+    // k1 A + j3 + n B of the items of 16 CONTIGUOUS lanes must fall into 16 different 8-byte slot classes mod 128 B --
+    // that is how ds_read2_b64 / ds_write2_b64, which the compiler makes of the n-loops, are banked (4 groups of 16 lanes,
+    // 32 banks) -- and the strides were searched for ds_read_b64's rule (2 x 32 lanes, 64 banks): with the natural
+    // assignment k1 = v mod R1, j3 = v / R1 and A = 2 (mod 16) the 16 lanes hit 8 classes twice (PMC: 43 % of the row
+    // passes' LDS cycles were bank-conflict cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  Row mode, R1 = 16: lane bits
+    // (a = v mod 8, b = bit 3, c = v / 16) -> k1 = a + 8 (c mod 2), j3 = b + 2 (c / 2): classes 2 a + b (+ const).
+    constexpr bool MAP2 = FV_ST_MAP2 && !COL && R1 == 16 && (A % 16) == 2 && sizeof(ST) == 8;
+    auto item2 = [](int v) -> int {
+        if constexpr (MAP2) {
+            const int c = v >> 4;
+            return ((v & 7) | ((c & 1) << 3)) + R1 * (((v >> 3) & 1) | ((c >> 1) << 1));
+        } else {
+            return v;
+        }
+    };
 
     const int tid = threadIdx.x;
     const int vb = blockIdx.x;
     if constexpr (TW2) {
         // (before the early exits: every thread that stays reads the table after at least one workgroup barrier)
-        for (int e = tid; e < R3 * R2; e += THREADS) s_tw2[e] = tw[mul24(mul24(e / R2, e % R2), a.P * R1)];
+        for (int e = tid; e < R3 * R2; e += THREADS) s_tw2[(e / R2) * TW2S + e % R2] = tw[mul24(mul24(e / R2, e % R2), a.P * R1)];
         if constexpr (WAVE) __syncthreads();  // rows of one wave synchronise by wave barriers only
     }
     // line = the data row / column of this thread inside the workgroup, g = its residue group (PAIR), r = its exchange row
@@ -2077,7 +2099,7 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     int base2[NI2], base3[NI3];
 #pragma unroll
     for (int i = 0; i < NI2; ++i) {
-        const int v = u + i * TPR;
+        const int v = item2(u + i * TPR);
         base2[i] = (v % R1) * A + (v / R1);
     }
 #pragma unroll
@@ -2126,11 +2148,11 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     FV_STAMP(3);  // exchange 1 done
 #pragma unroll
     for (int i = 0; i < NI2; ++i) {
-        const int j3 = (u + i * TPR) / R1;
+        const int j3 = item2(u + i * TPR) / R1;
         dif_regs<T, R2>(vb2[i]);
         if constexpr (TW2) {
 #pragma unroll
-            for (int k = 1; k < R2; ++k) vb2[i][bitrev_small(k, L2)] = xmul(vb2[i][bitrev_small(k, L2)], s_tw2[j3 * R2 + k]);
+            for (int k = 1; k < R2; ++k) vb2[i][bitrev_small(k, L2)] = xmul(vb2[i][bitrev_small(k, L2)], s_tw2[j3 * TW2S + k]);
         } else {
             st_twiddle<T, R2>(vb2[i], tw[mul24(j3, a.P * R1)]);  // w_{Q/R1}^{j3 k2}
         }
