@@ -1300,9 +1300,12 @@ class Sim : public SimBase {
         hipEvent_t prep_done = nullptr, heavy_done = nullptr;  // pipelined mode (see run())
         bool heavy_pending = false;
         std::unique_ptr<Nufft3<T>> nufft;
+        std::unique_ptr<Nufft3<T>> nufft_l;  // the plan of the LIGHT height terms (see Sim::wt_k0): looser tolerance, sigma = 1.25
         DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scan_tot, d_scan_off, d_enu;
         int binned_ti = -1;
         int64_t binned_serial = -1;
+        int binned_ti_l = -1;  // the same for nufft_l
+        int64_t binned_serial_l = -1;
     };
     Lane lanes[4];  // [2], [3]: second pair of the gang mode (see run())
     int lane_mode = -1;       // 0 one stream per lane, 1 pipelined, 2 pipelined gangs: what the lanes last ran as
@@ -1357,6 +1360,13 @@ class Sim : public SimBase {
     // Taken while K <= 16 (|b_z| up to metres); beyond, or with FFTVIS_HIP_NO_WTERM=1, the 3-D transform runs.
     int wt_K = 0;   // terms of the current run (0: no expansion)
     double wt_zc = 0.0, wt_zh = 0.0, wt_a = 0.0;
+    // Light terms: term k enters with weight |c_k| <= 2 (a / 2)^k / k!, so the higher terms need far less than the run's
+    // tolerance -- with a = 0.35 (3 cm of scatter at 200 MHz) |c_2| = 0.03, |c_4| = 8e-5.  The terms k >= wt_k0 run on a
+    // second plan at wt_eps_l = 0.3 eps / sum_{k >= k0} |c_k| and sigma = 1.25 (a grid of 0.39 x the cells: the FFT passes
+    // are the bulk of a term), chosen as the smallest k0 whose tolerance is above that sigma's floor by a decade; fp64,
+    // runs at sigma = 2 on large grids only.  wt_k0 = 0: every term on the run's own plan.  FFTVIS_HIP_NO_WTERM_LIGHT=1.
+    int wt_k0 = 0;
+    double wt_eps_l = 0.0;
     int run_D = 2;  // dimensions of the current run's transforms
 
     size_t ev_slot(int kind) {
@@ -1428,6 +1438,7 @@ class Sim : public SimBase {
         (void)hipSetDevice(device);
         for (Lane &L : lanes) {
             L.nufft.reset();
+            L.nufft_l.reset();
             if (L.done) (void)hipEventDestroy(L.done);
             if (L.prep_done) (void)hipEventDestroy(L.prep_done);
             if (L.heavy_done) (void)hipEventDestroy(L.heavy_done);
@@ -1819,6 +1830,7 @@ class Sim : public SimBase {
     };
     std::vector<std::unique_ptr<ColPlan>> col_plans;
     std::vector<ColPlan *> col_plan_of;  // [group * pairs + pair] of the current run
+    std::vector<ColPlan *> col_plan_of_l;  // the same for the light height terms' plan (wt_k0)
     ColPlan *column_plan(int pi, const Pair &pr, int fa, int fb, Nufft3<T> *n0) {
         const DimGeom &x = n0->geo.d[0], &y = n0->geo.d[1];
         const int w = n0->ker.w;
@@ -2507,6 +2519,26 @@ class Sim : public SimBase {
                 wt_a = a;
             }
         }
+        wt_k0 = 0;
+        wt_eps_l = 0.0;
+        if (wt_K >= 3 && sizeof(T) == 8 && this->sigma == 2.0 && !std::getenv("FFTVIS_HIP_NO_WTERM_LIGHT")) {
+            std::vector<double> ck(wt_K);
+            double c = 1.0;  // (a / 2)^k / k!
+            for (int k = 0; k < wt_K; ++k) {
+                ck[k] = (k ? 2.0 : 1.0) * c;
+                c *= 0.5 * wt_a / (k + 1);
+            }
+            for (int k0 = 1; k0 + 2 <= wt_K; ++k0) {  // at least two light terms
+                double sl = 0;
+                for (int k = k0; k < wt_K; ++k) sl += ck[k];
+                const double el = 0.3 * eps / sl;
+                if (el >= 1e-7) {
+                    wt_k0 = k0;
+                    wt_eps_l = std::min(el, 1e-2);
+                    break;
+                }
+            }
+        }
         const int D = wt_K ? 2 : dim();
         run_D = D;
         st[15] = wt_K;
@@ -2722,6 +2754,11 @@ class Sim : public SimBase {
                     lanes[li].own_stream = true;
                 }
         }
+        {  // (sigma = 1.25 pays on large grids only, as in the automatic choice; FFTVIS_HIP_WTERM_LIGHT_CELLS moves the bound: tests)
+            const char *elc = std::getenv("FFTVIS_HIP_WTERM_LIGHT_CELLS");
+            if (wt_k0 > 0 && cells_top < (elc ? std::atof(elc) : 4.0e6)) wt_k0 = 0;
+        }
+        st[18] = wt_k0;
         for (int li = 0; li < nlanes_used; ++li) {
             Lane &L = lanes[li];
             // height terms: term k enters with weight a^k / k!, each with the transform's relative error -- the plans run
@@ -2734,6 +2771,15 @@ class Sim : public SimBase {
             L.nufft->disc_radius = (D == 2 || L.nufft->zdirect) && !std::getenv("FFTVIS_HIP_NO_DISC") ? 2.0 * M_PI : 0.0;
             L.nufft->transpose_flipped = !reference_compat;
             if (li > 0) L.nufft->order_cache = lanes[0].nufft->order_cache;  // one table per grid size for all lanes
+            if (wt_k0 > 0) {  // the light height terms' plan
+                if (!L.nufft_l || L.nufft_l->eps != wt_eps_l)
+                    L.nufft_l.reset(new Nufft3<T>(2, wt_eps_l, 1.25, li < 2 || !pipe ? L.stream : stream));
+                L.nufft_l->err_oob = d_err.as<int>();
+                L.nufft_l->disc_radius = L.nufft->disc_radius;
+                L.nufft_l->transpose_flipped = !reference_compat;
+                if (li > 0) L.nufft_l->order_cache = lanes[0].nufft_l->order_cache;
+                L.binned_ti_l = -1;
+            }
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
             L.d_az.reserve(sizeof(T) * cap);
             L.d_za.reserve(sizeof(T) * cap);
@@ -2767,6 +2813,26 @@ class Sim : public SimBase {
                 lanes[li].nufft->reserve_buffers(need, na_max, n2_max);
                 lanes[li].nufft->strengths_buffer_reserve(cap, (int)need_str);
             }
+            if (wt_k0 > 0) {  // the light height terms' plan: its own (smaller) grids
+                int64_t need_l = 0;
+                int na_l[3] = {8, 8, 8}, n2_l[3] = {64, 64, 64};
+                for (const auto &grp : groups) {
+                    double smax = 0;
+                    for (int f = grp.first; f < grp.second; ++f) smax = std::max(smax, std::fabs(freqs[f]));
+                    for (const Pair &pr : pairs) {
+                        if (pr.n == 0) continue;
+                        const int ntrans = (grp.second - grp.first) * (pr.herm ? 2 : tpol);
+                        for (double sl : {0.0, -1.0}) {
+                            lanes[0].nufft_l->grid_slack = sl;
+                            need_l = std::max(need_l, lanes[0].nufft_l->plan_buffer_cells(X, pr.box_B(), smax, na_l, n2_l) * ntrans);
+                        }
+                    }
+                }
+                for (int li = 0; li < nlanes_used; ++li) {
+                    lanes[li].nufft_l->reserve_buffers(need_l, na_l, n2_l);
+                    lanes[li].nufft_l->strengths_buffer_reserve(cap, (int)need_str);
+                }
+            }
             // column plans of every (group, pair), from the geometry the run will set (large 2-D grids only)
             col_plan_of.assign(groups.size() * pairs.size(), nullptr);
             // plans of earlier target sets / groupings pile up in a long-lived handle: start over now and then (here,
@@ -2790,6 +2856,23 @@ class Sim : public SimBase {
                     }
                 }
                 FV_HIP(hipStreamSynchronize(n0->stream));  // the table kernels of these set_geometry calls are done before the run's own
+            }
+            col_plan_of_l.assign(groups.size() * pairs.size(), nullptr);
+            if (wt_k0 > 0 && !std::getenv("FFTVIS_HIP_NO_COLUMN_PLAN")) {
+                Nufft3<T> *n0 = lanes[0].nufft_l.get();
+                for (size_t gi = 0; gi < groups.size(); ++gi) {
+                    double smax = 0;
+                    for (int f = groups[gi].first; f < groups[gi].second; ++f) smax = std::max(smax, std::fabs(freqs[f]));
+                    for (size_t pi = 0; pi < pairs.size(); ++pi) {
+                        const Pair &pr = pairs[pi];
+                        if (pr.n == 0) continue;
+                        n0->grid_slack = 0.0;
+                        n0->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
+                        if (!n0->columns_possible() || n0->geo.cells_o() < 4000000) continue;
+                        col_plan_of_l[gi * pairs.size() + pi] = column_plan((int)pi, pr, groups[gi].first, groups[gi].second, n0);
+                    }
+                }
+                FV_HIP(hipStreamSynchronize(n0->stream));
             }
         }
         if (dbg_t) std::fprintf(stderr, "run: buffers and column plans %.3f s\n", pin.since());
@@ -2851,7 +2934,6 @@ class Sim : public SimBase {
             Lane &L0 = *Ls[0];
             const hipStream_t ls = pipe ? stream : L0.stream;        // big kernels
             const hipStream_t ps = pipe ? prep_stream : L0.stream;   // per-time preparation
-            Nufft3<T> *mate = nm == 2 ? Ls[1]->nufft.get() : nullptr;
             bool sampled = false, heavy_recorded = false;
             for (int m = 0; m < nm; ++m) sampled = sampled || (tu + m - t0) % TIMING_STRIDE == sample_step;
             // ---- per-time: rotate, horizon cut, az/za, 2 pi R topo --------------------------
@@ -2899,8 +2981,10 @@ class Sim : public SimBase {
                 FV_HIP(hipEventRecord(L0.prep_done, ps));
                 FV_HIP(hipStreamWaitEvent(ls, L0.prep_done, 0));
             }
-            for (int m = 0; m < nm; ++m) Ls[m]->nufft->stream = ls;
-            Nufft3<T> *nufft = L0.nufft.get();
+            for (int m = 0; m < nm; ++m) {
+                Ls[m]->nufft->stream = ls;
+                if (wt_k0 > 0) Ls[m]->nufft_l->stream = ls;
+            }
 
             for (const auto &grp : groups) {
                 const int fa = grp.first, fb = grp.second, nfg = fb - fa;
@@ -2913,38 +2997,46 @@ class Sim : public SimBase {
                     // height terms (wt_K): one round of strengths -> spread -> FFT -> gather per term, the gather adding
                     // term k with every baseline's own factor; otherwise a single round
                     for (int kt = 0; kt < std::max(1, wt_K); ++kt) {
+                    // the plan of this term: the run's own, or the light terms' (wt_k0)
+                    const bool light = wt_k0 > 0 && kt >= wt_k0;
+                    auto plan_of = [&](Lane &L) { return light ? L.nufft_l.get() : L.nufft.get(); };
+                    const std::vector<ColPlan *> &cplans = light ? col_plan_of_l : col_plan_of;
+                    Nufft3<T> *nufft = plan_of(L0);
+                    Nufft3<T> *mate = nm == 2 ? plan_of(*Ls[1]) : nullptr;
                     for (int m = 0; m < nm; ++m) {
                         Lane &L = *Ls[m];
-                        Nufft3<T> *nf_ = L.nufft.get();
+                        Nufft3<T> *nf_ = plan_of(L);
+                        int &b_ti = light ? L.binned_ti_l : L.binned_ti;
+                        int64_t &b_serial = light ? L.binned_serial_l : L.binned_serial;
                         // ---- geometry + bin sort (skipped when unchanged since last set) -------
                         RoctxRange rr("prep");
                         size_t e1 = ev_begin(TM_PREP, ls);
                         {
-                            const ColPlan *cpq = col_plan_of[(size_t)(&grp - groups.data()) * pairs.size() + (size_t)(&pr - pairs.data())];
+                            const ColPlan *cpq = cplans[(size_t)(&grp - groups.data()) * pairs.size() + (size_t)(&pr - pairs.data())];
                             nf_->grid_slack = cpq && cpq->use ? 0.0 : -1.0;
                         }
                         nf_->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
-                        if (L.binned_ti != (tu + m) * nch + chunk || L.binned_serial != nf_->geom_serial || nf_->M != M) {
+                        if (b_ti != (tu + m) * nch + chunk || b_serial != nf_->geom_serial || nf_->M != M) {
                             nf_->set_sources(M, L.d_xyz.template as<T>(), L.d_xyz.template as<T>() + cap,
                                              D > 2 ? L.d_xyz.template as<T>() + 2 * cap : nullptr, Mps[m]);
-                            L.binned_ti = (tu + m) * nch + chunk;
-                            L.binned_serial = nf_->geom_serial;
+                            b_ti = (tu + m) * nch + chunk;
+                            b_serial = nf_->geom_serial;
                         }
                         ev_end(e1, ls);
                         // ---- strengths (already queued with the preparation for the first pair) -------
                         if (!(strengths_ahead && &grp == &groups.front() && &pr == first_pair && kt == 0))
-                            launch_strengths(L, pr, fa, nfg, M, Mps[m], ls, kt);
+                            launch_strengths(L, pr, fa, nfg, M, Mps[m], ls, kt, nf_);
                     }
                     // ---- NUFFT ----------------------------------------------------------
                     {
-                        ColPlan *cp = col_plan_of[(size_t)(&grp - groups.data()) * pairs.size() + (size_t)(&pr - pairs.data())];
+                        ColPlan *cp = cplans[(size_t)(&grp - groups.data()) * pairs.size() + (size_t)(&pr - pairs.data())];
                         const bool on = cp && cp->use;
                         for (int m = 0; m < nm; ++m) {
-                            Ls[m]->nufft->arm_columns(on ? cp->tab.template as<int>() : nullptr, on ? cp->xtab.template as<int>() : nullptr, tg,
+                            plan_of(*Ls[m])->arm_columns(on ? cp->tab.template as<int>() : nullptr, on ? cp->xtab.template as<int>() : nullptr, tg,
                                                       on ? cp->ncc : 0, d_err.as<int>() + 3,
                                                       on && cp->omask.p ? cp->omask.template as<unsigned long long>() : nullptr,
                                                       on ? cp->nblk : 0);
-                            Ls[m]->nufft->col_out_cells = on && cp->omask.p ? cp->out_cells : 0.0;
+                            plan_of(*Ls[m])->col_out_cells = on && cp->omask.p ? cp->out_cells : 0.0;
                         }
                     }
                     {
@@ -2998,7 +3090,7 @@ class Sim : public SimBase {
                             for (int part = 1; part <= nparts; ++part) {
                                 bt.part = nparts == 2 ? part : 0;
                                 bt.negate = nparts == 2 && part == 2;
-                                Ls[m]->nufft->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
+                                plan_of(*Ls[m])->interp(pr.n, d_bls.as<T>(), d_bls.as<T>() + nbls,
                                       D > 2 ? d_bls.as<T>() + 2 * nbls : nullptr,
                                       pr.trivial ? nullptr : pr.idx->template as<int>(),
                                       pr.trivial ? nullptr : pr.flip->template as<signed char>(),
@@ -3009,12 +3101,14 @@ class Sim : public SimBase {
                             }
                     ev_end(e5, ls);
                     st[4] += (double)(pr.upairs ? pr.nitems : pr.ustart ? pr.nu : pr.n) * ntrans * nm * (pr.herm ? 2 : 1);  // footprints gathered: distinct targets; packed transforms are read at s and -s
-                    st[6] = nufft->geo.d[0].n2;
-                    st[7] = nufft->geo.d[1].n2;
-                    st[8] = nufft->geo.d[0].na * 65536.0 + nufft->geo.d[1].na;
-                    st[13] = D > 2 ? nufft->geo.d[2].n2 : 1;
-                    st[14] = D > 2 ? nufft->geo.d[2].na : 1;
-                    st[9] = nufft->ker.w;
+                    if (!light) {  // (the run's own plan describes the run)
+                        st[6] = nufft->geo.d[0].n2;
+                        st[7] = nufft->geo.d[1].n2;
+                        st[8] = nufft->geo.d[0].na * 65536.0 + nufft->geo.d[1].na;
+                        st[13] = D > 2 ? nufft->geo.d[2].n2 : 1;
+                        st[14] = D > 2 ? nufft->geo.d[2].na : 1;
+                        st[9] = nufft->ker.w;
+                    }
                     }  // height terms
                 }
             }
@@ -3068,8 +3162,9 @@ class Sim : public SimBase {
     }
 
     // beam x coherency strengths of one (frequency group, beam pair) for the lane's current sources
-    void launch_strengths(Lane &L, const Pair &pr, int fa, int nfg, int64_t M, const int *Mp, hipStream_t on, int wt_k = 0) {
-        Nufft3<T> *nufft = L.nufft.get();
+    void launch_strengths(Lane &L, const Pair &pr, int fa, int nfg, int64_t M, const int *Mp, hipStream_t on, int wt_k = 0,
+                          Nufft3<T> *plan = nullptr) {
+        Nufft3<T> *nufft = plan ? plan : L.nufft.get();
         const int D = run_D;
         RoctxRange rr("strengths");
         size_t e2 = ev_begin(TM_STRENGTHS, on);

@@ -249,7 +249,9 @@ int fv_sim_sync(fv_sim *h);
  * expansion -- coplanar, or the 3-D transform), [16] lanes of the last type-3 run (2: consecutive time steps alternate
  * between two sets of scratch and grid buffers), [17] how they ran: 0 freely on two streams of equal priority (large
  * grids: the kernels of two time steps share the GPU, and kernel durations are those of kernels sharing it), 1
- * pipelined (big kernels in order on one stream, the next step's preparation beside them), 2 pipelined gangs.   */
+ * pipelined (big kernels in order on one stream, the next step's preparation beside them), 2 pipelined gangs,
+ * [18] first LIGHT height term of the last run (terms k >= this ran on a second plan at a looser tolerance and
+ * upsampling factor 1.25: they enter with weights 2 |J_k|; 0: none).                                               */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,

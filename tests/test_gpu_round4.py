@@ -328,8 +328,11 @@ def test_fuzz_heights_from_millimetres_to_metres(gpu, monkeypatch):
     from fftvis_amd.gpu import gpu_simulate
 
     monkeypatch.setenv("FFTVIS_HIP_HANDLE_CACHE_BYTES", str(2**40))
+    # the light terms' second plan (looser tolerance, upsampling 1.25) is for large grids: here on these small ones too
+    monkeypatch.setenv("FFTVIS_HIP_WTERM_LIGHT_CELLS", "0")
     rng = np.random.default_rng(404)
     kinds = set()
+    light = 0
     for it in range(64):
         nant = int(rng.integers(4, 12))
         ext = float(np.exp(rng.uniform(np.log(10), np.log(400))))
@@ -362,10 +365,35 @@ def test_fuzz_heights_from_millimetres_to_metres(gpu, monkeypatch):
         got = fftvis_amd.simulate_vis(**cfg)
         st = _last_handle_stats()
         kinds.add("K" if st["height_terms"] else "3-D" if st["n2_3"] > 1 else "2-D")
+        light += st["height_terms_light_from"] > 0
         err = rel_l2(got, oracle_simulate(cfg))
-        assert err < 10 * eps + 1e-12, (it, err, eps, zs, st["height_terms"], pol, nbeam)
+        assert err < 10 * eps + 1e-12, (it, err, eps, zs, st["height_terms"], st["height_terms_light_from"], pol, nbeam)
     gpu_simulate.release_handles()
     assert kinds == {"K", "3-D", "2-D"} or kinds == {"K", "3-D"}, kinds
+    assert light >= 10, light  # (18 000 configurations of scratch/fuzz_r4.py with this switch: half took the light plan, 2 beyond 10 eps -- a plain 2-D run and an fp32 one)
+
+
+def test_light_height_terms_on_a_large_grid(gpu, monkeypatch):
+    """The higher height terms enter with weights 2 |J_k(a)| -- 0.03 for k = 2, 8e-5 for k = 4 at 3 cm of scatter -- and
+    run on a second plan at a looser tolerance and upsampling factor 1.25 (`Sim::wt_k0`): HERA-350 with 3 cm of height
+    scatter takes it by itself (the grid is large), agrees with the run that keeps every term on the full plan far
+    inside the tolerance, and both agree with the oracle's exact 3-D sums on a subset of the baselines."""
+    from fftvis_amd.gpu import gpu_simulate
+
+    cfg = synth.make_config("C3", nsrc=3000, nfreq=2, ntimes=1, z_scatter=0.03)
+    sub = sorted(np.random.default_rng(1).choice(61075, 64, replace=False))
+    gpu_simulate.release_handles()
+    got = fftvis_amd.simulate_vis(**cfg)
+    st = _last_handle_stats()
+    assert st["height_terms"] >= 5 and 1 <= st["height_terms_light_from"] <= st["height_terms"] - 2, st
+    exp = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
+    assert rel_l2(got[..., sub], exp) < TOL
+    monkeypatch.setenv("FFTVIS_HIP_NO_WTERM_LIGHT", "1")
+    gpu_simulate.release_handles()
+    full = fftvis_amd.simulate_vis(**cfg)
+    assert _last_handle_stats()["height_terms_light_from"] == 0
+    gpu_simulate.release_handles()
+    assert rel_l2(got, full) < 0.3 * cfg["eps"]
 
 
 @pytest.mark.parametrize("order", [0, 2, 4, 5])
