@@ -1300,12 +1300,12 @@ class Sim : public SimBase {
         hipEvent_t prep_done = nullptr, heavy_done = nullptr;  // pipelined mode (see run())
         bool heavy_pending = false;
         std::unique_ptr<Nufft3<T>> nufft;
-        std::unique_ptr<Nufft3<T>> nufft_l;  // the plan of the LIGHT height terms (see Sim::wt_k0): looser tolerance, sigma = 1.25
+        std::unique_ptr<Nufft3<T>> nufft_l[2];  // the plans of the LIGHT height terms (see Sim::wt_k0): looser tolerances, sigma = 1.25
         DevBuf d_xyz, d_az, d_za, d_srcidx, d_blockcnt, d_blockoff, d_scan_tot, d_scan_off, d_enu;
         int binned_ti = -1;
         int64_t binned_serial = -1;
-        int binned_ti_l = -1;  // the same for nufft_l
-        int64_t binned_serial_l = -1;
+        int binned_ti_l[2] = {-1, -1};  // the same for nufft_l
+        int64_t binned_serial_l[2] = {-1, -1};
     };
     Lane lanes[4];  // [2], [3]: second pair of the gang mode (see run())
     int lane_mode = -1;       // 0 one stream per lane, 1 pipelined, 2 pipelined gangs: what the lanes last ran as
@@ -1365,8 +1365,11 @@ class Sim : public SimBase {
     // second plan at wt_eps_l = 0.3 eps / sum_{k >= k0} |c_k| and sigma = 1.25 (a grid of 0.39 x the cells: the FFT passes
     // are the bulk of a term), chosen as the smallest k0 whose tolerance is above that sigma's floor by a decade; fp64,
     // runs at sigma = 2 on large grids only.  wt_k0 = 0: every term on the run's own plan.  FFTVIS_HIP_NO_WTERM_LIGHT=1.
-    int wt_k0 = 0;
-    double wt_eps_l = 0.0;
+    // Where the tail of the light terms can take a tolerance of 1e-4 or looser (a kernel of 8 cells instead of 12: the
+    // gather of a light term is most of its time) the light terms split in two classes, [k0, k1) and [k1, K), with half
+    // of the budget each; wt_k1 = wt_K: one class.
+    int wt_k0 = 0, wt_k1 = 0;
+    double wt_eps_l[2] = {0.0, 0.0};
     int run_D = 2;  // dimensions of the current run's transforms
 
     size_t ev_slot(int kind) {
@@ -1438,7 +1441,8 @@ class Sim : public SimBase {
         (void)hipSetDevice(device);
         for (Lane &L : lanes) {
             L.nufft.reset();
-            L.nufft_l.reset();
+            L.nufft_l[0].reset();
+            L.nufft_l[1].reset();
             if (L.done) (void)hipEventDestroy(L.done);
             if (L.prep_done) (void)hipEventDestroy(L.prep_done);
             if (L.heavy_done) (void)hipEventDestroy(L.heavy_done);
@@ -1830,7 +1834,7 @@ class Sim : public SimBase {
     };
     std::vector<std::unique_ptr<ColPlan>> col_plans;
     std::vector<ColPlan *> col_plan_of;  // [group * pairs + pair] of the current run
-    std::vector<ColPlan *> col_plan_of_l;  // the same for the light height terms' plan (wt_k0)
+    std::vector<ColPlan *> col_plan_of_l[2];  // the same for the light height terms' plans (wt_k0, wt_k1)
     ColPlan *column_plan(int pi, const Pair &pr, int fa, int fb, Nufft3<T> *n0) {
         const DimGeom &x = n0->geo.d[0], &y = n0->geo.d[1];
         const int w = n0->ker.w;
@@ -2520,7 +2524,8 @@ class Sim : public SimBase {
             }
         }
         wt_k0 = 0;
-        wt_eps_l = 0.0;
+        wt_k1 = wt_K;
+        wt_eps_l[0] = wt_eps_l[1] = 0.0;
         if (wt_K >= 3 && sizeof(T) == 8 && this->sigma == 2.0 && !std::getenv("FFTVIS_HIP_NO_WTERM_LIGHT")) {
             std::vector<double> ck(wt_K);
             double c = 1.0;  // (a / 2)^k / k!
@@ -2534,8 +2539,23 @@ class Sim : public SimBase {
                 const double el = 0.3 * eps / sl;
                 if (el >= 1e-7) {
                     wt_k0 = k0;
-                    wt_eps_l = std::min(el, 1e-2);
+                    wt_eps_l[0] = std::min(el, 1e-2);
                     break;
+                }
+            }
+            // a second class for the tail, where it can run at 1e-4 or looser: half of the light budget each
+            if (wt_k0 > 0 && !std::getenv("FFTVIS_HIP_WTERM_ONE_LIGHT_CLASS")) {
+                for (int k1 = wt_k0 + 1; k1 + 2 <= wt_K; ++k1) {
+                    double s2 = 0, s1 = 0;
+                    for (int k = k1; k < wt_K; ++k) s2 += ck[k];
+                    for (int k = wt_k0; k < k1; ++k) s1 += ck[k];
+                    const double e2 = 0.15 * eps / s2, e1 = 0.15 * eps / s1;
+                    if (e2 >= 1e-4 && e1 >= 1e-7) {
+                        wt_k1 = k1;
+                        wt_eps_l[0] = std::min(e1, 1e-2);
+                        wt_eps_l[1] = std::min(e2, 1e-2);
+                        break;
+                    }
                 }
             }
         }
@@ -2758,7 +2778,10 @@ class Sim : public SimBase {
             const char *elc = std::getenv("FFTVIS_HIP_WTERM_LIGHT_CELLS");
             if (wt_k0 > 0 && cells_top < (elc ? std::atof(elc) : 4.0e6)) wt_k0 = 0;
         }
+        if (wt_k0 == 0) wt_k1 = wt_K;
         st[18] = wt_k0;
+        st[19] = wt_k0 > 0 && wt_k1 < wt_K ? wt_k1 : 0;
+        const int nlc = wt_k0 == 0 ? 0 : wt_k1 < wt_K ? 2 : 1;  // light classes of this run
         for (int li = 0; li < nlanes_used; ++li) {
             Lane &L = lanes[li];
             // height terms: term k enters with weight a^k / k!, each with the transform's relative error -- the plans run
@@ -2771,14 +2794,14 @@ class Sim : public SimBase {
             L.nufft->disc_radius = (D == 2 || L.nufft->zdirect) && !std::getenv("FFTVIS_HIP_NO_DISC") ? 2.0 * M_PI : 0.0;
             L.nufft->transpose_flipped = !reference_compat;
             if (li > 0) L.nufft->order_cache = lanes[0].nufft->order_cache;  // one table per grid size for all lanes
-            if (wt_k0 > 0) {  // the light height terms' plan
-                if (!L.nufft_l || L.nufft_l->eps != wt_eps_l)
-                    L.nufft_l.reset(new Nufft3<T>(2, wt_eps_l, 1.25, li < 2 || !pipe ? L.stream : stream));
-                L.nufft_l->err_oob = d_err.as<int>();
-                L.nufft_l->disc_radius = L.nufft->disc_radius;
-                L.nufft_l->transpose_flipped = !reference_compat;
-                if (li > 0) L.nufft_l->order_cache = lanes[0].nufft_l->order_cache;
-                L.binned_ti_l = -1;
+            for (int c = 0; c < nlc; ++c) {  // the light height terms' plans
+                if (!L.nufft_l[c] || L.nufft_l[c]->eps != wt_eps_l[c])
+                    L.nufft_l[c].reset(new Nufft3<T>(2, wt_eps_l[c], 1.25, li < 2 || !pipe ? L.stream : stream));
+                L.nufft_l[c]->err_oob = d_err.as<int>();
+                L.nufft_l[c]->disc_radius = L.nufft->disc_radius;
+                L.nufft_l[c]->transpose_flipped = !reference_compat;
+                if (li > 0) L.nufft_l[c]->order_cache = lanes[0].nufft_l[c]->order_cache;
+                L.binned_ti_l[c] = -1;
             }
             L.d_xyz.reserve(sizeof(T) * 3 * cap);
             L.d_az.reserve(sizeof(T) * cap);
@@ -2813,7 +2836,7 @@ class Sim : public SimBase {
                 lanes[li].nufft->reserve_buffers(need, na_max, n2_max);
                 lanes[li].nufft->strengths_buffer_reserve(cap, (int)need_str);
             }
-            if (wt_k0 > 0) {  // the light height terms' plan: its own (smaller) grids
+            for (int c = 0; c < nlc; ++c) {  // the light height terms' plans: their own (smaller) grids
                 int64_t need_l = 0;
                 int na_l[3] = {8, 8, 8}, n2_l[3] = {64, 64, 64};
                 for (const auto &grp : groups) {
@@ -2823,14 +2846,14 @@ class Sim : public SimBase {
                         if (pr.n == 0) continue;
                         const int ntrans = (grp.second - grp.first) * (pr.herm ? 2 : tpol);
                         for (double sl : {0.0, -1.0}) {
-                            lanes[0].nufft_l->grid_slack = sl;
-                            need_l = std::max(need_l, lanes[0].nufft_l->plan_buffer_cells(X, pr.box_B(), smax, na_l, n2_l) * ntrans);
+                            lanes[0].nufft_l[c]->grid_slack = sl;
+                            need_l = std::max(need_l, lanes[0].nufft_l[c]->plan_buffer_cells(X, pr.box_B(), smax, na_l, n2_l) * ntrans);
                         }
                     }
                 }
                 for (int li = 0; li < nlanes_used; ++li) {
-                    lanes[li].nufft_l->reserve_buffers(need_l, na_l, n2_l);
-                    lanes[li].nufft_l->strengths_buffer_reserve(cap, (int)need_str);
+                    lanes[li].nufft_l[c]->reserve_buffers(need_l, na_l, n2_l);
+                    lanes[li].nufft_l[c]->strengths_buffer_reserve(cap, (int)need_str);
                 }
             }
             // column plans of every (group, pair), from the geometry the run will set (large 2-D grids only)
@@ -2857,9 +2880,9 @@ class Sim : public SimBase {
                 }
                 FV_HIP(hipStreamSynchronize(n0->stream));  // the table kernels of these set_geometry calls are done before the run's own
             }
-            col_plan_of_l.assign(groups.size() * pairs.size(), nullptr);
-            if (wt_k0 > 0 && !std::getenv("FFTVIS_HIP_NO_COLUMN_PLAN")) {
-                Nufft3<T> *n0 = lanes[0].nufft_l.get();
+            for (int c = 0; c < 2; ++c) col_plan_of_l[c].assign(groups.size() * pairs.size(), nullptr);
+            for (int c = 0; c < nlc && !std::getenv("FFTVIS_HIP_NO_COLUMN_PLAN"); ++c) {
+                Nufft3<T> *n0 = lanes[0].nufft_l[c].get();
                 for (size_t gi = 0; gi < groups.size(); ++gi) {
                     double smax = 0;
                     for (int f = groups[gi].first; f < groups[gi].second; ++f) smax = std::max(smax, std::fabs(freqs[f]));
@@ -2869,7 +2892,7 @@ class Sim : public SimBase {
                         n0->grid_slack = 0.0;
                         n0->set_geometry(xc, X, pr.box_c(), pr.box_B(), smax);
                         if (!n0->columns_possible() || n0->geo.cells_o() < 4000000) continue;
-                        col_plan_of_l[gi * pairs.size() + pi] = column_plan((int)pi, pr, groups[gi].first, groups[gi].second, n0);
+                        col_plan_of_l[c][gi * pairs.size() + pi] = column_plan((int)pi, pr, groups[gi].first, groups[gi].second, n0);
                     }
                 }
                 FV_HIP(hipStreamSynchronize(n0->stream));
@@ -2983,7 +3006,7 @@ class Sim : public SimBase {
             }
             for (int m = 0; m < nm; ++m) {
                 Ls[m]->nufft->stream = ls;
-                if (wt_k0 > 0) Ls[m]->nufft_l->stream = ls;
+                for (int c = 0; c < nlc; ++c) Ls[m]->nufft_l[c]->stream = ls;
             }
 
             for (const auto &grp : groups) {
@@ -2999,15 +3022,16 @@ class Sim : public SimBase {
                     for (int kt = 0; kt < std::max(1, wt_K); ++kt) {
                     // the plan of this term: the run's own, or the light terms' (wt_k0)
                     const bool light = wt_k0 > 0 && kt >= wt_k0;
-                    auto plan_of = [&](Lane &L) { return light ? L.nufft_l.get() : L.nufft.get(); };
-                    const std::vector<ColPlan *> &cplans = light ? col_plan_of_l : col_plan_of;
+                    const int lc = light && kt >= wt_k1 ? 1 : 0;  // its class
+                    auto plan_of = [&](Lane &L) { return light ? L.nufft_l[lc].get() : L.nufft.get(); };
+                    const std::vector<ColPlan *> &cplans = light ? col_plan_of_l[lc] : col_plan_of;
                     Nufft3<T> *nufft = plan_of(L0);
                     Nufft3<T> *mate = nm == 2 ? plan_of(*Ls[1]) : nullptr;
                     for (int m = 0; m < nm; ++m) {
                         Lane &L = *Ls[m];
                         Nufft3<T> *nf_ = plan_of(L);
-                        int &b_ti = light ? L.binned_ti_l : L.binned_ti;
-                        int64_t &b_serial = light ? L.binned_serial_l : L.binned_serial;
+                        int &b_ti = light ? L.binned_ti_l[lc] : L.binned_ti;
+                        int64_t &b_serial = light ? L.binned_serial_l[lc] : L.binned_serial;
                         // ---- geometry + bin sort (skipped when unchanged since last set) -------
                         RoctxRange rr("prep");
                         size_t e1 = ev_begin(TM_PREP, ls);

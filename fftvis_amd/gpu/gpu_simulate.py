@@ -236,12 +236,12 @@ class SimHandle:
         _lib.check(self._L.fv_sim_sync(self._h))
 
     def stats(self):
-        v = np.zeros(19)
-        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 19))
+        v = np.zeros(20)
+        _lib.check(self._L.fv_sim_stats(self._h, _lib.ptr(v), 20))
         # ("n2z" is historical: active cells na_x * 65536 + na_y; the third dimension's sizes are n2_3 / na_3)
         keys = ["spread_launches", "spread_cells", "source_visits", "fft_cells", "interp_items",
                 "sources_above_horizon", "n2x", "n2y", "n2z", "w", "upsample_used", "max_above_horizon", "fft_flops",
-                "n2_3", "na_3", "height_terms", "lanes", "lane_mode", "height_terms_light_from"]
+                "n2_3", "na_3", "height_terms", "lanes", "lane_mode", "height_terms_light_from", "height_terms_lighter_from"]
         return dict(zip(keys, v))
 
     def reset_stats(self):

@@ -251,7 +251,8 @@ int fv_sim_sync(fv_sim *h);
  * grids: the kernels of two time steps share the GPU, and kernel durations are those of kernels sharing it), 1
  * pipelined (big kernels in order on one stream, the next step's preparation beside them), 2 pipelined gangs,
  * [18] first LIGHT height term of the last run (terms k >= this ran on a second plan at a looser tolerance and
- * upsampling factor 1.25: they enter with weights 2 |J_k|; 0: none).                                               */
+ * upsampling factor 1.25: they enter with weights 2 |J_k|; 0: none), [19] first term of a second, looser light class
+ * (0: one class).                                                                                                   */
 int fv_sim_stats(fv_sim *h, double *vals, int n);
 int fv_sim_reset_stats(fv_sim *h);
 /* HIP-event timing on the handle's stream (ms, summed since reset): [0] spread, [1] fft,

@@ -386,6 +386,7 @@ def test_light_height_terms_on_a_large_grid(gpu, monkeypatch):
     got = fftvis_amd.simulate_vis(**cfg)
     st = _last_handle_stats()
     assert st["height_terms"] >= 5 and 1 <= st["height_terms_light_from"] <= st["height_terms"] - 2, st
+    assert st["height_terms_light_from"] < st["height_terms_lighter_from"] <= st["height_terms"] - 2, st  # two light classes here
     exp = oracle_simulate(dict(cfg, baselines=[cfg["baselines"][i] for i in sub]))
     assert rel_l2(got[..., sub], exp) < TOL
     monkeypatch.setenv("FFTVIS_HIP_NO_WTERM_LIGHT", "1")
@@ -394,6 +395,13 @@ def test_light_height_terms_on_a_large_grid(gpu, monkeypatch):
     assert _last_handle_stats()["height_terms_light_from"] == 0
     gpu_simulate.release_handles()
     assert rel_l2(got, full) < 0.3 * cfg["eps"]
+    monkeypatch.delenv("FFTVIS_HIP_NO_WTERM_LIGHT")
+    monkeypatch.setenv("FFTVIS_HIP_WTERM_ONE_LIGHT_CLASS", "1")
+    one = fftvis_amd.simulate_vis(**cfg)
+    st1 = _last_handle_stats()
+    assert st1["height_terms_light_from"] > 0 and st1["height_terms_lighter_from"] == 0
+    gpu_simulate.release_handles()
+    assert rel_l2(one, full) < 0.3 * cfg["eps"]
 
 
 @pytest.mark.parametrize("order", [0, 2, 4, 5])
