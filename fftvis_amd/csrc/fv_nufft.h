@@ -528,7 +528,6 @@ __global__ __launch_bounds__(SPREAD_THREADS, FV_SPREAD_MINW) void k_spread2d(
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int e = lane + 64 * i;
             if (wj[i] < n) {
                 s_kw[wave][wj[i]][0][wk[i]] = pkx[i];
                 s_kw[wave][wj[i]][1][wk[i]] = pky[i];
@@ -871,7 +870,6 @@ __global__ __launch_bounds__(SPREAD_THREADS, TCH == 8 ? FV_SPREAD_MM_MINW8 : FV_
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int e = lane + 64 * i;
             if (wj[i] < n) {
                 s_kwx[wave][wj[i]][wk[i]] = pkx[i];
                 s_kwy[wave][wj[i]][wk[i]] = pky[i];
@@ -1745,7 +1743,6 @@ __global__ __launch_bounds__(st_threads(LOGQ, COL, PAIR), LOGQ == 12 && !COL ? F
     const int64_t rplane = row / a.rpp, rk = row % a.rpp;
     const bool ok_line = row < a.nrows && rk < a.rpp_valid;  // the line exists: its inputs are read
     const bool ok = ok_line && p < a.P;                      // ... and so does this thread's residue: outputs are stored
-    const int n2 = a.n2;
     ST *rb = smem + r * ROW;
     ST *rbi = DUAL ? rb + RPW * ROW : rb;
 
@@ -3500,8 +3497,6 @@ inline void rowfft_shape(const DimGeom &g, bool col, int &tpr, int &rpw) {
 // then padded to a multiple of 8 elements so that those 128-B segments are whole cache lines.
 template <typename T>
 int64_t Nufft3<T>::b_pitch() const {
-    const DimGeom &x = geo.d[0], &y = geo.d[1];
-    (void)y;
     // whole 128-B lines per workgroup (8 columns) or per pair of neighbouring workgroups (4 columns each;
     // giving such pairs consecutive slots on one XCD was measured to change nothing: 1.836 vs 1.833 ms)
     return y_reads_columns() ? (xcols() + 7) / 8 * 8 : xcols();
