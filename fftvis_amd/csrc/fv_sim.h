@@ -2784,8 +2784,8 @@ class Sim : public SimBase {
         const int nlc = wt_k0 == 0 ? 0 : wt_k1 < wt_K ? 2 : 1;  // light classes of this run
         for (int li = 0; li < nlanes_used; ++li) {
             Lane &L = lanes[li];
-            // height terms: term k enters with weight a^k / k!, each with the transform's relative error -- the plans run
-            // at eps / e^a so that the sum keeps eps
+            // height terms: term k enters with weight |c_k| <= 2 (a / 2)^k / k! (sum <= 2 e^{a/2} - 1), each with the
+            // transform's relative error -- the run's own plan takes eps / (2 e^{a/2} - 1) so that the sum keeps eps
             const double eps_plan = wt_K ? std::max(eps / (2.0 * std::exp(0.5 * wt_a) - 1.0), sizeof(T) == 8 ? 1e-14 : 1e-7) : eps;
             if (!L.nufft || L.nufft->dim != D || L.nufft->sigma != sigma || L.nufft->eps != eps_plan)
                 L.nufft.reset(new Nufft3<T>(D, eps_plan, sigma, li < 2 || !pipe ? L.stream : stream));
