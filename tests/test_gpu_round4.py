@@ -561,3 +561,56 @@ def test_either_import_order_leaves_one_hip_runtime(gpu):
         "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_integration_stub_call_sequence_with_raw_ctypes(gpu):
+    """INTEGRATION.md's stub, run as written -- `ctypes.CDLL` on the library, no `fftvis_amd._lib` / `SimHandle` in
+    between: create, sources, per-time rotations, frequencies, array, one Airy beam, one pair list, chunking, run, destroy
+    -- against the oracle (unpolarized C1)."""
+    import ctypes
+
+    from fftvis_amd import _lib
+    from fftvis_amd.core import coords, utils
+    from fftvis_amd.gpu.gpu_simulate import prepare_array
+
+    cfg = synth.make_config("C1", nsrc=200, nfreq=4, ntimes=2)
+    _lib.lib()  # (the library is built, and the wheel's HIP runtime is in: what an embedding host does once)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.fv_last_error.restype = ctypes.c_char_p
+
+    def ck(st):
+        if st:
+            raise RuntimeError(L.fv_last_error().decode())
+
+    def vp(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    eps, precision, polarized = 1e-9, 2, False
+    freqs64 = np.ascontiguousarray(cfg["freqs"], dtype=np.float64)
+    nsrc, nfreqs, ntimes = len(cfg["ra"]), len(freqs64), len(cfg["times"])
+    eq_xyz = np.ascontiguousarray(coords.eq_unit_vectors(cfg["ra"], cfg["dec"]))
+    coherency = np.ascontiguousarray(utils.prepare_source_catalog(cfg["fluxes"], polarized)[0], dtype=np.float64)
+    rot = np.ascontiguousarray(coords.SiderealRotation(cfg["times"], cfg["telescope_loc"]).matrices())
+    R, bls, is_coplanar = prepare_array(cfg["ants"], cfg["baselines"], 1e-6, np.float64)
+    nbls = bls.shape[1]
+    rotation_matrix64, bls_seconds64 = np.ascontiguousarray(R, dtype=np.float64), np.ascontiguousarray(bls, dtype=np.float64)
+    bi, bj = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    offsets = np.array([0, nbls], dtype=np.int64)
+    bl_idx, flipped = np.arange(nbls, dtype=np.int32), np.zeros(nbls, np.int8)
+
+    h = ctypes.c_void_p()
+    ck(L.fv_sim_create(ctypes.byref(h), 0, precision, ctypes.c_double(eps), ctypes.c_double(2.0), int(polarized)))
+    try:
+        ck(L.fv_sim_set_sources(h, ctypes.c_int64(nsrc), nfreqs, vp(eq_xyz), vp(coherency), 0, 0))
+        ck(L.fv_sim_set_times(h, ntimes, vp(rot)))
+        ck(L.fv_sim_set_freqs(h, nfreqs, vp(freqs64)))
+        ck(L.fv_sim_set_array(h, vp(rotation_matrix64), ctypes.c_int64(nbls), vp(bls_seconds64), int(is_coplanar)))
+        ck(L.fv_sim_set_nbeams(h, 1))
+        ck(L.fv_sim_set_beam_airy(h, 0, ctypes.c_double(cfg["beam"].diameter)))
+        ck(L.fv_sim_set_beam_pairs(h, 1, vp(bi), vp(bj), vp(offsets), vp(bl_idx), vp(flipped)))
+        ck(L.fv_sim_set_chunking(h, 1, ctypes.c_double(1.0)))
+        vis = np.empty((nfreqs, ntimes, nbls), np.complex128)
+        ck(L.fv_sim_run(h, 0, ntimes, 0, nfreqs, vp(vis), 0))
+    finally:
+        L.fv_sim_destroy(h)
+    assert rel_l2(vis, oracle_simulate(dict(cfg, eps=eps))) < 5 * eps
