@@ -596,6 +596,7 @@ def main():
                                      "active": [int(st["n2z"]) // 65536, int(st["n2z"]) % 65536] + ([int(st["na_3"])] if d == 3 else [])},
                 "kernel_width": int(st["w"]),
                 "height_terms": hterms,
+                "height_terms_light_from": [int(st.get("height_terms_light_from", 0)), int(st.get("height_terms_lighter_from", 0))],
             }
             if tm_all["fft"] > 0:
                 gbps = fft_bytes / (tm_all["fft"] * 1e-3) / 1e9

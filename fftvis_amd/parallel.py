@@ -385,6 +385,7 @@ class _SharedResult:
             dist.barrier()  # everybody has mapped it (or failed): the name can go
             if self.rank == self.owner:
                 os.unlink(self.path)
+            dist.barrier()  # ... and is gone when any rank returns (a fresh segment only: warm reuse skips all of this)
 
     def seal(self):
         """Every rank: all blocks are in.  Returns the result on the owner (an array over the shared pages; the
